@@ -1,0 +1,147 @@
+"""C3D2 speaker-embedding network on PyTorch-ROCm (the one piece of the hot
+path that is NOT hand-written HIP, by the north-star's decree).
+
+Mirrors `/root/reference/model.py:104-191`: same constructor arguments, same
+sub-module names (so a reference-format checkpoint's `state_dict` loads
+unchanged), same `forward(x, development=True)`, `load_checkpoint(d)` and
+`create_Speaker_Model(u)`.  Input convention `(batch, 1, 20, 80, 40)`
+(`/root/reference/utils.py:368-379`).
+
+What is different, on purpose, for MI355X inference:
+  * the network is described by one table and built in a loop;
+  * `fused_inference()` folds eval-mode BatchNorm into the convolution weights
+    and returns a lean callable for large-batch embedding extraction;
+  * nothing here hard-codes `.cuda()` or prints (cf. Q20).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# name suffix, in_ch (None = num_channels), out_ch, kernel, stride, maxpool after
+_LAYERS = (
+    ("1_1", None, 16, (3, 1, 5), (1, 1, 1), False),
+    ("1_2", 16, 16, (3, 9, 1), (1, 2, 1), True),
+    ("2_1", 16, 32, (3, 1, 4), (1, 1, 1), False),
+    ("2_2", 32, 32, (3, 8, 1), (1, 2, 1), True),
+    ("3_1", 32, 64, (3, 1, 3), (1, 1, 1), False),
+    ("3_2", 64, 64, (3, 7, 1), (1, 1, 1), False),
+    ("4_1", 64, 128, (3, 1, 3), (1, 1, 1), False),
+    ("4_2", 128, 128, (3, 7, 1), (1, 1, 1), False),
+)
+EMBED_DIM = 128
+_FLAT = 4 * 3 * 3 * 128
+
+
+class C3D2(nn.Module):
+    def __init__(self, n_labels, num_channels):
+        super().__init__()
+        self.n_labels, self.num_channels = n_labels, num_channels
+        # creation order = the reference's, so that the same torch seed draws
+        # the same initial weights (model.py:110-139)
+        for tag, cin, cout, kernel, stride, pool in _LAYERS:
+            cin = num_channels if cin is None else cin
+            setattr(self, "conv" + tag, nn.Conv3d(cin, cout, kernel_size=kernel, stride=stride))
+            setattr(self, "batch_norm" + tag, nn.BatchNorm3d(num_features=cout))
+            setattr(self, "PReLu" + tag, nn.PReLU())
+            if pool:
+                setattr(self, "pool" + tag[0], nn.MaxPool3d(kernel_size=(1, 1, 2), stride=(1, 1, 2)))
+        self.FC5 = nn.Linear(_FLAT, EMBED_DIM)
+        self.PReLu5 = nn.PReLU()
+        self.FC6 = nn.Linear(EMBED_DIM, n_labels)
+
+    def forward(self, x, development=True):
+        for tag, _, _, _, _, pool in _LAYERS:
+            x = getattr(self, "conv" + tag)(x)
+            x = getattr(self, "batch_norm" + tag)(x)
+            x = getattr(self, "PReLu" + tag)(x)
+            if pool:
+                x = getattr(self, "pool" + tag[0])(x)
+        x = self.FC5(x.view(-1, _FLAT))
+        if development:
+            x = F.softmax(self.FC6(self.PReLu5(x)), dim=1)
+        return x
+
+    def load_checkpoint(self, checkpoint_dict):
+        """New model with `checkpoint_dict["state_dict"]` loaded; `module.`
+        prefixes left by DataParallel are stripped (model.py:177-186)."""
+        model = C3D2(n_labels=self.n_labels, num_channels=self.num_channels)
+        if torch.cuda.is_available():
+            model.cuda()
+        wanted = model.state_dict()
+        loaded = {}
+        for key, value in checkpoint_dict["state_dict"].items():
+            key = key.replace("module.", "")
+            if key in wanted:
+                loaded[key] = value
+        model.load_state_dict(loaded)
+        return model
+
+    def create_Speaker_Model(self, utterance):
+        self.eval()
+        return self.forward(utterance, development=False)
+
+    # ---- MI355X inference path -------------------------------------------
+    def fused_inference(self, channels_last=False):
+        """Embedding-only callable with BatchNorm folded into the convolutions
+        (eval-mode statistics).  Same maths as forward(development=False)."""
+        return FusedEmbedder(self, channels_last=channels_last)
+
+
+class FusedEmbedder:
+    """conv(+folded BN) -> PReLU chain; weights snapshot the model at build time."""
+
+    def __init__(self, model, channels_last=False):
+        self.channels_last = channels_last
+        self.stages = []
+        fmt = torch.channels_last_3d if channels_last else torch.contiguous_format
+        with torch.no_grad():
+            for tag, _, _, _, stride, pool in _LAYERS:
+                conv = getattr(model, "conv" + tag)
+                bn = getattr(model, "batch_norm" + tag)
+                act = getattr(model, "PReLu" + tag)
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                w = (conv.weight * scale.view(-1, 1, 1, 1, 1)).contiguous(memory_format=fmt)
+                b = ((conv.bias - bn.running_mean) * scale + bn.bias).contiguous()
+                self.stages.append((w, b, act.weight.detach().clone(), stride, pool))
+            self.fc_w = model.FC5.weight.detach().clone()
+            self.fc_b = model.FC5.bias.detach().clone()
+
+    @torch.no_grad()
+    def __call__(self, x):
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last_3d)
+        for w, b, slope, stride, pool in self.stages:
+            x = F.prelu(F.conv3d(x, w, b, stride=stride), slope)
+            if pool:
+                x = F.max_pool3d(x, kernel_size=(1, 1, 2), stride=(1, 1, 2))
+        return F.linear(x.reshape(x.shape[0], _FLAT), self.fc_w, self.fc_b)
+
+
+def seeded_model(seed, n_labels=1211, num_channels=1):
+    """Random-init C3D2 under a fixed torch seed (the reference's checkpoint
+    `Models/model_14_percent_best_so_far.pt` does not ship)."""
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    model = C3D2(n_labels, num_channels)
+    torch.random.set_rng_state(gen_state)
+    return model.eval()
+
+
+def perturb_inference_state(state_dict, seed):
+    """Give BatchNorm running statistics, affine terms and PReLU slopes
+    non-trivial values (a fresh init has mean 0 / var 1 / slope 0.25, which
+    would leave BN folding and PReLU untested).  In place, deterministic."""
+    gen = torch.Generator().manual_seed(seed)
+    for key in sorted(state_dict.keys()):
+        t = state_dict[key]
+        if key.endswith("running_mean"):
+            t.copy_(0.05 * torch.randn(t.shape, generator=gen))
+        elif key.endswith("running_var"):
+            t.copy_(0.5 + torch.rand(t.shape, generator=gen))
+        elif "batch_norm" in key and key.endswith(".weight"):
+            t.copy_(0.8 + 0.4 * torch.rand(t.shape, generator=gen))
+        elif "batch_norm" in key and key.endswith(".bias"):
+            t.copy_(0.05 * torch.randn(t.shape, generator=gen))
+        elif "PReLu" in key:
+            t.copy_(0.1 + 0.3 * torch.rand(t.shape, generator=gen))
+    return state_dict

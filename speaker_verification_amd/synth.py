@@ -1,0 +1,75 @@
+"""Seeded synthetic 16 kHz PCM clips (there is no dataset offline).
+
+Two families, both int16:
+  * `noise_clip`   -- N(0, sigma^2) white noise; kernel micro-benchmarks and
+                      most golden fixtures.
+  * `speaker_clip` -- a crude "voice": a per-speaker set of formant sinusoids,
+                      switched on and off in bursts of 0.5-1.2 s (so the 300 ms
+                      VAD hysteresis of `vad.py:60-129` both triggers and
+                      releases), syllable-rate amplitude modulation, and a
+                      per-utterance noise floor.  Clips of the same speaker
+                      share formants, so cosine scoring has a non-trivial EER.
+
+Everything is a pure function of its integer seeds (NumPy PCG64), so the CPU
+oracle and the GPU path can be fed the same bytes on any machine.
+"""
+import numpy as np
+
+SAMPLE_RATE = 16000
+CLIP_SAMPLES = 48000          # 3 s, the VoxCeleb1-shaped clip of BASELINE.json
+
+
+def noise_clip(seed, n_samples=CLIP_SAMPLES, sigma=3000.0):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(n_samples) * sigma).astype(np.int16)
+
+
+def _speaker_voice(speaker):
+    rng = np.random.default_rng(1000 + int(speaker))
+    n_formants = int(rng.integers(4, 7))
+    freqs = np.sort(rng.uniform(180.0, 3800.0, n_formants))
+    amps = rng.uniform(0.4, 1.0, n_formants) / (1.0 + freqs / 1500.0)
+    return freqs, amps
+
+
+def speaker_clip(speaker, utterance, n_samples=CLIP_SAMPLES, fs=SAMPLE_RATE):
+    """int16 clip of `speaker`'s `utterance`-th recording."""
+    freqs, amps = _speaker_voice(speaker)
+    rng = np.random.default_rng([int(speaker), int(utterance), 7])
+    t = np.arange(n_samples) / float(fs)
+
+    # on/off burst pattern
+    gate = np.zeros(n_samples)
+    pos = int(rng.uniform(0.0, 0.15) * fs)
+    while pos < n_samples:
+        on = int(rng.uniform(0.5, 1.2) * fs)
+        gate[pos:pos + on] = 1.0
+        pos += on + int(rng.uniform(0.12, 0.6) * fs)
+    ramp = int(0.01 * fs)
+    gate = np.convolve(gate, np.ones(ramp) / ramp, mode="same")
+
+    # syllable-rate modulation, shallow enough to stay above the VAD threshold
+    syll = 0.75 + 0.25 * np.sin(2 * np.pi * rng.uniform(3.0, 5.0) * t + rng.uniform(0, 2 * np.pi))
+    jitter = 1.0 + 0.01 * rng.standard_normal(freqs.shape[0])
+    voice = np.zeros(n_samples)
+    for f, a, ph in zip(freqs * jitter, amps, rng.uniform(0, 2 * np.pi, freqs.shape[0])):
+        voice += a * np.sin(2 * np.pi * f * t + ph)
+    voice *= 3000.0 / max(np.std(voice), 1e-9)
+
+    floor = rng.standard_normal(n_samples) * 60.0
+    breath = rng.standard_normal(n_samples) * 500.0 * gate
+    x = gate * syll * voice + breath + floor
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def corpus(n_speakers, utts_per_speaker, n_samples=CLIP_SAMPLES, first_speaker=0):
+    """(pcm [n, n_samples] int16, speaker id per row int32), speaker-major."""
+    n = n_speakers * utts_per_speaker
+    pcm = np.empty((n, n_samples), dtype=np.int16)
+    spk = np.empty((n,), dtype=np.int32)
+    for s in range(n_speakers):
+        for u in range(utts_per_speaker):
+            row = s * utts_per_speaker + u
+            pcm[row] = speaker_clip(first_speaker + s, u, n_samples)
+            spk[row] = first_speaker + s
+    return pcm, spk

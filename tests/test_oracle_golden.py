@@ -1,0 +1,228 @@
+"""Pin the CPU oracle (oracle/*.py) to the reference's own outputs
+(tests/golden/*.npz, made by tools/make_golden.py importing /root/reference).
+Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref, scoring_ref, speechpy_ref as sp, vad_ref
+from speaker_verification_amd import synth
+from speaker_verification_amd.model import perturb_inference_state, seeded_model
+
+TIGHT = dict(rtol=1e-12, atol=1e-12)
+
+
+def test_functions(golden):
+    g = golden["speechpy"]
+    np.testing.assert_allclose(sp.frequency_to_mel(g["fn_hz"]), g["fn_mel"], **TIGHT)
+    np.testing.assert_allclose(sp.mel_to_frequency(g["fn_mel"]), g["fn_hz_back"], **TIGHT)
+    np.testing.assert_allclose(sp.triangle(g["fn_tri_x"], 5, 9, 15), g["fn_tri"], **TIGHT)
+    np.testing.assert_array_equal(sp.zero_handling(g["fn_zh_in"]), g["fn_zh"])
+    assert sp.frequency_to_mel(300) == pytest.approx(401.9726618189514, abs=1e-10)
+    assert sp.frequency_to_mel(8000) == pytest.approx(2840.0377117383778, abs=1e-10)
+
+
+@pytest.mark.parametrize("key,args", [
+    ("fb_A", (40, 257, 16000, 0, 8000)), ("fb_B", (40, 513, 16000, 0, 8000)),
+    ("fb_C", (26, 257, 16000, 100.0, 7000.0)), ("fb_D", (20, 129, 8000, None, None))])
+def test_filterbanks(golden, key, args):
+    np.testing.assert_array_equal(sp.filterbanks(*args), golden["speechpy"][key])
+
+
+def test_filterbank_quirks(golden):
+    fb = sp.filterbanks(40, 257, 16000, 0, 8000)
+    assert np.count_nonzero(fb) == 200                                  # Q2
+    np.testing.assert_array_equal(fb, sp.filterbanks(40, 257, 16000, 300, 8000))  # Q1
+    edges = sp.mel_edges(40, 257, 16000, 0, 8000)
+    assert edges[0] == 4 and edges[-1] == 128
+
+
+def test_processing_stages(golden):
+    g = golden["speechpy"]
+    short = synth.noise_clip(*g["short_seed"])
+    out = sp.preemphasis(short, shift=1, cof=0.98)
+    assert out.dtype == np.float64
+    np.testing.assert_allclose(out, g["pre_short_i16"], **TIGHT)
+    f32 = sp.preemphasis((short / 32768.0).astype(np.float32), shift=1, cof=0.98)
+    assert f32.dtype == np.float32
+    np.testing.assert_array_equal(f32, g["pre_short_f32"])
+    np.testing.assert_allclose(sp.preemphasis(short, shift=3, cof=0.5), g["pre_short_shift3"], **TIGHT)
+    x = short.astype(float)
+    ones = lambda n: np.ones((n,))
+    np.testing.assert_array_equal(sp.stack_frames(x, 16000, 0.020, 0.010, ones, False), g["frames_nopad"])
+    np.testing.assert_array_equal(sp.stack_frames(x, 16000, 0.020, 0.020, ones, True), g["frames_pad"])
+    np.testing.assert_allclose(sp.stack_frames(x, 16000, 0.025, 0.010, np.hamming, True),
+                               g["frames_hamming"], **TIGHT)
+    fr = g["frames_nopad"]
+    np.testing.assert_allclose(sp.fft_spectrum(fr, 512), g["fftmag_512"], **TIGHT)
+    np.testing.assert_allclose(sp.power_spectrum(fr, 512), g["pow_512"], rtol=1e-12, atol=1e-6)
+    np.testing.assert_allclose(sp.power_spectrum(g["frames_hamming"], 1024), g["pow_1024"], rtol=1e-12, atol=1e-6)
+    np.testing.assert_allclose(sp.power_spectrum(fr, 256), g["pow_256_crop"], rtol=1e-12, atol=1e-6)
+    np.testing.assert_allclose(sp.log_power_spectrum(fr, 512, True), g["logpow_512_norm"], **TIGHT)
+    np.testing.assert_allclose(sp.log_power_spectrum(fr, 512, False), g["logpow_512_raw"], **TIGHT)
+
+
+def test_frame_counts():
+    # Q3: no '+1' without padding
+    assert sp.frame_geometry(48000, 16000, 0.020, 0.010, False) == (320, 160.0, 298)
+    assert sp.frame_geometry(48000, 16000, 0.025, 0.010, False) == (400, 160.0, 297)
+    # reference test_stack_frames: ceil((N - window) / step) with padding
+    assert sp.stack_frames(np.zeros(100000), 16000, 0.02, 0.02, zero_padding=True).shape == (312, 320)
+
+
+def test_features(golden):
+    g = golden["speechpy"]
+    one = synth.noise_clip(*g["one_seed"])
+    f, e = sp.mfe(one, 16000)
+    np.testing.assert_allclose(f, g["mfe_A_feat"], rtol=1e-12)
+    np.testing.assert_allclose(e, g["mfe_A_energy"], rtol=1e-12)
+    np.testing.assert_allclose(sp.lmfe(one, 16000), g["lmfe_A"], **TIGHT)
+    np.testing.assert_allclose(sp.mfcc(one, 16000), g["mfcc_A"], **TIGHT)
+    np.testing.assert_allclose(sp.mfcc(one, 16000, dc_elimination=False), g["mfcc_A_nodc"], **TIGHT)
+    np.testing.assert_allclose(sp.mfcc(one, 16000, num_cepstral=40), g["mfcc_A_40"], **TIGHT)
+    np.testing.assert_allclose(sp.mfcc(sp.preemphasis(one, cof=0.98), 16000), g["mfcc_A_pre"], **TIGHT)
+    np.testing.assert_allclose(sp.mfcc(one, 16000, num_filters=26, low_frequency=100.0, high_frequency=7000.0),
+                               g["mfcc_A_lowhigh"], **TIGHT)
+    one_f32 = (one / 32768.0).astype(np.float32)
+    np.testing.assert_allclose(sp.lmfe(one_f32, 16000, 0.025, 0.01, 40, 1024), g["lmfe_B_f32"], **TIGHT)
+    np.testing.assert_allclose(sp.mfcc(one_f32, 16000, 0.025, 0.01, 13, 40, 1024), g["mfcc_B_f32"], **TIGHT)
+    spk = synth.speaker_clip(*g["spk_seed"])
+    np.testing.assert_allclose(sp.mfcc(spk, 16000), g["mfcc_A_spk"], **TIGHT)
+    np.testing.assert_allclose(sp.lmfe(spk, 16000, 0.025, 0.01, 40, 1024), g["lmfe_B_spk"], **TIGHT)
+    zero = sp.mfcc(np.zeros(1600, dtype=np.int16), 16000)
+    np.testing.assert_allclose(zero, g["mfcc_A_zero"], **TIGHT)
+    assert zero[0, 0] == pytest.approx(-36.04365338911715) and np.abs(zero[:, 1:]).max() < 1e-12   # Q7
+    assert sp.mfcc(np.zeros(320, dtype=np.int16), 16000).shape == g["mfcc_A_tooshort"].shape == (0, 13)
+
+
+def test_known_answers_3s(golden):
+    """Scalars quoted in SURVEY.md 8(c)."""
+    g = golden["speechpy"]
+    rng = np.random.default_rng(0)
+    sig = (rng.standard_normal(48000) * 3000).astype(np.int16)
+    assert list(sig[:4]) == [377, -396, 1921, 314] and int(sig.sum()) == -3820
+    m = sp.mfcc(sig, 16000)
+    assert m.shape == (298, 13)
+    np.testing.assert_allclose(m, g["kat_mfcc_A_3s"], **TIGHT)
+    np.testing.assert_allclose(m[0, :4], [21.1385077877, -4.2238004459, -0.1995078033, -1.6293471466], atol=1e-9)
+    assert m.sum() == pytest.approx(4545.562374768052, abs=1e-7)
+    c = sp.cmvn(sp.mfcc(sp.preemphasis(sig, cof=0.98), 16000), True)
+    np.testing.assert_allclose(c, g["kat_mfcc_A_3s_pre_cmvn"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(c[0, :4], [0.3847559544, 0.5312670914, 0.5733337404, -0.6579142096], atol=1e-9)
+    b = sp.lmfe(sig.astype(np.float32) / 32768, 16000, 0.025, 0.01, 40, 1024)
+    assert b.shape == (297, 40)
+    np.testing.assert_allclose(b, g["kat_lmfe_B_3s"], **TIGHT)
+    assert b.sum() == pytest.approx(-51156.72226611714, abs=1e-6)
+
+
+def test_postprocessing(golden):
+    g = golden["speechpy"]
+    base = g["mfcc_A"]
+    np.testing.assert_allclose(sp.cmvn(base, False), g["cmvn_mean"], **TIGHT)
+    np.testing.assert_allclose(sp.cmvn(base, True), g["cmvn_var"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(sp.cmvn(g["cmvn_wide_in"], True), g["cmvn_wide_var"], rtol=1e-11, atol=1e-11)
+    for key, kw in (("cmvnw_mean", dict(win_size=301, variance_normalization=False)),
+                    ("cmvnw_var", dict(win_size=301, variance_normalization=True)),
+                    ("cmvnw_var_w31", dict(win_size=31, variance_normalization=True))):
+        out = sp.cmvnw(base, **kw)
+        assert out.dtype == np.float32                                   # Q10
+        np.testing.assert_allclose(out, g[key], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sp.derivative_extraction(base, 2), g["deriv_w2"], **TIGHT)
+    np.testing.assert_allclose(sp.derivative_extraction(base, 3), g["deriv_w3"], **TIGHT)
+    np.testing.assert_allclose(sp.extract_derivative_feature(g["lmfe_A"]), g["deriv_cube"], **TIGHT)
+    with pytest.raises(AssertionError):
+        sp.cmvnw(base, win_size=300)
+
+
+def _vad_clip(name, g):
+    if name == "pattern":
+        return g["pattern_pcm"]
+    table = {"spk_0_0": (0, 0, 48000), "spk_1_4": (1, 4, 48000), "spk_7_2": (7, 2, 48000),
+             "spk_5_0_long": (5, 0, 112000), "len_47999": (2, 1, 47999), "len_48001": (2, 2, 48001)}
+    if name in table:
+        return synth.speaker_clip(*table[name])
+    noise = {"noise_loud": (3, 48000, 3000.0), "noise_quiet": (4, 48000, 100.0),
+             "len_480": (6, 480), "len_481": (6, 481), "len_100": (6, 100)}
+    return synth.noise_clip(*noise[name])
+
+
+def test_vad(golden):
+    g = golden["vad"]
+    thr = int(g["threshold"][0])
+    saw_release = saw_drop = False
+    for name in g["cases"]:
+        pcm = _vad_clip(str(name), g)
+        assert pcm.size == int(g[f"{name}_pcm_len"][0])
+        assert vad_ref.num_frames(pcm.size * 2, 30, 16000) == int(g[f"{name}_nframes"][0])   # Q12
+        flags = vad_ref.frame_flags(pcm, 30, 16000, thr)
+        np.testing.assert_array_equal(flags, g[f"{name}_flags"])
+        keep, seg, voiced = vad_ref.vad_energy(pcm, 16000, 30, 300, thr)
+        np.testing.assert_array_equal(keep, g[f"{name}_keep"])                               # Q13
+        np.testing.assert_array_equal(seg, g[f"{name}_seg"])
+        v = voiced.astype(np.int64)
+        np.testing.assert_array_equal([v.sum(), v.size, (v ** 2).sum()], g[f"{name}_voiced_sum"])
+        saw_release |= len(g[f"{name}_seglens"]) > 1
+        saw_drop |= bool(keep.any() and not keep.all())
+    assert vad_ref.num_frames(96000, 30, 16000) == 99
+    assert saw_release and saw_drop, "fixtures must exercise trigger AND release"
+
+
+def test_c3d2_and_cube(golden):
+    g = golden["c3d2_embed"]
+    model = seeded_model(int(g["init_seed"][0]), int(g["n_labels"][0]), 1)
+    state = perturb_inference_state(model.state_dict(), int(g["perturb_seed"][0]))
+    names = sorted(state.keys())
+    assert names == [str(n) for n in g["state_names"]]
+    sums = [float(state[k].double().abs().sum()) for k in names]
+    np.testing.assert_allclose(sums, g["state_abs_sums"], rtol=1e-12)       # same init as the reference's C3D2
+    cubes = (np.random.default_rng(int(g["cube_seed"][0])).standard_normal((3, 1, 20, 80, 40)) * 2.0 - 6.0
+             ).astype(np.float32)
+    emb = model_ref.c3d2_embed(state, cubes).numpy()
+    np.testing.assert_allclose(emb, g["embed"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(emb[1:2], g["speaker_model"], rtol=1e-5, atol=1e-5)
+    # product module on CPU agrees too (plain and BN-folded)
+    model.load_state_dict(state)
+    with torch.no_grad():
+        np.testing.assert_allclose(model(torch.from_numpy(cubes), development=False).numpy(), g["embed"],
+                                   rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(model(torch.from_numpy(cubes[:1])).numpy()[0, :8], g["softmax_row0_top"],
+                                   rtol=1e-4, atol=1e-7)
+    fused = model.fused_inference()
+    np.testing.assert_allclose(fused(torch.from_numpy(cubes)).numpy(), g["embed"], rtol=1e-4, atol=1e-4)
+    # FeatureCube
+    feat = np.random.default_rng(int(g["cube_feat_seed"][0])).standard_normal((297, 40))
+    idx = model_ref.draw_crops(np.random.RandomState(int(g["cube_np_seed"][0])), 297)
+    np.testing.assert_array_equal(idx, g["cube_idx"])
+    np.testing.assert_array_equal(model_ref.feature_cube(feat, idx), g["cube_out"])
+
+
+def test_scoring(golden):
+    g = golden["scoring"]
+    test, enroll = g["test"], g["enroll"]
+    full = scoring_ref.cosine_matrix(test, enroll)
+    assert full.dtype == np.float32
+    np.testing.assert_allclose(full, g["sims"], rtol=0, atol=2e-7)
+    for i in (0, 5, 41):
+        sims, assigned = scoring_ref.compute_similarity(test[i], enroll)
+        np.testing.assert_allclose(sims, g["sims"][i], rtol=0, atol=2e-7)
+        np.testing.assert_array_equal(assigned, g["assigned"][i])
+    eer, auc, fpr, tpr = scoring_ref.get_eer_auc(g["labels"].flatten(), g["sims"].flatten())
+    assert eer == pytest.approx(float(g["eer"][0]), abs=1e-12)
+    assert auc == pytest.approx(float(g["auc"][0]), abs=1e-12)
+    np.testing.assert_array_equal(fpr, g["fpr"])
+    np.testing.assert_array_equal(tpr, g["tpr"])
+    eer2, auc2, _, _ = scoring_ref.get_eer_auc(g["big_labels"], g["big_scores"])
+    assert eer2 == pytest.approx(float(g["big_eer"][0]), abs=1e-12)
+    assert auc2 == pytest.approx(float(g["big_auc"][0]), abs=1e-12)
+    assert scoring_ref.k_fold_eer_auc(g["big_labels"], g["big_scores"], 1)[0] == pytest.approx(eer2)
+    np.testing.assert_allclose(scoring_ref.l2_dist(g["l2_o1"], g["l2_o2"]), g["l2_dist"], rtol=1e-6)
+
+
+def test_contrastive_loss_formula():
+    """siamese.py:14-25 restated; unpinned (the reference's forward needs CUDA)."""
+    y = np.array([1, 0, 1, 0], dtype=np.float32)
+    o1 = np.zeros((4, 3), dtype=np.float32)
+    o2 = np.array([[3, 4, 0], [0.6, 0.8, 0], [0, 0, 0], [3, 0, 0]], dtype=np.float32)   # d = 5, 1, 0, 3
+    loss = scoring_ref.contrastive_loss(y, o1, o2, [2.0, 1.0], LAMBDA=0.1, M=2.0)
+    expected = (0.5 * 25 + 0.5 * 1 + 0 + 0 + 4 * 0.1 * 3.0) / 4
+    assert loss == pytest.approx(expected, rel=1e-6)
