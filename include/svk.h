@@ -1,0 +1,164 @@
+/*
+ * svk.h -- C-ABI of libsvk.so: the MI355X (gfx950) speaker-verification hot path.
+ *
+ * The reference (MingmChen/Speaker_Verification) is 100 % Python and has no FFI
+ * layer; its boundary for this path is the Python API of its vendored SpeechPy
+ * plus vad.py / evaluation.py / siamese.py.  Each entry point below names the
+ * reference function(s) (file:line under /root/reference) whose arithmetic it
+ * replaces; `speaker_verification_amd/` binds them with ctypes and re-exposes the
+ * reference's own Python signatures.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer named d_* is a DEVICE pointer
+ *     (hipMalloc'd / a torch tensor's data_ptr()), every h_* a host pointer.
+ *   - the caller allocates every input and output; the library owns only what it
+ *     returns through svk_create / svk_*_plan_create and frees it in *_destroy.
+ *   - every function returns SVK_OK (0) or a negative svk_status; no exceptions,
+ *     no aborts.  svk_last_error(ctx) holds a message for the last failure.
+ *   - launches go to the stream set by svk_set_stream (default: the null stream)
+ *     and are asynchronous w.r.t. the host; svk_sync waits for that stream.
+ *   - a context is bound to one device and is not thread-safe.
+ */
+#ifndef SVK_H
+#define SVK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVK_VERSION 100 /* 0.1.0 */
+
+typedef enum svk_status {
+  SVK_OK = 0,
+  SVK_ERR_BAD_ARG = -1,      /* NULL pointer, negative size, inconsistent shape   */
+  SVK_ERR_UNSUPPORTED = -2,  /* a parameter combination the kernels do not cover  */
+  SVK_ERR_HIP = -3,          /* a HIP runtime call failed (message has the code)  */
+  SVK_ERR_NO_DEVICE = -4,    /* no usable gfx950 device                           */
+  SVK_ERR_OOM = -5
+} svk_status;
+
+typedef struct svk_ctx svk_ctx;
+typedef struct svk_frontend_plan svk_frontend_plan;
+
+/* ---- context, stream, memory --------------------------------------------- */
+int svk_version(void);
+int svk_create(int device_id, svk_ctx** out);
+void svk_destroy(svk_ctx* ctx);
+const char* svk_last_error(const svk_ctx* ctx);
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream), NULL = null stream */
+int svk_set_stream(svk_ctx* ctx, void* hip_stream);
+int svk_sync(svk_ctx* ctx);
+/* so that a host without torch can drive the library */
+int svk_malloc(svk_ctx* ctx, size_t bytes, void** d_out);
+int svk_free(svk_ctx* ctx, void* d_ptr);
+int svk_memcpy_h2d(svk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int svk_memcpy_d2h(svk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int svk_memset(svk_ctx* ctx, void* d_dst, int value, size_t bytes);
+/* device facts for roofline reporting: [0]=CU count, [1]=max clock kHz, [2]=LDS bytes/CU, [3]=wavefront size */
+int svk_device_info(svk_ctx* ctx, int64_t out[4]);
+
+/* ---- fused front end -------------------------------------------------------
+ * PCM -> [pre-emphasis] -> frames -> rFFT power spectrum -> frame energy ->
+ * mel filterbank (f32 MFMA) -> [log] -> [DCT-II (f32 MFMA)] -> [c0 := log E]
+ * Replaces speechpy/feature.py:102-153 (mfcc), :156-219 (mfe), :222-258 (lmfe)
+ * and, when preemph != 0, speechpy/processing.py:45-58 applied to the whole
+ * clip first (circular, Q5).  Framing is the no-padding branch of
+ * processing.py:112-120 (Q3) with a rectangular window (Q4).
+ */
+typedef enum svk_out_kind { SVK_OUT_MFE = 0, SVK_OUT_LMFE = 1, SVK_OUT_MFCC = 2 } svk_out_kind;
+typedef enum svk_pcm_dtype { SVK_PCM_I16 = 0, SVK_PCM_F32 = 1 } svk_pcm_dtype;
+
+typedef struct svk_frontend_cfg {
+  int32_t frame_len;      /* samples per frame  = int(round(fs * frame_length))  */
+  int32_t frame_stride;   /* samples per hop    = round(fs * frame_stride)       */
+  int32_t nfft;           /* 512 or 1024 (fft_length)                            */
+  int32_t num_filters;    /* 1..64                                               */
+  int32_t num_ceps;       /* MFCC only: 1..num_filters                           */
+  int32_t out_kind;       /* svk_out_kind                                        */
+  int32_t dc_elimination; /* MFCC only: column 0 := log(frame energy) (Q8)       */
+  int32_t preemph;        /* 0 = none, 1 = y[n] = x[n] - cof * x[(n-shift) mod N] */
+  int32_t preemph_shift;
+  float preemph_cof;
+} svk_frontend_cfg;
+
+/* h_filterbank: num_filters x (nfft/2+1) float64, row-major -- the matrix of
+ * speechpy/feature.py:33-99, built on the host (its bin edges hinge on float64
+ * libm rounding, Q1/Q2, so the host language that owns parity builds it).   */
+int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const double* h_filterbank,
+                             svk_frontend_plan** out);
+void svk_frontend_plan_destroy(svk_frontend_plan* plan);
+/* number of frames of a clip of n_samples: floor((n - frame_len) / stride), >= 0 (Q3) */
+int64_t svk_frontend_num_frames(const svk_frontend_cfg* cfg, int64_t n_samples);
+/* columns of the feature matrix: num_filters (MFE/LMFE) or num_ceps (MFCC) */
+int svk_frontend_num_cols(const svk_frontend_cfg* cfg);
+
+/* d_pcm      : concatenated clips, int16 or float32 (pcm_dtype)
+ * d_offsets  : [n_utt] int64 first sample of each clip in d_pcm, or NULL = i * clip_stride
+ * d_lengths  : [n_utt] int32 samples per clip, or NULL = clip_len for all
+ * max_frames : row stride of the outputs (>= frames of the longest clip)
+ * d_feat     : [n_utt][max_frames][num_cols] float32; rows >= n_frames are zeroed
+ * d_energy   : [n_utt][max_frames] float32 frame energies (after zero handling), or NULL
+ * d_n_frames : [n_utt] int32 frames produced per clip, or NULL
+ */
+int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_pcm, int pcm_dtype,
+                     const int64_t* d_offsets, const int32_t* d_lengths, int64_t clip_stride,
+                     int32_t clip_len, int32_t n_utt, int32_t max_frames, float* d_feat, float* d_energy,
+                     int32_t* d_n_frames);
+
+/* ---- stage-level entry points (one speechpy function each) ----------------- */
+/* processing.py:45-58.  d_in int16/float32 [n]; d_out float32 [n]; circular. */
+int svk_preemphasis(svk_ctx* ctx, const void* d_in, int pcm_dtype, int64_t n, int32_t shift, float cof,
+                    float* d_out);
+/* processing.py:61-139.  frame t = d_sig[t*stride .. +frame_len) (zeros past n) times d_window
+ * (NULL = rectangular).  d_out float32 [n_frames][frame_len].                 */
+int svk_stack_frames(svk_ctx* ctx, const float* d_sig, int64_t n, int32_t frame_len, int32_t stride,
+                     int32_t n_frames, const float* d_window, float* d_out);
+/* processing.py:142-174.  d_frames float32 [n_frames][frame_len] -> d_out
+ * [n_frames][nfft/2+1]; power = 0: |rfft| (fft_spectrum), 1: |rfft|^2/nfft (power_spectrum).
+ * Frames longer than nfft are cropped, shorter are zero-padded (Q6).  Any nfft >= 2. */
+int svk_spectrum(svk_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_len, int32_t nfft,
+                 int32_t power, float* d_out);
+/* processing.py:239-271 per clip: d_feat [n_utt][max_frames][n_cols], rows < n_frames[u]
+ * (NULL = max_frames) are normalised in place; variance != 0 divides by (std + 2^-30). */
+int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+             const int32_t* d_n_frames, int32_t variance);
+
+/* ---- energy VAD ------------------------------------------------------------
+ * vad.py:44-57 (framer, Q12) + vad.py:60-129 (ring-buffer hysteresis, Q13) with
+ * the per-frame decision  sum(x^2) > threshold * frame_samples  (int64) in place of
+ * webrtcvad (vad.py:90).  ring_len = int(padding_ms / frame_ms); ring_thresh =
+ * floor(0.9 * ring_len) (trigger when voiced > ring_thresh, release when unvoiced >
+ * ring_thresh).
+ * d_keep       : [n_utt][max_vad_frames] uint8, 1 = frame is in some yielded segment
+ * d_seg        : [n_utt][max_vad_frames] int32 segment ordinal or -1, or NULL
+ * d_n_vad_frames: [n_utt] int32, or NULL
+ * d_voiced     : int16, same offsets as d_pcm: kept frames packed to the front, or NULL
+ * d_voiced_len : [n_utt] int32 samples kept (required when d_voiced != NULL)
+ */
+int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t* d_offsets, const int32_t* d_lengths,
+                   int64_t clip_stride, int32_t clip_len, int32_t n_utt, int32_t frame_samples,
+                   int32_t ring_len, int32_t ring_thresh, int64_t threshold, int32_t max_vad_frames,
+                   uint8_t* d_keep, int32_t* d_seg, int32_t* d_n_vad_frames, int16_t* d_voiced,
+                   int32_t* d_voiced_len);
+
+/* ---- feature cube ------------------------------------------------------------
+ * utils.py:351-379 (FeatureCube): out[u][0][c][r][:] = feat[u][crop[u][c] + r][:].
+ * d_out float32 [n_utt][1][n_crops][crop_frames][n_cols] (a torch tensor's data_ptr()). */
+int svk_cube_gather(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                    const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, float* d_out);
+
+/* ---- scoring ---------------------------------------------------------------
+ * evaluation.py:67-84: cosine of every test row against every enrolled row,
+ * float32, out [n_test][n_enroll]  (f32 MFMA).  dim <= 4096.                 */
+int svk_cosine_scores(svk_ctx* ctx, const float* d_test, const float* d_enroll, int32_t n_test,
+                      int32_t n_enroll, int32_t dim, float* d_out);
+/* siamese.py:29-30: out[i] = || a[i] - b[i] ||_2 */
+int svk_l2_dist(svk_ctx* ctx, const float* d_a, const float* d_b, int32_t n, int32_t dim, float* d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVK_H */

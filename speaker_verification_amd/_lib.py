@@ -1,0 +1,98 @@
+"""ctypes binding of libsvk.so (C-ABI: include/svk.h).
+
+This is the only place that touches the shared library.  There is NO fallback:
+if `libsvk.so` is missing or a call fails, an exception is raised.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C speaker_verification_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvk.so")
+
+SVK_OK = 0
+SVK_ERR_BAD_ARG, SVK_ERR_UNSUPPORTED, SVK_ERR_HIP, SVK_ERR_NO_DEVICE, SVK_ERR_OOM = -1, -2, -3, -4, -5
+OUT_MFE, OUT_LMFE, OUT_MFCC = 0, 1, 2
+PCM_I16, PCM_F32 = 0, 1
+
+_STATUS_NAMES = {-1: "SVK_ERR_BAD_ARG", -2: "SVK_ERR_UNSUPPORTED", -3: "SVK_ERR_HIP",
+                 -4: "SVK_ERR_NO_DEVICE", -5: "SVK_ERR_OOM"}
+
+
+class SvkError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"{_STATUS_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class FrontendCfg(C.Structure):
+    """mirror of struct svk_frontend_cfg"""
+    _fields_ = [("frame_len", C.c_int32), ("frame_stride", C.c_int32), ("nfft", C.c_int32),
+                ("num_filters", C.c_int32), ("num_ceps", C.c_int32), ("out_kind", C.c_int32),
+                ("dc_elimination", C.c_int32), ("preemph", C.c_int32), ("preemph_shift", C.c_int32),
+                ("preemph_cof", C.c_float)]
+
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes).  Must list every symbol include/svk.h declares
+# (tests/test_cabi.py checks the two against each other).
+SIGNATURES = {
+    "svk_version": (C.c_int, []),
+    "svk_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "svk_destroy": (None, [_vp]),
+    "svk_last_error": (C.c_char_p, [_vp]),
+    "svk_set_stream": (C.c_int, [_vp, _vp]),
+    "svk_sync": (C.c_int, [_vp]),
+    "svk_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "svk_free": (C.c_int, [_vp, _vp]),
+    "svk_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "svk_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "svk_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
+    "svk_device_info": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "svk_frontend_plan_create": (C.c_int, [_vp, C.POINTER(FrontendCfg), C.POINTER(C.c_double), C.POINTER(_vp)]),
+    "svk_frontend_plan_destroy": (None, [_vp]),
+    "svk_frontend_num_frames": (_i64, [C.POINTER(FrontendCfg), _i64]),
+    "svk_frontend_num_cols": (C.c_int, [C.POINTER(FrontendCfg)]),
+    "svk_frontend_run": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "svk_preemphasis": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _f32, _vp]),
+    "svk_stack_frames": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "svk_spectrum": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "svk_cmvn": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32]),
+    "svk_vad_energy": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i64, _i32,
+                                  _vp, _vp, _vp, _vp, _vp]),
+    "svk_cube_gather": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "svk_cosine_scores": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "svk_l2_dist": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """The loaded library (cached).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `make -C speaker_verification_amd/csrc`); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)            # AttributeError if the .so is stale
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.svk_version() != 100:
+            raise RuntimeError(f"libsvk.so version {lib.svk_version()} does not match this package (100)")
+        _lib = lib
+    return _lib
+
+
+def check(rc, ctx=None):
+    if rc != SVK_OK:
+        msg = ""
+        if ctx:
+            raw = load().svk_last_error(ctx)
+            msg = raw.decode("utf-8", "replace") if raw else ""
+        raise SvkError(rc, msg)

@@ -1,0 +1,549 @@
+// Fused front end for gfx950: PCM -> [pre-emphasis] -> frames -> rFFT power spectrum ->
+// frame energy -> mel filterbank -> [log] -> [DCT-II] -> [c0 := log E].
+//
+// Replaces, per clip, /root/reference/speech_feature_extraction/speechpy/
+//   processing.py:45-58 (preemphasis, circular)   processing.py:112-138 (framing, no padding)
+//   processing.py:142-174 (|rfft|^2 / nfft)       feature.py:202-205 (frame energy, 0 -> eps)
+//   feature.py:216-217 (mel projection, 0 -> eps) feature.py:146-153 (log, DCT-II ortho, c0 := log E)
+//
+// Work decomposition (one 64-lane wave per workgroup, no cross-wave traffic):
+//   a wave owns a TILE of 16 consecutive frames of one clip and loops over tiles.
+//   1. the tile's sample span is read from HBM once with 16-byte loads, pre-emphasised
+//      in flight and parked in LDS as f32 (frames overlap, so each sample feeds 2+ frames);
+//   2. a 512-point complex FFT runs across the wave: 8 points per lane, three radix-8
+//      passes in registers, two transposes through a padded (bank-conflict-free) LDS
+//      scratch.  nfft = 512 packs TWO real frames into one complex FFT; nfft = 1024 packs
+//      the even/odd samples of ONE frame.  The untangle step pairs bin k with bin N-k,
+//      which lives in lane 64-l: one wave shuffle per register, no LDS;
+//   3. the low power bins that the mel filters touch go to a [16 x KP] LDS tile, the
+//      frame energy is a wave reduction over all bins;
+//   4. mel energies^T = filterbank x P^T on v_mfma_f32_16x16x4_f32 (exact f32), skipping
+//      the 16-bin chunks where a 16-filter tile is identically zero (Q2: the bank is
+//      ~97 % zeros);  log;  the accumulator layout of that product is exactly the B
+//      operand layout of the next one, so cepstra^T = DCT x log(mel)^T follows with no
+//      data movement;
+//   5. results go straight to HBM.
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "fft_wave.h"
+#include "svk_internal.h"
+
+using namespace svk_fft;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TILE = 16;     // frames per wave tile (= MFMA N)
+constexpr int MAX_FT = 4;    // 16-filter tiles  (<= 64 filters)
+constexpr int MAX_CT = 4;    // 16-cepstrum tiles
+constexpr int PT_PAD = 8;    // ptile row padding (floats): conflict-free ds_read_b128
+constexpr float EPS64 = 2.220446049250313e-16f;  // np.finfo(float).eps, functions.py:62
+
+struct FrontendParams {
+  const void* pcm;
+  const int64_t* offsets;
+  const int32_t* lengths;
+  int64_t clip_stride;
+  int32_t clip_len;
+  int32_t n_utt, max_frames, tiles_per_utt;
+  int32_t flen, flen_eff, stride, nfilt, ncols, out_kind, dc_elim, preemph, pre_shift;
+  float pre_cof;
+  int32_t kp;        // power bins kept for the mel product, multiple of 16
+  int32_t span_pad;  // floats reserved for the staged samples
+  int32_t n_ft, n_ct;
+  int32_t chunk_lo[MAX_FT], chunk_hi[MAX_FT];
+  const float2* tw1;    // [8][64]  W512^(lane*r)
+  const float2* tw2;    // [8][64]  W64^((lane&7)*r)
+  const float2* tw3;    // [5][64]  W1024^(lane+64q), q<4; [4][0] = W1024^256
+  const f32x4* fbfrag;  // [n_ft][kp/16][64]
+  const float* dctfrag; // [n_ct][n_ft][4][64]
+  float* feat;
+  float* energy;
+  int32_t* n_frames;
+};
+
+template <typename PcmT>
+__device__ __forceinline__ void stage_span(const FrontendParams& p, const PcmT* x, int64_t s0, int need,
+                                           int len, float* sig, int lane) {
+  constexpr int V = 16 / (int)sizeof(PcmT);
+  typedef PcmT vec_t __attribute__((ext_vector_type(V)));
+  const bool fast = (!p.preemph || p.pre_shift == 1) && ((reinterpret_cast<uintptr_t>(x + s0) & 15) == 0);
+  for (int i = lane * V; i < need; i += 64 * V) {
+    const int64_t idx = s0 + i;
+    float v[V];
+    float o[V];
+    if (fast && idx + V <= len) {
+      vec_t raw = *reinterpret_cast<const vec_t*>(x + idx);
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = (float)raw[e];
+      if (p.preemph) {
+        const float prev = (float)x[idx == 0 ? len - 1 : idx - 1];
+        o[0] = v[0] - p.pre_cof * prev;
+#pragma unroll
+        for (int e = 1; e < V; ++e) o[e] = v[e] - p.pre_cof * v[e - 1];
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = v[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const int64_t id = idx + e;
+        float val = 0.f;
+        if (id < len) {
+          val = (float)x[id];
+          if (p.preemph) {
+            int64_t j = (id - p.pre_shift) % len;
+            if (j < 0) j += len;
+            val -= p.pre_cof * (float)x[j];
+          }
+        }
+        o[e] = val;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < V; e += 4)
+      *reinterpret_cast<f32x4*>(sig + i + e) = (f32x4){o[e], o[e + 1], o[e + 2], o[e + 3]};
+  }
+}
+
+template <typename PcmT, bool SPLIT1024>
+__global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sig = reinterpret_cast<float*>(smem);
+  float* ptile = sig + p.span_pad;
+  const int prow = p.kp + PT_PAD;
+  float2* scr = reinterpret_cast<float2*>(ptile + TILE * prow);
+  float* elds = reinterpret_cast<float*>(scr + SCR);
+  const int lane = threadIdx.x;
+  const int jf = lane & 15, g = lane >> 4;
+
+  float2 t1[8], t2[8], t3[5];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    t1[r] = p.tw1[r * 64 + lane];
+    t2[r] = p.tw2[r * 64 + lane];
+  }
+  if (SPLIT1024) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) t3[q] = p.tw3[q * 64 + lane];
+  }
+  const float inv_scale = SPLIT1024 ? (1.0f / 1024.0f) : (1.0f / (4.0f * 512.0f));
+  const int mirror = (64 - lane) & 63;
+  const bool lane0 = lane == 0;
+  const int nchunks = p.kp >> 4;
+  const int64_t total = (int64_t)p.n_utt * p.tiles_per_utt;
+
+  for (int64_t tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const int utt = (int)(tile / p.tiles_per_utt);
+    const int f0 = (int)(tile % p.tiles_per_utt) * TILE;
+    const int64_t off = p.offsets ? p.offsets[utt] : (int64_t)utt * p.clip_stride;
+    const int len = p.lengths ? p.lengths[utt] : p.clip_len;
+    const int T = len >= p.flen ? (len - p.flen) / p.stride : 0;  // processing.py:115-116 (Q3)
+    if (f0 == 0 && lane0 && p.n_frames) p.n_frames[utt] = T < p.max_frames ? T : p.max_frames;
+    int nvalid = T - f0;
+    nvalid = nvalid > TILE ? TILE : nvalid;
+    if (f0 + nvalid > p.max_frames) nvalid = p.max_frames - f0;
+    float* out_rows = p.feat + ((int64_t)utt * p.max_frames + f0) * p.ncols;
+
+    if (nvalid > 0) {
+      const PcmT* x = reinterpret_cast<const PcmT*>(p.pcm) + off;
+      const int need = (nvalid - 1) * p.stride + p.flen_eff;
+      __syncthreads();  // previous tile's readers of sig / ptile are done
+      stage_span<PcmT>(p, x, (int64_t)f0 * p.stride, need, len, sig, lane);
+      __syncthreads();
+
+      // ---- spectra -----------------------------------------------------------
+      constexpr int FR_PER_FFT = SPLIT1024 ? 1 : 2;
+      for (int fa = 0; fa < nvalid; fa += FR_PER_FFT) {
+        float2 v[8];
+        if (SPLIT1024) {
+          const float* s = sig + fa * p.stride;
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            const int i0 = 2 * (lane + 64 * a);
+            v[a].x = i0 < p.flen_eff ? s[i0] : 0.f;
+            v[a].y = i0 + 1 < p.flen_eff ? s[i0 + 1] : 0.f;
+          }
+        } else {
+          const float* sa = sig + fa * p.stride;
+          const bool hasb = fa + 1 < nvalid;
+          const float* sb = sig + (hasb ? fa + 1 : fa) * p.stride;
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            const int n = lane + 64 * a;
+            const bool in = n < p.flen_eff;
+            v[a].x = in ? sa[n] : 0.f;
+            v[a].y = (in && hasb) ? sb[n] : 0.f;
+          }
+        }
+        fft512_wave(v, scr, lane, t1, t2);
+
+        float2 s7 = shfl2(v[7], mirror), s6 = shfl2(v[6], mirror), s5 = shfl2(v[5], mirror),
+               s4 = shfl2(v[4], mirror);
+        float2 zm[4] = {lane0 ? v[0] : s7, lane0 ? s7 : s6, lane0 ? s6 : s5, lane0 ? s5 : s4};
+        float ea = 0.f, eb = 0.f;
+        float* rowa = ptile + fa * prow;
+        float* rowb = rowa + prow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float2 zk = v[j], zn = zm[j];
+          const int k = lane + 64 * j;
+          if (SPLIT1024) {
+            // X[k] = E + W^k O, X[512-k] = conj(E - W^k O)
+            const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            const float2 O = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+            const float2 Tw = cmul(t3[j], O);
+            const float2 xp = E + Tw, xm = E - Tw;
+            const float pk = (xp.x * xp.x + xp.y * xp.y) * inv_scale;
+            const float pm = (xm.x * xm.x + xm.y * xm.y) * inv_scale;
+            ea += pk + pm;
+            if (k < p.kp) rowa[k] = pk;
+          } else {
+            const float ar = zk.x + zn.x, ai = zk.y - zn.y, br = zk.y + zn.y, bi = zk.x - zn.x;
+            const float pa = (ar * ar + ai * ai) * inv_scale;
+            const float pb = (br * br + bi * bi) * inv_scale;
+            ea += pa;
+            eb += pb;
+            if (k < p.kp) {
+              rowa[k] = pa;
+              rowb[k] = pb;
+            }
+          }
+        }
+        if (lane0) {  // bin nfft/2 (k = 256 of the complex FFT), its own partner
+          const float2 z = v[4];
+          if (SPLIT1024) {
+            ea += (z.x * z.x + z.y * z.y) * inv_scale;  // |E + (-i) O|^2 with E, O real
+          } else {
+            ea += (4.f * z.x * z.x) * inv_scale;
+            eb += (4.f * z.y * z.y) * inv_scale;
+          }
+        }
+        ea = wave_sum(ea);
+        if (!SPLIT1024) eb = wave_sum(eb);
+        if (lane0) {
+          elds[fa] = ea == 0.f ? EPS64 : ea;  // feature.py:205
+          if (!SPLIT1024) elds[fa + 1] = eb == 0.f ? EPS64 : eb;
+        }
+      }
+      __syncthreads();
+
+      // ---- mel^T = fb x P^T (f32 MFMA), block-sparse over 16-bin chunks ---------
+      f32x4 acc[MAX_FT];
+#pragma unroll
+      for (int t = 0; t < MAX_FT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* pb = ptile + jf * prow + 4 * g;
+#pragma unroll
+      for (int t = 0; t < MAX_FT; ++t) {
+        if (t < p.n_ft) {
+          for (int u = p.chunk_lo[t]; u < p.chunk_hi[t]; ++u) {
+            const f32x4 a = p.fbfrag[((int64_t)t * nchunks + u) * 64 + lane];
+            const f32x4 b = *reinterpret_cast<const f32x4*>(pb + 16 * u);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc[t], 0, 0, 0);
+          }
+        }
+      }
+      // lane (jf, g) now holds mel[filter 16 t + 4 g + reg][frame jf]
+      const bool row_ok = jf < nvalid;
+      float* orow = out_rows + (int64_t)jf * p.ncols;
+#pragma unroll
+      for (int t = 0; t < MAX_FT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float m = acc[t][r];
+          m = m == 0.f ? EPS64 : m;  // feature.py:217
+          const int filt = 16 * t + 4 * g + r;
+          if (p.out_kind != SVK_OUT_MFE) m = filt < p.nfilt ? logf(m) : 0.f;
+          acc[t][r] = m;
+        }
+      }
+      if (p.out_kind != SVK_OUT_MFCC) {
+#pragma unroll
+        for (int t = 0; t < MAX_FT; ++t) {
+          const int filt = 16 * t + 4 * g;
+          if (row_ok && t < p.n_ft) {
+            if ((p.ncols & 3) == 0 && filt + 3 < p.nfilt) {
+              *reinterpret_cast<f32x4*>(orow + filt) = acc[t];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (filt + r < p.nfilt) orow[filt + r] = acc[t][r];
+            }
+          }
+        }
+      } else {
+        // ---- cepstra^T = DCT x log(mel)^T: acc[t][r] is already the B operand ------
+        const float le = logf(elds[jf]);
+#pragma unroll
+        for (int c = 0; c < MAX_CT; ++c) {
+          if (c < p.n_ct) {
+            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < MAX_FT; ++t) {
+              if (t < p.n_ft) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const float a = p.dctfrag[(((int64_t)c * p.n_ft + t) * 4 + r) * 64 + lane];
+                  o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[t][r], o, 0, 0, 0);
+                }
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int cep = 16 * c + 4 * g + r;
+              if (row_ok && cep < p.ncols) orow[cep] = (cep == 0 && p.dc_elim) ? le : o[r];  // feature.py:151-152
+            }
+          }
+        }
+      }
+      if (p.energy && row_ok && g == 0) p.energy[(int64_t)utt * p.max_frames + f0 + jf] = elds[jf];
+    }
+
+    // rows of this tile past the clip's last frame: defined (zero) output
+    const int first_bad = nvalid > 0 ? nvalid : 0;
+    int last = p.max_frames - f0;
+    last = last > TILE ? TILE : last;
+    for (int i = first_bad * p.ncols + lane; i < last * p.ncols; i += 64) out_rows[i] = 0.f;
+    if (p.energy)
+      for (int i = first_bad + lane; i < last; i += 64) p.energy[(int64_t)utt * p.max_frames + f0 + i] = 0.f;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// plan: device tables derived on the host, once per configuration
+// ---------------------------------------------------------------------------------
+struct svk_frontend_plan {
+  svk_frontend_cfg cfg;
+  int device;
+  int kp, n_ft, n_ct, ncols, flen_eff, span_pad;
+  int chunk_lo[MAX_FT], chunk_hi[MAX_FT];
+  size_t lds_bytes;
+  void* d_tables;  // one allocation: tw1 | tw2 | tw3 | fbfrag | dctfrag
+  const float2 *tw1, *tw2, *tw3;
+  const f32x4* fbfrag;
+  const float* dctfrag;
+};
+
+extern "C" {
+
+int64_t svk_frontend_num_frames(const svk_frontend_cfg* cfg, int64_t n_samples) {
+  if (!cfg || cfg->frame_stride <= 0 || n_samples < cfg->frame_len) return 0;
+  return (n_samples - cfg->frame_len) / cfg->frame_stride;
+}
+
+int svk_frontend_num_cols(const svk_frontend_cfg* cfg) {
+  if (!cfg) return 0;
+  return cfg->out_kind == SVK_OUT_MFCC ? cfg->num_ceps : cfg->num_filters;
+}
+
+int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const double* h_filterbank,
+                             svk_frontend_plan** out) {
+  if (!ctx || !cfg || !h_filterbank || !out) return SVK_ERR_BAD_ARG;
+  *out = nullptr;
+  SVK_REQUIRE(ctx, cfg->frame_len >= 1 && cfg->frame_stride >= 1, "frame_len / frame_stride must be >= 1");
+  SVK_REQUIRE(ctx, cfg->num_filters >= 1, "num_filters must be >= 1");
+  SVK_REQUIRE(ctx, cfg->out_kind >= SVK_OUT_MFE && cfg->out_kind <= SVK_OUT_MFCC, "out_kind");
+  if (cfg->nfft != 512 && cfg->nfft != 1024)
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "fused front end supports fft_length 512 or 1024, got %d", cfg->nfft);
+  if (cfg->num_filters > 16 * MAX_FT)
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "fused front end supports up to %d filters, got %d", 16 * MAX_FT,
+                    cfg->num_filters);
+  if (cfg->out_kind == SVK_OUT_MFCC)
+    SVK_REQUIRE(ctx, cfg->num_ceps >= 1 && cfg->num_ceps <= cfg->num_filters, "1 <= num_ceps <= num_filters");
+  if (cfg->preemph) SVK_REQUIRE(ctx, cfg->preemph_shift != 0 || true, "preemph_shift");
+
+  svk_frontend_plan* plan = new (std::nothrow) svk_frontend_plan();
+  if (!plan) return SVK_ERR_OOM;
+  plan->cfg = *cfg;
+  plan->device = ctx->device;
+  const int nbins = cfg->nfft / 2 + 1;
+  const int nf = cfg->num_filters;
+  plan->ncols = svk_frontend_num_cols(cfg);
+  plan->n_ft = (nf + 15) / 16;
+  plan->n_ct = cfg->out_kind == SVK_OUT_MFCC ? (cfg->num_ceps + 15) / 16 : 0;
+  plan->flen_eff = cfg->frame_len < cfg->nfft ? cfg->frame_len : cfg->nfft;
+
+  // highest bin with a non-zero weight decides how many power bins are kept
+  int kmax = -1;
+  for (int i = 0; i < nf; ++i)
+    for (int k = 0; k < nbins; ++k)
+      if (h_filterbank[(size_t)i * nbins + k] != 0.0 && k > kmax) kmax = k;
+  if (kmax >= 256) {
+    delete plan;
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED,
+                    "filterbank reaches bin %d; the fused kernel keeps bins < 256 (the SpeechPy bank stops at "
+                    "(nfft/2+2)/2, Q2)", kmax);
+  }
+  plan->kp = ((kmax + 1 + 15) / 16) * 16;
+  if (plan->kp < 16) plan->kp = 16;
+  const int nchunks = plan->kp / 16;
+  for (int t = 0; t < MAX_FT; ++t) {
+    int lo = nchunks, hi = 0;
+    for (int i = 16 * t; i < 16 * t + 16 && i < nf; ++i)
+      for (int k = 0; k < plan->kp && k < nbins; ++k)
+        if (h_filterbank[(size_t)i * nbins + k] != 0.0) {
+          lo = std::min(lo, k / 16);
+          hi = std::max(hi, k / 16 + 1);
+        }
+    if (hi <= lo) lo = hi = 0;
+    plan->chunk_lo[t] = lo;
+    plan->chunk_hi[t] = hi;
+  }
+  const int span = (TILE - 1) * cfg->frame_stride + plan->flen_eff;
+  plan->span_pad = ((span + 31) / 32) * 32 + 32;  // staging writes whole 16-byte groups per lane
+  plan->lds_bytes = sizeof(float) * (size_t)(plan->span_pad + TILE * (plan->kp + PT_PAD) + 2 * SCR + TILE);
+  if (plan->lds_bytes > 160 * 1024) {
+    delete plan;
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "frame stride %d needs %zu bytes of LDS per wave (limit 160 KiB)",
+                    cfg->frame_stride, plan->lds_bytes);
+  }
+
+  // ---- host tables (float64 maths, rounded once to f32) ----
+  const size_t n_tw = 8 * 64, n_tw3 = 5 * 64;
+  const size_t n_fb = (size_t)plan->n_ft * nchunks * 64 * 4;
+  const size_t n_dct = (size_t)std::max(plan->n_ct, 1) * plan->n_ft * 4 * 64;
+  std::vector<float> host(2 * n_tw * 2 + n_tw3 * 2 + n_fb + n_dct, 0.f);
+  float* h_tw1 = host.data();
+  float* h_tw2 = h_tw1 + 2 * n_tw;
+  float* h_tw3 = h_tw2 + 2 * n_tw;
+  float* h_fb = h_tw3 + 2 * n_tw3;
+  float* h_dct = h_fb + n_fb;
+  const double PI = 3.14159265358979323846;
+  for (int r = 0; r < 8; ++r)
+    for (int l = 0; l < 64; ++l) {
+      double a1 = -2.0 * PI * (double)(l * r) / 512.0;
+      double a2 = -2.0 * PI * (double)((l & 7) * r) / 64.0;
+      h_tw1[2 * (r * 64 + l)] = (float)cos(a1);
+      h_tw1[2 * (r * 64 + l) + 1] = (float)sin(a1);
+      h_tw2[2 * (r * 64 + l)] = (float)cos(a2);
+      h_tw2[2 * (r * 64 + l) + 1] = (float)sin(a2);
+    }
+  for (int q = 0; q < 5; ++q)
+    for (int l = 0; l < 64; ++l) {
+      double a = -2.0 * PI * (double)(l + 64 * q) / 1024.0;
+      h_tw3[2 * (q * 64 + l)] = (float)cos(a);
+      h_tw3[2 * (q * 64 + l) + 1] = (float)sin(a);
+    }
+  // A-operand fragments of the filterbank: lane l = (i = l & 15, kk = l >> 4), element e of
+  // chunk u is fb[16 t + i][16 u + 4 kk + e]
+  for (int t = 0; t < plan->n_ft; ++t)
+    for (int u = 0; u < nchunks; ++u)
+      for (int l = 0; l < 64; ++l)
+        for (int e = 0; e < 4; ++e) {
+          const int filt = 16 * t + (l & 15), bin = 16 * u + 4 * (l >> 4) + e;
+          double w = (filt < nf && bin < nbins) ? h_filterbank[(size_t)filt * nbins + bin] : 0.0;
+          h_fb[(((size_t)t * nchunks + u) * 64 + l) * 4 + e] = (float)w;
+        }
+  // A-operand fragments of the DCT-II (ortho) matrix, k-step (t, r) <-> filter 16 t + 4 (l >> 4) + r
+  // scipy.fftpack.dct(type=2, norm='ortho'): D[k][n] = sqrt(2/N) cos(pi k (2n+1) / 2N), D[0][n] = sqrt(1/N)
+  for (int c = 0; c < plan->n_ct; ++c)
+    for (int t = 0; t < plan->n_ft; ++t)
+      for (int r = 0; r < 4; ++r)
+        for (int l = 0; l < 64; ++l) {
+          const int cep = 16 * c + (l & 15), filt = 16 * t + 4 * (l >> 4) + r;
+          double d = 0.0;
+          if (cep < cfg->num_ceps && filt < nf)
+            d = cep == 0 ? sqrt(1.0 / nf) : sqrt(2.0 / nf) * cos(PI * cep * (2.0 * filt + 1.0) / (2.0 * nf));
+          h_dct[(((size_t)c * plan->n_ft + t) * 4 + r) * 64 + l] = (float)d;
+        }
+
+  if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&plan->d_tables, host.size() * sizeof(float)) != hipSuccess) {
+    delete plan;
+    return svk_fail(ctx, SVK_ERR_HIP, "hipMalloc of front-end tables failed");
+  }
+  if (hipMemcpy(plan->d_tables, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(plan->d_tables);
+    delete plan;
+    return svk_fail(ctx, SVK_ERR_HIP, "upload of front-end tables failed");
+  }
+  float* d = reinterpret_cast<float*>(plan->d_tables);
+  plan->tw1 = reinterpret_cast<const float2*>(d);
+  plan->tw2 = reinterpret_cast<const float2*>(d + 2 * n_tw);
+  plan->tw3 = reinterpret_cast<const float2*>(d + 4 * n_tw);
+  plan->fbfrag = reinterpret_cast<const f32x4*>(d + 4 * n_tw + 2 * n_tw3);
+  plan->dctfrag = d + 4 * n_tw + 2 * n_tw3 + n_fb;
+  *out = plan;
+  return SVK_OK;
+}
+
+void svk_frontend_plan_destroy(svk_frontend_plan* plan) {
+  if (!plan) return;
+  if (plan->d_tables) (void)hipFree(plan->d_tables);
+  delete plan;
+}
+
+int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_pcm, int pcm_dtype,
+                     const int64_t* d_offsets, const int32_t* d_lengths, int64_t clip_stride, int32_t clip_len,
+                     int32_t n_utt, int32_t max_frames, float* d_feat, float* d_energy, int32_t* d_n_frames) {
+  if (!ctx || !plan) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, plan->device == ctx->device, "plan belongs to another device");
+  SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 0, "n_utt / max_frames negative");
+  if (n_utt == 0 || max_frames == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_pcm && d_feat, "d_pcm / d_feat is NULL");
+  SVK_REQUIRE(ctx, pcm_dtype == SVK_PCM_I16 || pcm_dtype == SVK_PCM_F32, "pcm_dtype");
+  SVK_REQUIRE(ctx, d_offsets || clip_stride >= 0, "clip_stride negative");
+  SVK_REQUIRE(ctx, d_lengths || clip_len >= 0, "clip_len negative");
+
+  FrontendParams p;
+  p.pcm = d_pcm;
+  p.offsets = d_offsets;
+  p.lengths = d_lengths;
+  p.clip_stride = clip_stride;
+  p.clip_len = clip_len;
+  p.n_utt = n_utt;
+  p.max_frames = max_frames;
+  p.tiles_per_utt = (max_frames + TILE - 1) / TILE;
+  p.flen = plan->cfg.frame_len;
+  p.flen_eff = plan->flen_eff;
+  p.stride = plan->cfg.frame_stride;
+  p.nfilt = plan->cfg.num_filters;
+  p.ncols = plan->ncols;
+  p.out_kind = plan->cfg.out_kind;
+  p.dc_elim = plan->cfg.dc_elimination;
+  p.preemph = plan->cfg.preemph;
+  p.pre_shift = plan->cfg.preemph_shift;
+  p.pre_cof = plan->cfg.preemph_cof;
+  p.kp = plan->kp;
+  p.span_pad = plan->span_pad;
+  p.n_ft = plan->n_ft;
+  p.n_ct = plan->n_ct;
+  for (int t = 0; t < MAX_FT; ++t) {
+    p.chunk_lo[t] = plan->chunk_lo[t];
+    p.chunk_hi[t] = plan->chunk_hi[t];
+  }
+  p.tw1 = plan->tw1;
+  p.tw2 = plan->tw2;
+  p.tw3 = plan->tw3;
+  p.fbfrag = plan->fbfrag;
+  p.dctfrag = plan->dctfrag;
+  p.feat = d_feat;
+  p.energy = d_energy;
+  p.n_frames = d_n_frames;
+
+  const int64_t total = (int64_t)n_utt * p.tiles_per_utt;
+  const int waves_per_cu = std::max(1, std::min(32, (int)(ctx->lds_per_cu / plan->lds_bytes)));
+  int64_t grid = std::min<int64_t>(total, (int64_t)ctx->num_cu * waves_per_cu * 2);
+  const bool split = plan->cfg.nfft == 1024;
+  void (*kern)(const FrontendParams) = nullptr;
+  if (pcm_dtype == SVK_PCM_I16)
+    kern = split ? frontend_kernel<int16_t, true> : frontend_kernel<int16_t, false>;
+  else
+    kern = split ? frontend_kernel<float, true> : frontend_kernel<float, false>;
+  SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)plan->lds_bytes));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), plan->lds_bytes, ctx->stream, p);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+}  // extern "C"

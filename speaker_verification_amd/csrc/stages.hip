@@ -1,0 +1,347 @@
+// Stage-level entry points: one kernel per SpeechPy function, so that every function of
+// the reference's processing module can be routed to the GPU on its own.
+//   svk_preemphasis  <- processing.py:45-58      svk_stack_frames <- processing.py:61-139
+//   svk_spectrum     <- processing.py:142-174    svk_cmvn         <- processing.py:239-271
+//   svk_cube_gather  <- /root/reference/utils.py:351-379
+// All of these are HBM-streaming kernels: 16-byte accesses where alignment allows,
+// grid capped at a few workgroups per CU with a grid-stride loop.
+#include <algorithm>
+
+#include "fft_wave.h"
+#include "svk_internal.h"
+
+using namespace svk_fft;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+inline unsigned capped_grid(const svk_ctx* ctx, int64_t work_items, int per_block) {
+  int64_t blocks = (work_items + per_block - 1) / per_block;
+  int64_t cap = (int64_t)ctx->num_cu * 8;
+  return (unsigned)std::max<int64_t>(1, std::min(blocks, cap));
+}
+
+// ---- pre-emphasis ---------------------------------------------------------------
+template <typename PcmT>
+__global__ __launch_bounds__(256) void preemph_kernel(const PcmT* __restrict__ x, int64_t n, int64_t shift_mod,
+                                                      float cof, float* __restrict__ y) {
+  // shift_mod = shift mod n in [0, n): y[i] = x[i] - cof * x[(i - shift) mod n]
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t j = i - shift_mod;
+    if (j < 0) j += n;
+    y[i] = (float)x[i] - cof * (float)x[j];
+  }
+}
+
+// ---- framing ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stack_frames_kernel(const float* __restrict__ sig, int64_t n, int flen,
+                                                           int stride, int64_t total, const float* __restrict__ win,
+                                                           float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / flen;
+    const int j = (int)(i - t * flen);
+    const int64_t s = t * stride + j;
+    float v = s < n ? sig[s] : 0.f;  // zero padding of processing.py:107-109
+    if (win) v *= win[j];
+    out[i] = v;
+  }
+}
+
+// ---- spectrum: wave FFT for nfft 512 / 1024 ------------------------------------------
+// One wave per workgroup; nfft = 512 handles two frames per FFT, nfft = 1024 one.
+template <bool SPLIT1024>
+__global__ __launch_bounds__(64) void spectrum_fft_kernel(const float* __restrict__ frames, int nframes, int flen,
+                                                          int power, const float2* __restrict__ tw,
+                                                          float* __restrict__ out) {
+  __shared__ float2 scr[SCR];
+  const int lane = threadIdx.x;
+  const int nfft = SPLIT1024 ? 1024 : 512;
+  const int nbins = nfft / 2 + 1;
+  const int feff = flen < nfft ? flen : nfft;
+  float2 t1[8], t2[8], t3[5];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    t1[r] = tw[r * 64 + lane];
+    t2[r] = tw[512 + r * 64 + lane];
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) t3[q] = tw[1024 + q * 64 + lane];
+  const int mirror = (64 - lane) & 63;
+  const bool lane0 = lane == 0;
+  constexpr int PER = SPLIT1024 ? 1 : 2;
+  const float scale = power ? (SPLIT1024 ? 1.f / 1024.f : 1.f / 2048.f) : (SPLIT1024 ? 1.f : 0.25f);
+  for (int fa = blockIdx.x * PER; fa < nframes; fa += gridDim.x * PER) {
+    const float* sa = frames + (int64_t)fa * flen;
+    const bool hasb = !SPLIT1024 && fa + 1 < nframes;
+    const float* sb = frames + (int64_t)(hasb ? fa + 1 : fa) * flen;
+    float2 v[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      if (SPLIT1024) {
+        const int i0 = 2 * (lane + 64 * a);
+        v[a].x = i0 < feff ? sa[i0] : 0.f;
+        v[a].y = i0 + 1 < feff ? sa[i0 + 1] : 0.f;
+      } else {
+        const int nn = lane + 64 * a;
+        v[a].x = nn < feff ? sa[nn] : 0.f;
+        v[a].y = (nn < feff && hasb) ? sb[nn] : 0.f;
+      }
+    }
+    fft512_wave(v, scr, lane, t1, t2);
+    float2 s7 = shfl2(v[7], mirror), s6 = shfl2(v[6], mirror), s5 = shfl2(v[5], mirror), s4 = shfl2(v[4], mirror);
+    float2 zm[5] = {lane0 ? v[0] : s7, lane0 ? s7 : s6, lane0 ? s6 : s5, lane0 ? s5 : s4, v[4]};
+    float* oa = out + (int64_t)fa * nbins;
+    float* ob = oa + nbins;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j == 4 && !lane0) continue;
+      const float2 zk = v[j], zn = zm[j];
+      const int k = j == 4 ? 256 : lane + 64 * j;
+      if (SPLIT1024) {
+        const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const float2 O = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        const float2 Tw = cmul(t3[j], O);
+        const float2 xp = E + Tw, xm = E - Tw;
+        float pk = (xp.x * xp.x + xp.y * xp.y) * scale, pm = (xm.x * xm.x + xm.y * xm.y) * scale;
+        if (!power) {
+          pk = sqrtf(pk);
+          pm = sqrtf(pm);
+        }
+        oa[k] = pk;
+        if (j != 4) oa[512 - k] = pm;
+      } else {
+        const float ar = zk.x + zn.x, ai = zk.y - zn.y, br = zk.y + zn.y, bi = zk.x - zn.x;
+        float pa = (ar * ar + ai * ai) * scale, pb = (br * br + bi * bi) * scale;
+        if (!power) {
+          pa = sqrtf(pa);
+          pb = sqrtf(pb);
+        }
+        oa[k] = pa;
+        if (hasb) ob[k] = pb;
+      }
+    }
+  }
+}
+
+// ---- spectrum: direct DFT for every other length (O(n^2), float64 phase) -----------------
+__global__ __launch_bounds__(256) void spectrum_dft_kernel(const float* __restrict__ frames, int nframes, int flen,
+                                                           int nfft, int power, float* __restrict__ out) {
+  const int nbins = nfft / 2 + 1;
+  const int feff = flen < nfft ? flen : nfft;
+  const int64_t total = (int64_t)nframes * nbins;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = i / nbins;
+    const int k = (int)(i - f * nbins);
+    const float* s = frames + f * flen;
+    double re = 0.0, im = 0.0;
+    for (int nn = 0; nn < feff; ++nn) {
+      const int ph = (int)(((int64_t)k * nn) % nfft);
+      double sn, cs;
+      sincospi(2.0 * (double)ph / (double)nfft, &sn, &cs);
+      re += (double)s[nn] * cs;
+      im -= (double)s[nn] * sn;
+    }
+    const double mag2 = re * re + im * im;
+    out[i] = (float)(power ? mag2 / (double)nfft : sqrt(mag2));
+  }
+}
+
+// ---- CMVN: one workgroup per clip ------------------------------------------------------
+// Threads form a [R rows][cb cols] grid over a column block; column sums are kept in float64.
+__global__ __launch_bounds__(256) void cmvn_kernel(float* __restrict__ feat, int max_frames, int ncols,
+                                                   const int32_t* __restrict__ n_frames, int variance) {
+  __shared__ double red[256];
+  const int utt = blockIdx.x;
+  int T = n_frames ? n_frames[utt] : max_frames;
+  T = T < max_frames ? T : max_frames;
+  if (T <= 0) return;
+  float* base = feat + (int64_t)utt * max_frames * ncols;
+  for (int c0 = 0; c0 < ncols; c0 += 256) {
+    const int cb = min(256, ncols - c0);  // columns in this block
+    const int R = 256 / cb;               // row groups
+    const int tc = threadIdx.x % cb, tr = threadIdx.x / cb;
+    const bool active = tr < R;
+    // pass 1: mean
+    double s = 0.0;
+    if (active)
+      for (int t = tr; t < T; t += R) s += (double)base[(int64_t)t * ncols + c0 + tc];
+    red[threadIdx.x] = active ? s : 0.0;
+    __syncthreads();
+    double mean = 0.0;
+    if (active) {
+      for (int r = 0; r < R; ++r) mean += red[r * cb + tc];
+      mean /= (double)T;
+    }
+    __syncthreads();
+    // pass 2: population std of the centred values (processing.py:264)
+    double inv = 1.0;
+    if (variance) {
+      double q = 0.0;
+      if (active)
+        for (int t = tr; t < T; t += R) {
+          const double d = (double)base[(int64_t)t * ncols + c0 + tc] - mean;
+          q += d * d;
+        }
+      red[threadIdx.x] = active ? q : 0.0;
+      __syncthreads();
+      if (active) {
+        double var = 0.0;
+        for (int r = 0; r < R; ++r) var += red[r * cb + tc];
+        inv = 1.0 / (sqrt(var / (double)T) + 9.313225746154785e-10);  // + 2^-30, processing.py:250,266
+      }
+      __syncthreads();
+    }
+    if (active)
+      for (int t = tr; t < T; t += R) {
+        const int64_t o = (int64_t)t * ncols + c0 + tc;
+        base[o] = (float)(((double)base[o] - mean) * inv);
+      }
+    __syncthreads();
+  }
+}
+
+// ---- feature cube: each crop is one contiguous run of crop_frames * ncols floats ---------------
+__global__ __launch_bounds__(256) void cube_gather_kernel(const float* __restrict__ feat, int max_frames, int ncols,
+                                                          const int32_t* __restrict__ crop, int n_crops,
+                                                          int crop_frames, int64_t n_jobs, float* __restrict__ out) {
+  const int run = crop_frames * ncols;
+  for (int64_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
+    const int64_t utt = job / n_crops;
+    int start = crop[job];
+    start = start < 0 ? 0 : (start > max_frames ? max_frames : start);
+    const float* src = feat + (utt * max_frames + start) * ncols;
+    float* dst = out + job * run;
+    const int avail = (max_frames - start) * ncols;  // never read past the clip's rows
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 &&
+                     (run & 3) == 0 && avail >= run;
+    if (vec) {
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+      f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+      for (int i = threadIdx.x; i < run / 4; i += blockDim.x) d4[i] = s4[i];
+    } else {
+      for (int i = threadIdx.x; i < run; i += blockDim.x) dst[i] = i < avail ? src[i] : 0.f;
+    }
+  }
+}
+
+// twiddles for spectrum_fft_kernel: tw1 [8][64] | tw2 [8][64] | tw3 [5][64]
+float2* g_spectrum_tables[64] = {nullptr};
+
+int spectrum_tables(svk_ctx* ctx, const float2** out) {
+  if (ctx->device < 0 || ctx->device >= 64) return svk_fail(ctx, SVK_ERR_BAD_ARG, "device index out of range");
+  float2*& d = g_spectrum_tables[ctx->device];
+  if (!d) {
+    const double PI = 3.14159265358979323846;
+    static float2 h[1024 + 5 * 64];
+    for (int r = 0; r < 8; ++r)
+      for (int l = 0; l < 64; ++l) {
+        const double a1 = -2.0 * PI * (double)(l * r) / 512.0, a2 = -2.0 * PI * (double)((l & 7) * r) / 64.0;
+        h[r * 64 + l] = make_float2((float)cos(a1), (float)sin(a1));
+        h[512 + r * 64 + l] = make_float2((float)cos(a2), (float)sin(a2));
+      }
+    for (int q = 0; q < 5; ++q)
+      for (int l = 0; l < 64; ++l) {
+        const double a = -2.0 * PI * (double)(l + 64 * q) / 1024.0;
+        h[1024 + q * 64 + l] = make_float2((float)cos(a), (float)sin(a));
+      }
+    SVK_HIP(ctx, hipSetDevice(ctx->device));
+    SVK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(h)));
+    SVK_HIP(ctx, hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
+  }
+  *out = d;
+  return SVK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int svk_preemphasis(svk_ctx* ctx, const void* d_in, int pcm_dtype, int64_t n, int32_t shift, float cof,
+                    float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n >= 0, "n negative");
+  if (n == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_in && d_out, "NULL buffer");
+  SVK_REQUIRE(ctx, pcm_dtype == SVK_PCM_I16 || pcm_dtype == SVK_PCM_F32, "pcm_dtype");
+  int64_t sm = (int64_t)shift % n;
+  if (sm < 0) sm += n;
+  const unsigned grid = capped_grid(ctx, n, 256);
+  if (pcm_dtype == SVK_PCM_I16)
+    hipLaunchKernelGGL(preemph_kernel<int16_t>, dim3(grid), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const int16_t*>(d_in), n, sm, cof, d_out);
+  else
+    hipLaunchKernelGGL(preemph_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const float*>(d_in), n, sm, cof, d_out);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+int svk_stack_frames(svk_ctx* ctx, const float* d_sig, int64_t n, int32_t frame_len, int32_t stride,
+                     int32_t n_frames, const float* d_window, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n >= 0 && frame_len >= 1 && stride >= 1 && n_frames >= 0, "negative or zero geometry");
+  if (n_frames == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_sig && d_out, "NULL buffer");
+  const int64_t total = (int64_t)n_frames * frame_len;
+  hipLaunchKernelGGL(stack_frames_kernel, dim3(capped_grid(ctx, total, 256)), dim3(256), 0, ctx->stream, d_sig, n,
+                     frame_len, stride, total, d_window, d_out);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+int svk_spectrum(svk_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_len, int32_t nfft,
+                 int32_t power, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_frames >= 0 && frame_len >= 1 && nfft >= 2, "geometry");
+  if (n_frames == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_frames && d_out, "NULL buffer");
+  if (nfft == 512 || nfft == 1024) {
+    const float2* tw = nullptr;
+    int rc = spectrum_tables(ctx, &tw);
+    if (rc != SVK_OK) return rc;
+    if (nfft == 512) {
+      const unsigned grid = capped_grid(ctx, (n_frames + 1) / 2, 1);
+      hipLaunchKernelGGL(spectrum_fft_kernel<false>, dim3(grid), dim3(64), 0, ctx->stream, d_frames, n_frames,
+                         frame_len, power, tw, d_out);
+    } else {
+      const unsigned grid = capped_grid(ctx, n_frames, 1);
+      hipLaunchKernelGGL(spectrum_fft_kernel<true>, dim3(grid), dim3(64), 0, ctx->stream, d_frames, n_frames,
+                         frame_len, power, tw, d_out);
+    }
+  } else {
+    const int64_t total = (int64_t)n_frames * (nfft / 2 + 1);
+    hipLaunchKernelGGL(spectrum_dft_kernel, dim3(capped_grid(ctx, total, 256)), dim3(256), 0, ctx->stream, d_frames,
+                       n_frames, frame_len, nfft, power, d_out);
+  }
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+             const int32_t* d_n_frames, int32_t variance) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 0 && n_cols >= 0, "negative shape");
+  if (n_utt == 0 || max_frames == 0 || n_cols == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_feat, "NULL buffer");
+  hipLaunchKernelGGL(cmvn_kernel, dim3(n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols, d_n_frames,
+                     variance);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+int svk_cube_gather(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                    const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_utt >= 0 && n_crops >= 0 && crop_frames >= 0 && n_cols >= 0 && max_frames >= 0, "negative shape");
+  const int64_t jobs = (int64_t)n_utt * n_crops;
+  if (jobs == 0 || crop_frames == 0 || n_cols == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_feat && d_crop_idx && d_out, "NULL buffer");
+  SVK_REQUIRE(ctx, crop_frames <= max_frames, "crop_frames exceeds max_frames");
+  const unsigned grid = (unsigned)std::min<int64_t>(jobs, (int64_t)ctx->num_cu * 16);
+  hipLaunchKernelGGL(cube_gather_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols,
+                     d_crop_idx, n_crops, crop_frames, jobs, d_out);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+}  // extern "C"

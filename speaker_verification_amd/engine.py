@@ -1,0 +1,304 @@
+"""Device engine: the thin host layer between Python callers and libsvk.so.
+
+One `Engine` per process and GPU.  torch supplies device memory and streams
+(plumbing); every computation below is a hand-written gfx950 kernel reached
+through the C-ABI.  Methods take torch CUDA tensors (zero-copy) or NumPy arrays
+(uploaded) and return torch CUDA tensors; the drop-in modules
+(`speechpy/`, `vad.py`, `evaluation.py`, `siamese.py`) convert to the
+reference's NumPy return types.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import FrontendCfg, check
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class FrontendSpec:
+    """Hashable description of one front-end configuration (SURVEY.md section 5:
+    'a small frozen FrontEndConfig')."""
+
+    __slots__ = ("fs", "frame_len", "frame_stride", "nfft", "num_filters", "num_ceps", "out_kind",
+                 "dc_elimination", "low_freq", "high_freq", "preemph", "preemph_shift", "preemph_cof")
+
+    def __init__(self, fs, frame_len, frame_stride, nfft, num_filters, num_ceps, out_kind,
+                 dc_elimination=True, low_freq=0, high_freq=None, preemph=False, preemph_shift=1,
+                 preemph_cof=0.98):
+        self.fs, self.frame_len, self.frame_stride, self.nfft = fs, int(frame_len), int(frame_stride), int(nfft)
+        self.num_filters, self.num_ceps, self.out_kind = int(num_filters), int(num_ceps), int(out_kind)
+        self.dc_elimination, self.low_freq, self.high_freq = bool(dc_elimination), low_freq, high_freq
+        self.preemph, self.preemph_shift, self.preemph_cof = bool(preemph), int(preemph_shift), float(preemph_cof)
+
+    def key(self):
+        return tuple(getattr(self, s) for s in self.__slots__)
+
+    @property
+    def num_cols(self):
+        return self.num_ceps if self.out_kind == _lib.OUT_MFCC else self.num_filters
+
+    def num_frames(self, n_samples):
+        """floor((L - flen) / stride), never negative (processing.py:115-116, Q3)."""
+        return max(0, int(math.floor((n_samples - self.frame_len) / float(self.frame_stride)))) \
+            if n_samples >= self.frame_len else 0
+
+    def c_struct(self):
+        return FrontendCfg(self.frame_len, self.frame_stride, self.nfft, self.num_filters,
+                           max(1, self.num_ceps), self.out_kind, int(self.dc_elimination), int(self.preemph),
+                           self.preemph_shift, self.preemph_cof)
+
+
+def spec_from_seconds(fs, frame_length, frame_stride, nfft, num_filters, num_ceps, out_kind, **kw):
+    """frame sizes as the reference derives them (processing.py:94-98)."""
+    flen = int(np.round(fs * frame_length))
+    stride = int(float(np.round(fs * frame_stride)))
+    return FrontendSpec(fs, flen, stride, nfft, num_filters, num_ceps, out_kind, **kw)
+
+
+class Engine:
+    def __init__(self, device=None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("speaker_verification_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        handle = C.c_void_p()
+        check(self.lib.svk_create(self.device_index, C.byref(handle)))
+        self.ctx = handle
+        self._plans = {}
+        info = (C.c_int64 * 4)()
+        check(self.lib.svk_device_info(self.ctx, info), self.ctx)
+        self.num_cu, self.clock_khz, self.lds_per_cu, self.wave = (int(v) for v in info)
+
+    def __del__(self):
+        try:
+            for plan, _ in self._plans.values():
+                self.lib.svk_frontend_plan_destroy(plan)
+            if self.ctx:
+                self.lib.svk_destroy(self.ctx)
+        except Exception:
+            pass
+
+    # ---- plumbing -----------------------------------------------------------
+    def _stream(self):
+        torch = _torch()
+        stream = torch.cuda.current_stream(self.device)
+        check(self.lib.svk_set_stream(self.ctx, C.c_void_p(stream.cuda_stream)), self.ctx)
+
+    def to_device(self, x, dtype=None):
+        """torch CUDA tensor (contiguous) from a NumPy array / tensor."""
+        torch = _torch()
+        if isinstance(x, torch.Tensor):
+            t = x.to(self.device)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        return t.contiguous()
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def synchronize(self):
+        check(self.lib.svk_sync(self.ctx), self.ctx)
+
+    # ---- fused front end -------------------------------------------------------
+    def plan(self, spec):
+        from .speechpy import feature as _feature
+        key = spec.key()
+        hit = self._plans.get(key)
+        if hit is None:
+            bank = np.ascontiguousarray(
+                _feature.filterbanks(spec.num_filters, spec.nfft // 2 + 1, spec.fs, spec.low_freq,
+                                     spec.high_freq or spec.fs / 2), dtype=np.float64)
+            cfg = spec.c_struct()
+            handle = C.c_void_p()
+            check(self.lib.svk_frontend_plan_create(self.ctx, C.byref(cfg),
+                                                    bank.ctypes.data_as(C.POINTER(C.c_double)), C.byref(handle)),
+                  self.ctx)
+            hit = (handle, cfg)
+            self._plans[key] = hit
+        return hit
+
+    def features(self, pcm, spec, lengths=None, offsets=None, clip_len=None, max_frames=None,
+                 want_energy=False):
+        """Batched front end.
+
+        pcm     : [n_utt, L] (uniform clips) or, with `offsets`, a 1-D concatenation;
+                  int16 or float32, NumPy or CUDA tensor
+        lengths : optional [n_utt] int32 samples per clip (device or host)
+        returns (feat [n_utt, max_frames, cols] f32, n_frames [n_utt] i32, energy or None)
+        """
+        torch = _torch()
+        handle, _ = self.plan(spec)
+        pcm = self.to_device(pcm)
+        if pcm.dtype == torch.int16:
+            kind = _lib.PCM_I16
+        else:
+            pcm = pcm.to(torch.float32) if pcm.dtype != torch.float32 else pcm
+            kind = _lib.PCM_F32
+        if lengths is not None:
+            lengths = self.to_device(lengths, torch.int32)
+        if offsets is not None:
+            if lengths is None:
+                raise ValueError("offsets need lengths")
+            offsets = self.to_device(offsets, torch.int64)
+            n_utt, stride, length = offsets.numel(), 0, 0
+            longest = int(lengths.max().item()) if n_utt else 0
+        else:
+            if pcm.dim() == 1:
+                pcm = pcm[None]
+            n_utt, stride = pcm.shape[0], pcm.shape[1]
+            length = stride if clip_len is None else int(clip_len)
+            longest = length
+        if max_frames is None:
+            max_frames = spec.num_frames(longest)
+        cols = spec.num_cols
+        feat = torch.empty((n_utt, max_frames, cols), dtype=torch.float32, device=self.device)
+        n_frames = torch.empty((n_utt,), dtype=torch.int32, device=self.device)
+        energy = torch.empty((n_utt, max_frames), dtype=torch.float32, device=self.device) if want_energy else None
+        self._stream()
+        check(self.lib.svk_frontend_run(self.ctx, handle, self._ptr(pcm), kind, self._ptr(offsets),
+                                        self._ptr(lengths), stride, length, n_utt, max_frames,
+                                        self._ptr(feat), self._ptr(energy), self._ptr(n_frames)), self.ctx)
+        return feat, n_frames, energy
+
+    # ---- stage-level kernels ------------------------------------------------------
+    def preemphasis(self, signal, shift=1, cof=0.98):
+        torch = _torch()
+        x = self.to_device(signal)
+        if x.dtype == torch.int16:
+            kind = _lib.PCM_I16
+        else:
+            x = x.to(torch.float32)
+            kind = _lib.PCM_F32
+        out = torch.empty(x.shape, dtype=torch.float32, device=self.device)
+        self._stream()
+        check(self.lib.svk_preemphasis(self.ctx, self._ptr(x), kind, x.numel(), int(shift), float(cof),
+                                       self._ptr(out)), self.ctx)
+        return out
+
+    def stack_frames(self, sig, frame_len, stride, n_frames, window=None):
+        torch = _torch()
+        x = self.to_device(sig, torch.float32)
+        win = self.to_device(window, torch.float32) if window is not None else None
+        out = torch.empty((max(n_frames, 0), frame_len), dtype=torch.float32, device=self.device)
+        self._stream()
+        check(self.lib.svk_stack_frames(self.ctx, self._ptr(x), x.numel(), int(frame_len), int(stride),
+                                        int(max(n_frames, 0)), self._ptr(win), self._ptr(out)), self.ctx)
+        return out
+
+    def spectrum(self, frames, nfft, power):
+        torch = _torch()
+        fr = self.to_device(frames, torch.float32)
+        if fr.dim() != 2:
+            raise ValueError("frames must be (num_frames, frame_len)")
+        out = torch.empty((fr.shape[0], nfft // 2 + 1), dtype=torch.float32, device=self.device)
+        self._stream()
+        check(self.lib.svk_spectrum(self.ctx, self._ptr(fr), fr.shape[0], fr.shape[1], int(nfft), int(bool(power)),
+                                    self._ptr(out)), self.ctx)
+        return out
+
+    def cmvn_(self, feat, n_frames=None, variance=False):
+        """In place on feat [n_utt, max_frames, cols] (or [rows, cols] = one clip)."""
+        torch = _torch()
+        if not (isinstance(feat, torch.Tensor) and feat.is_cuda and feat.dtype == torch.float32
+                and feat.is_contiguous()):
+            raise ValueError("cmvn_ works in place on a contiguous float32 CUDA tensor")
+        shape = feat.shape if feat.dim() == 3 else (1,) + tuple(feat.shape)
+        nf = self.to_device(n_frames, torch.int32) if n_frames is not None else None
+        self._stream()
+        check(self.lib.svk_cmvn(self.ctx, self._ptr(feat), shape[0], shape[1], shape[2], self._ptr(nf),
+                                int(bool(variance))), self.ctx)
+        return feat
+
+    def vad_energy(self, pcm, threshold, fs=16000, frame_ms=30, padding_ms=300, lengths=None, compact=True,
+                   want_segments=False, frame_samples=None, ring_len=None):
+        """pcm [n_utt, L] int16 -> dict(keep [n, F] u8, n_vad_frames [n] i32, voiced [n, L] i16,
+        voiced_len [n] i32, seg [n, F] i32)."""
+        torch = _torch()
+        x = self.to_device(pcm)
+        if x.dtype != torch.int16:
+            raise TypeError("VAD works on int16 PCM (vad.py:16-17 asserts 16-bit mono)")
+        if x.dim() == 1:
+            x = x[None]
+        n_utt, L = x.shape
+        fsamp = int(frame_samples) if frame_samples else int(fs * (frame_ms / 1000.0) * 2) // 2   # vad.py:50
+        ring_len = int(ring_len) if ring_len else int(padding_ms / frame_ms)                       # vad.py:81
+        ring_thresh = int(math.floor(0.9 * ring_len))                    # count > 0.9 * maxlen, vad.py:99,117
+        max_vf = max(1, (2 * L - 1) // (2 * fsamp)) if L > 0 else 1
+        lens = self.to_device(lengths, torch.int32) if lengths is not None else None
+        keep = torch.empty((n_utt, max_vf), dtype=torch.uint8, device=self.device)
+        nvf = torch.empty((n_utt,), dtype=torch.int32, device=self.device)
+        seg = torch.empty((n_utt, max_vf), dtype=torch.int32, device=self.device) if want_segments else None
+        voiced = torch.zeros_like(x) if compact else None
+        vlen = torch.empty((n_utt,), dtype=torch.int32, device=self.device) if compact else None
+        self._stream()
+        check(self.lib.svk_vad_energy(self.ctx, self._ptr(x), None, self._ptr(lens), L, L, n_utt, fsamp, ring_len,
+                                      ring_thresh, int(threshold), max_vf, self._ptr(keep), self._ptr(seg),
+                                      self._ptr(nvf), self._ptr(voiced), self._ptr(vlen)), self.ctx)
+        return {"keep": keep, "n_vad_frames": nvf, "voiced": voiced, "voiced_len": vlen, "seg": seg,
+                "frame_samples": fsamp}
+
+    def cube_gather(self, feat, crop_idx, crop_frames=80, out=None):
+        """feat [n, T, C] + crop_idx [n, n_crops] -> [n, 1, n_crops, crop_frames, C] (utils.py:364-379)."""
+        torch = _torch()
+        feat = self.to_device(feat, torch.float32)
+        idx = self.to_device(crop_idx, torch.int32)
+        n, T, Cc = feat.shape
+        n_crops = idx.shape[1]
+        if out is None:
+            out = torch.empty((n, 1, n_crops, crop_frames, Cc), dtype=torch.float32, device=self.device)
+        self._stream()
+        check(self.lib.svk_cube_gather(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), n_crops, crop_frames,
+                                       self._ptr(out)), self.ctx)
+        return out
+
+    def cosine_scores(self, test, enroll):
+        torch = _torch()
+        t = self.to_device(test, torch.float32)
+        e = self.to_device(enroll, torch.float32)
+        if t.dim() != 2 or e.dim() != 2 or t.shape[1] != e.shape[1]:
+            raise ValueError("cosine_scores wants (Nt, D) and (Ns, D)")
+        out = torch.empty((t.shape[0], e.shape[0]), dtype=torch.float32, device=self.device)
+        self._stream()
+        check(self.lib.svk_cosine_scores(self.ctx, self._ptr(t), self._ptr(e), t.shape[0], e.shape[0], t.shape[1],
+                                         self._ptr(out)), self.ctx)
+        return out
+
+    def l2_dist(self, a, b):
+        torch = _torch()
+        a = self.to_device(a, torch.float32)
+        b = self.to_device(b, torch.float32)
+        if a.shape != b.shape or a.dim() != 2:
+            raise ValueError("l2_dist wants two (n, D) matrices")
+        out = torch.empty((a.shape[0],), dtype=torch.float32, device=self.device)
+        self._stream()
+        check(self.lib.svk_l2_dist(self.ctx, self._ptr(a), self._ptr(b), a.shape[0], a.shape[1], self._ptr(out)),
+              self.ctx)
+        return out
+
+
+_engines = {}
+
+
+def get_engine(device=None):
+    """Process-wide engine for `device` (default: torch's current CUDA device)."""
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError("speaker_verification_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+    index = torch.cuda.current_device() if device is None else int(device)
+    eng = _engines.get(index)
+    if eng is None:
+        eng = _engines[index] = Engine(index)
+    return eng

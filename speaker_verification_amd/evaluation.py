@@ -1,0 +1,141 @@
+"""evaluation.py drop-in (`/root/reference/evaluation.py`): `get_eer_auc`,
+`get_and_plot_k_eer_auc`, `Evaluation(...).compute_Similarity(...)`,
+`evaluate()`.
+
+The reference scores one (utterance, speaker) pair per sklearn call inside a
+Python double loop (evaluation.py:67-84, 112-134); here the whole score matrix
+is one MFMA kernel launch (`svk_cosine_scores`).  ROC / EER / AUC stay on the
+host exactly as the reference computes them (sklearn + scipy, evaluation.py:
+47-52): one sort of n_test * n_speakers scores, milliseconds at the VoxCeleb1
+verification shape (SURVEY.md 8(f) lists a GPU ROC as a later row).
+"""
+import os
+
+import numpy as np
+import torch
+
+from .engine import get_engine
+
+
+def get_eer_auc(label, distance):
+    """(eer, auc, fpr, tpr) from flat labels and scores (evaluation.py:47-52)."""
+    from scipy.interpolate import interp1d
+    from scipy.optimize import brentq
+    from sklearn.metrics import roc_auc_score, roc_curve
+    fpr, tpr, thresholds = roc_curve(label, distance, pos_label=1)
+    auc = roc_auc_score(label, distance)
+    eer = brentq(lambda x: 1. - x - interp1d(fpr, tpr)(x), 0., 1.)
+    return eer, auc, fpr, tpr
+
+
+def get_and_plot_k_eer_auc(label, scores, k=1, plot_path='eer_auc.png'):
+    """Mean EER / AUC over k consecutive equal slices, printed in percent, ROC
+    curves saved to `plot_path` when matplotlib is importable (evaluation.py:11-44).
+    Returns (mean_eer, mean_auc) in addition to the reference's prints."""
+    step = int(label.shape[0] / float(k))
+    eers, aucs, curves = np.zeros((k, 1)), np.zeros((k, 1)), []
+    for split_num in range(k):
+        lo, hi = split_num * step, (split_num + 1) * step
+        eers[split_num], aucs[split_num], fpr, tpr = get_eer_auc(label[lo:hi], scores[lo:hi])
+        curves.append((fpr, tpr))
+    print("EER=", np.mean(eers) * 100)
+    print("AUC=", np.mean(aucs) * 100)
+    if plot_path:
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            fig = plt.figure()
+            ax = fig.gca()
+            for split_num, (fpr, tpr) in enumerate(curves):
+                plt.setp(plt.plot(fpr, tpr, label='{} split'.format(split_num)), linewidth=2)
+            ax.set_xticks(np.arange(0, 1.1, 0.1))
+            ax.set_yticks(np.arange(0, 1.1, 0.1))
+            plt.title('ROC with {}-fold cross validation'.format(k))
+            plt.xlabel('False Positive Rate')
+            plt.ylabel('True Positive Rate')
+            plt.grid()
+            plt.savefig(plot_path)
+            plt.close(fig)
+        except ImportError:
+            pass
+    return float(np.mean(eers)), float(np.mean(aucs))
+
+
+def score_matrix(test_embeddings, enroll_embeddings):
+    """[Nt, D] x [Ns, D] -> [Nt, Ns] float32 cosine scores on the device."""
+    return get_engine().cosine_scores(test_embeddings, enroll_embeddings)
+
+
+class Evaluation:
+    """Same constructor and `compute_Similarity` as evaluation.py:55-84.
+    `speaker_models_path` may be a directory of `{speaker_id}.pt` tensors (the
+    reference's format, Q17) or a dict {speaker_id: (1, D) tensor}."""
+
+    def __init__(self, background_model, speaker_models_path):
+        self.model = background_model
+        self.speaker_models = {}
+        if isinstance(speaker_models_path, dict):
+            for key, value in speaker_models_path.items():
+                self.speaker_models[key] = torch.as_tensor(value)
+        else:
+            for file in sorted(os.listdir(speaker_models_path)):          # explicit order
+                if file.endswith('.pt'):
+                    self.speaker_models[file.replace('.pt', '')] = torch.load(
+                        os.path.join(speaker_models_path, file), map_location="cpu", weights_only=True)
+        self._enroll = None
+
+    def _enroll_matrix(self):
+        if self._enroll is None:
+            eng = get_engine()
+            rows = [m.detach().reshape(1, -1).to(torch.float32) for m in self.speaker_models.values()]
+            self._enroll = eng.to_device(torch.cat(rows, dim=0))
+        return self._enroll
+
+    def embed(self, utterance):
+        eng = get_engine()
+        self.model.eval()
+        self.model.to(eng.device)
+        with torch.no_grad():
+            return self.model(eng.to_device(utterance, torch.float32), development=False)
+
+    def compute_Similarity(self, utterance, type='cosine_similarity'):
+        """(similarity_vec, assigned_speaker_vec), both float64 of length n_speakers."""
+        speaker_features = self.embed(utterance)
+        if type == 'cosine_similarity':
+            scores = get_engine().cosine_scores(speaker_features[:1], self._enroll_matrix())
+            similarity_vec = scores[0].to("cpu").numpy().astype(np.float64)
+            assigned_speaker_vec = np.zeros(len(self.speaker_models))
+            assigned_speaker_vec[np.argmax(similarity_vec)] = 1
+            return similarity_vec, assigned_speaker_vec
+
+    def score_all(self, cubes, batch=256):
+        """[N, 1, 20, 80, 40] cubes -> [N, n_speakers] float32 scores (device), batched."""
+        outs = []
+        for lo in range(0, len(cubes), batch):
+            outs.append(get_engine().cosine_scores(self.embed(cubes[lo:lo + batch]), self._enroll_matrix()))
+        return torch.cat(outs, dim=0)
+
+
+def labels_from_ids(test_ids, speaker_ids):
+    """One-hot truth rows like evaluation.py:130-132."""
+    speaker_ids = list(speaker_ids)
+    labels = np.zeros((len(test_ids), len(speaker_ids)))
+    for i, sid in enumerate(test_ids):
+        labels[i, speaker_ids.index(sid)] = 1
+    return labels
+
+
+def evaluate(model, cubes, test_ids, speaker_models, k=1, plot_path='eer_auc.png'):
+    """The loop of evaluation.py:90-146 on in-memory data (the reference's files --
+    checkpoint, id lists, WAVs -- do not ship): score every cube against every
+    enrolled speaker, build one-hot labels, report EER / AUC / top-1 accuracy."""
+    ev = Evaluation(model, speaker_models)
+    speaker_ids = list(ev.speaker_models.keys())
+    scores = ev.score_all(cubes).to("cpu").numpy().astype(np.float64)
+    labels = labels_from_ids(test_ids, speaker_ids)
+    correct = int(sum(speaker_ids[int(np.argmax(scores[i]))] == test_ids[i] for i in range(len(test_ids))))
+    eer, auc = get_and_plot_k_eer_auc(labels.flatten(), scores.flatten(), k=k, plot_path=plot_path)
+    accuracy = correct * 100 / max(1, len(test_ids))
+    print(f'Accuracy: {accuracy}%')
+    return {"eer": eer, "auc": auc, "accuracy": accuracy, "scores": scores, "labels": labels}

@@ -1,0 +1,103 @@
+"""End-to-end hot path on one GPU: 16 kHz PCM -> energy VAD -> log-mel front end
+(-> CMVN) -> 20 x 80 x 40 feature cube -> C3D2 embedding -> cosine scores.
+
+This is the batched, device-resident form of what the reference does one
+utterance at a time on the host:
+  vad.py:135-168  ->  load_data.py:50-87  ->  utils.py:351-397  ->
+  model.py:141-170  ->  evaluation.py:67-84.
+Every stage except the C3D2 forward (PyTorch-ROCm by the north-star's decree)
+is a libsvk.so kernel.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from . import constants as c
+from .engine import get_engine, spec_from_seconds
+
+
+class VerificationPipeline:
+    def __init__(self, model, use_vad=True, vad_threshold=c.VAD_ENERGY_THRESHOLD, normalize=c.NORMALIZE,
+                 fused_model=True, crop_seed=12345, micro_batch=1024, channels_last=False):
+        self.eng = get_engine()
+        self.model = model.to(self.eng.device).eval()
+        self.embedder = self.model.fused_inference(channels_last=channels_last) if fused_model else None
+        self.use_vad, self.vad_threshold, self.normalize = use_vad, int(vad_threshold), bool(normalize)
+        self.micro_batch = int(micro_batch)
+        # model front end: lmfe(signal, 16000, 0.025, 0.01, 40, 1024)  (load_data.py:64-70, Q14)
+        self.spec = spec_from_seconds(c.SAMPLE_RATE, c.FRAME_LEN, c.FRAME_STEP, c.NUM_FFT, c.NUM_COEF, c.NUM_COEF,
+                                      _lib.OUT_LMFE)
+        # the reference seeds the global NumPy RNG at utils import (utils.py:15) and draws
+        # the crop starts from it (utils.py:372); a private RandomState keeps that sequence
+        self.rng = np.random.RandomState(crop_seed)
+        self.last_stats = {}
+
+    # ---- stages ----------------------------------------------------------------------
+    def voiced(self, pcm):
+        """[n, L] int16 -> (packed voiced samples [n, L] int16, voiced_len [n] i32)."""
+        if not self.use_vad:
+            n, L = pcm.shape
+            return pcm, None
+        res = self.eng.vad_energy(pcm, self.vad_threshold, fs=c.SAMPLE_RATE, frame_ms=c.VAD_FRAME_MS,
+                                  padding_ms=c.VAD_PADDING_MS, compact=True)
+        return res["voiced"], res["voiced_len"]
+
+    def features(self, pcm, lengths=None):
+        feat, n_frames, _ = self.eng.features(pcm, self.spec, lengths=lengths)
+        if self.normalize:                                 # utils.CMVN with c.NORMALIZE (utils.py:394-395)
+            self.eng.cmvn_(feat, n_frames, variance=True)
+        return feat, n_frames
+
+    def draw_crops(self, n_frames_host):
+        """idx = randint(T - 80, size=20) per utterance, in order (utils.py:372, Q15)."""
+        out = np.empty((len(n_frames_host), c.CUBE_CROPS), dtype=np.int32)
+        for i, T in enumerate(n_frames_host):
+            if T - c.CUBE_FRAMES <= 0:
+                raise ValueError(f"utterance {i} has {T} feature frames; FeatureCube needs more than "
+                                 f"{c.CUBE_FRAMES} (numpy randint: low >= high)")
+            out[i] = self.rng.randint(int(T) - c.CUBE_FRAMES, size=c.CUBE_CROPS)
+        return out
+
+    def cubes(self, feat, crop_idx):
+        return self.eng.cube_gather(feat, crop_idx, c.CUBE_FRAMES)
+
+    def embed_cubes(self, cubes):
+        with torch.no_grad():
+            if self.embedder is not None:
+                return self.embedder(cubes)
+            return self.model(cubes, development=False)
+
+    # ---- whole path ---------------------------------------------------------------------
+    def embed(self, pcm, crop_idx=None, return_intermediates=False):
+        """[n, L] int16 PCM (NumPy or CUDA tensor) -> [n, 128] float32 embeddings (device).
+        `crop_idx` [n, 20] overrides the RNG draw (parity tests feed both sides the same crops)."""
+        pcm = self.eng.to_device(pcm)
+        outs, inter = [], []
+        for lo in range(0, pcm.shape[0], self.micro_batch):
+            chunk = pcm[lo:lo + self.micro_batch]
+            voiced, vlen = self.voiced(chunk)
+            feat, n_frames = self.features(voiced, vlen)
+            if crop_idx is None:
+                idx = self.draw_crops(n_frames.to("cpu").numpy())      # tiny D2H: T per utterance
+            else:
+                idx = np.asarray(crop_idx[lo:lo + self.micro_batch], dtype=np.int32)
+            cube = self.cubes(feat, idx)
+            outs.append(self.embed_cubes(cube))
+            if return_intermediates:
+                inter.append({"voiced": voiced, "voiced_len": vlen, "feat": feat, "n_frames": n_frames,
+                              "crop_idx": idx, "cube": cube})
+        emb = torch.cat(outs, dim=0) if len(outs) != 1 else outs[0]
+        return (emb, inter) if return_intermediates else emb
+
+    def score(self, test_emb, enroll_emb):
+        return self.eng.cosine_scores(test_emb, enroll_emb)
+
+
+def enroll_last_utterance(embeddings, speaker_ids):
+    """Speaker model = embedding of that speaker's LAST listed utterance: the reference
+    overwrites `{id}.pt` on every utterance, no averaging (Q17, model.py:374-388).
+    Returns (sorted unique ids, row index of each speaker's model)."""
+    speaker_ids = np.asarray(speaker_ids)
+    uniq = np.unique(speaker_ids)
+    last = np.array([np.nonzero(speaker_ids == s)[0][-1] for s in uniq], dtype=np.int64)
+    return uniq, last

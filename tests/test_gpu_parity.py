@@ -1,0 +1,427 @@
+"""GPU parity: every libsvk.so kernel, called through the C-ABI (ctypes) and through the
+drop-in Python surface, against the CPU oracle and the committed golden vectors.
+
+Tolerances (north-star): MFCC / log-mel allclose(rtol=1e-4, atol=1e-4) against the float64
+reference (the kernels compute in f32; element-wise RELATIVE error alone is not meaningful
+for cepstra that cross zero -- SURVEY.md section 7); cosine |d| <= 1e-5; VAD masks bit-exact;
+EER equal.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import model_ref, scoring_ref, speechpy_ref as ref, vad_ref   # noqa: E402
+from speaker_verification_amd import constants as c, synth                  # noqa: E402
+
+FEAT_TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from speaker_verification_amd.engine import get_engine
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return get_engine(0)
+
+
+@pytest.fixture(scope="module")
+def sp():
+    from speaker_verification_amd import speechpy
+    return speechpy
+
+
+def test_native_library_is_loaded(eng):
+    """The HIP extension must be the thing that ran (the driver checks /proc/self/maps too)."""
+    with open("/proc/self/maps") as fh:
+        assert "libsvk.so" in fh.read()
+    assert eng.num_cu >= 64 and eng.wave == 64
+
+
+# ---- fused front end against the golden vectors (reference outputs) ---------------------------
+def test_mfcc_config_A_golden(sp, golden):
+    g = golden["speechpy"]
+    one = synth.noise_clip(*g["one_seed"])
+    np.testing.assert_allclose(sp.feature.mfcc(one, 16000), g["mfcc_A"], **FEAT_TOL)
+    np.testing.assert_allclose(sp.feature.mfcc(one, 16000, dc_elimination=False), g["mfcc_A_nodc"], **FEAT_TOL)
+    np.testing.assert_allclose(sp.feature.mfcc(one, 16000, num_cepstral=40), g["mfcc_A_40"], **FEAT_TOL)
+    np.testing.assert_allclose(sp.feature.mfcc(one, 16000, num_filters=26, low_frequency=100.0,
+                                               high_frequency=7000.0), g["mfcc_A_lowhigh"], **FEAT_TOL)
+    f, e = sp.feature.mfe(one, 16000)
+    np.testing.assert_allclose(f, g["mfe_A_feat"], rtol=1e-4)
+    np.testing.assert_allclose(e, g["mfe_A_energy"], rtol=1e-4)
+    np.testing.assert_allclose(sp.feature.lmfe(one, 16000), g["lmfe_A"], **FEAT_TOL)
+    spk = synth.speaker_clip(*g["spk_seed"])
+    np.testing.assert_allclose(sp.feature.mfcc(spk, 16000), g["mfcc_A_spk"], **FEAT_TOL)
+
+
+def test_lmfe_config_B_golden(sp, golden):
+    g = golden["speechpy"]
+    one_f32 = (synth.noise_clip(*g["one_seed"]) / 32768.0).astype(np.float32)
+    np.testing.assert_allclose(sp.feature.lmfe(one_f32, 16000, 0.025, 0.01, 40, 1024), g["lmfe_B_f32"], **FEAT_TOL)
+    np.testing.assert_allclose(sp.feature.mfcc(one_f32, 16000, 0.025, 0.01, 13, 40, 1024), g["mfcc_B_f32"],
+                               **FEAT_TOL)
+    spk = synth.speaker_clip(*g["spk_seed"])
+    np.testing.assert_allclose(sp.feature.lmfe(spk, 16000, 0.025, 0.01, 40, 1024), g["lmfe_B_spk"], **FEAT_TOL)
+
+
+def test_known_answers_3s(sp, golden):
+    g = golden["speechpy"]
+    sig = (np.random.default_rng(0).standard_normal(48000) * 3000).astype(np.int16)
+    m = sp.feature.mfcc(sig, 16000)
+    assert m.shape == (298, 13) and m.dtype == np.float64
+    np.testing.assert_allclose(m, g["kat_mfcc_A_3s"], **FEAT_TOL)
+    assert m.sum() == pytest.approx(4545.562374768052, abs=0.05)
+    b = sp.feature.lmfe(sig.astype(np.float32) / 32768, 16000, 0.025, 0.01, 40, 1024)
+    assert b.shape == (297, 40)
+    np.testing.assert_allclose(b, g["kat_lmfe_B_3s"], **FEAT_TOL)
+    # fused pre-emphasis + separate CMVN == the reference chain preemphasis -> mfcc -> cmvn(var)
+    pre = sp.feature.mfcc(sp.processing.preemphasis(sig, cof=0.98), 16000)
+    np.testing.assert_allclose(sp.processing.cmvn(pre, True), g["kat_mfcc_A_3s_pre_cmvn"], rtol=1e-3, atol=1e-3)
+
+
+def test_zero_and_short_clips(sp, golden):
+    g = golden["speechpy"]
+    z = sp.feature.mfcc(np.zeros(1600, dtype=np.int16), 16000)
+    np.testing.assert_allclose(z, g["mfcc_A_zero"], rtol=0, atol=1e-5)          # Q7: log(eps) in c0, 0 elsewhere
+    assert z[0, 0] == pytest.approx(-36.04365338911715, abs=1e-5)
+    assert sp.feature.mfcc(np.zeros(320, dtype=np.int16), 16000).shape == (0, 13)   # feature.py:144-145
+    assert sp.feature.mfcc(np.zeros(10, dtype=np.int16), 16000).shape == (0, 13)
+    f, e = sp.feature.mfe(np.zeros(100, dtype=np.int16), 16000)
+    assert f.shape == (0, 40) and e.shape == (0,)
+
+
+# ---- batched front end through the engine (C-ABI) against the oracle ------------------------------
+@pytest.mark.parametrize("kind,nfft,fl,ncep", [("mfcc", 512, 0.020, 13), ("lmfe", 1024, 0.025, 40),
+                                               ("mfe", 512, 0.020, 13), ("mfcc", 1024, 0.025, 40)])
+def test_batched_ragged(eng, kind, nfft, fl, ncep):
+    from speaker_verification_amd.speechpy import feature
+    lens = [48000, 16000, 9999, 2723, 400, 320, 47999, 33333]
+    L = max(lens)
+    pcm = np.zeros((len(lens), L), dtype=np.int16)
+    for i, n in enumerate(lens):
+        pcm[i, :n] = synth.speaker_clip(i, 0, n) if i % 2 else synth.noise_clip(100 + i, n)
+    feat, n_frames, energy = feature.features_batch(pcm, 16000, kind=kind, frame_length=fl, num_cepstral=ncep,
+                                                    fft_length=nfft, lengths=np.array(lens, dtype=np.int32),
+                                                    want_energy=True)
+    feat, n_frames, energy = feat.cpu().numpy(), n_frames.cpu().numpy(), energy.cpu().numpy()
+    fn = {"mfcc": ref.mfcc, "lmfe": ref.lmfe, "mfe": lambda *a, **k: ref.mfe(*a, **k)[0]}[kind]
+    for i, n in enumerate(lens):
+        kw = dict(frame_length=fl, frame_stride=0.01, num_filters=40, fft_length=nfft)
+        if kind == "mfcc":
+            kw["num_cepstral"] = ncep
+        want = fn(pcm[i, :n], 16000, **kw)
+        assert n_frames[i] == want.shape[0], (i, n)
+        if kind == "mfe":
+            np.testing.assert_allclose(feat[i, :want.shape[0]], want, rtol=1e-4)
+        else:
+            np.testing.assert_allclose(feat[i, :want.shape[0]], want, **FEAT_TOL)
+        assert not feat[i, want.shape[0]:].any()                                   # padded rows are zero
+        np.testing.assert_allclose(energy[i, :want.shape[0]], ref.mfe(pcm[i, :n], 16000, **{
+            k: v for k, v in kw.items() if k != "num_cepstral"})[1], rtol=1e-4)
+
+
+def test_fused_preemphasis_matches_reference_chain(eng):
+    from speaker_verification_amd.speechpy import feature
+    pcm = np.stack([synth.noise_clip(5, 16000), synth.speaker_clip(2, 0, 16000)])
+    feat, _, _ = feature.features_batch(pcm, 16000, kind="mfcc", preemphasis_cof=0.98)
+    for i in range(2):
+        want = ref.mfcc(ref.preemphasis(pcm[i], cof=0.98), 16000)
+        np.testing.assert_allclose(feat[i].cpu().numpy(), want, **FEAT_TOL)
+    # float32 PCM in [-1, 1)
+    f32 = (pcm / 32768.0).astype(np.float32)
+    feat, _, _ = feature.features_batch(f32, 16000, kind="lmfe", frame_length=0.025, fft_length=1024,
+                                        preemphasis_cof=0.97)
+    for i in range(2):
+        want = ref.lmfe(ref.preemphasis(f32[i], cof=0.97), 16000, 0.025, 0.01, 40, 1024)
+        np.testing.assert_allclose(feat[i].cpu().numpy(), want, **FEAT_TOL)
+
+
+def test_full_size_batch_properties(eng):
+    """BASELINE config 2 shape (1 024 x 3 s): determinism, row independence, no NaN."""
+    from speaker_verification_amd.speechpy import feature
+    base = np.stack([synth.noise_clip(s) for s in range(8)])
+    pcm = np.tile(base, (128, 1))
+    a, nf, _ = feature.features_batch(pcm, 16000, kind="mfcc")
+    b, _, _ = feature.features_batch(pcm, 16000, kind="mfcc")
+    assert a.shape == (1024, 298, 13) and bool((nf == 298).all())
+    assert torch.equal(a, b)                                            # bitwise repeatable
+    assert torch.equal(a[:8], a[512:520])                               # same clip -> same bits anywhere in the batch
+    assert bool(torch.isfinite(a).all())
+    np.testing.assert_allclose(a[3].cpu().numpy(), ref.mfcc(base[3], 16000), **FEAT_TOL)
+
+
+# ---- stage-level drop-ins ------------------------------------------------------------------------
+def test_processing_stages(sp, golden):
+    g = golden["speechpy"]
+    short = synth.noise_clip(*g["short_seed"])
+    out = sp.processing.preemphasis(short, shift=1, cof=0.98)
+    assert out.dtype == np.float64 and out.shape == short.shape
+    np.testing.assert_allclose(out, g["pre_short_i16"], rtol=1e-6, atol=1e-3)
+    f32 = sp.processing.preemphasis((short / 32768.0).astype(np.float32), shift=1, cof=0.98)
+    assert f32.dtype == np.float32
+    np.testing.assert_allclose(f32, g["pre_short_f32"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(sp.processing.preemphasis(short, shift=3, cof=0.5), g["pre_short_shift3"],
+                               rtol=1e-6, atol=1e-3)
+    x = short.astype(float)
+    ones = lambda n: np.ones((n,))                                           # noqa: E731
+    np.testing.assert_array_equal(sp.processing.stack_frames(x, 16000, 0.020, 0.010, ones, False), g["frames_nopad"])
+    np.testing.assert_array_equal(sp.processing.stack_frames(x, 16000, 0.020, 0.020, ones, True), g["frames_pad"])
+    np.testing.assert_allclose(sp.processing.stack_frames(x, 16000, 0.025, 0.010, np.hamming, True),
+                               g["frames_hamming"], rtol=1e-6, atol=1e-3)
+    fr = g["frames_nopad"]
+    scale = float(np.abs(g["fftmag_512"]).max())
+    np.testing.assert_allclose(sp.processing.fft_spectrum(fr, 512), g["fftmag_512"], rtol=1e-4, atol=2e-6 * scale)
+    pmax = float(g["pow_512"].max())
+    np.testing.assert_allclose(sp.processing.power_spectrum(fr, 512), g["pow_512"], rtol=1e-4, atol=2e-6 * pmax)
+    np.testing.assert_allclose(sp.processing.power_spectrum(g["frames_hamming"], 1024), g["pow_1024"], rtol=1e-4,
+                               atol=2e-6 * float(g["pow_1024"].max()))
+    np.testing.assert_allclose(sp.processing.power_spectrum(fr, 256), g["pow_256_crop"], rtol=1e-4,
+                               atol=2e-6 * float(g["pow_256_crop"].max()))     # direct-DFT path, cropped frames
+    np.testing.assert_allclose(sp.processing.log_power_spectrum(fr, 512, True), g["logpow_512_norm"], rtol=0, atol=2e-2)
+
+
+def test_reference_own_tests(sp):
+    """What /root/reference/speech_feature_extraction/tests/test_speechpy.py asserts."""
+    rng = np.random.default_rng(1)
+    signal = rng.normal(0, 0.1, 200000)
+    pre = sp.processing.preemphasis(signal, cof=0.98)
+    assert pre.ndim == 1 and pre.shape == signal.shape
+    frames = sp.processing.stack_frames(signal, sampling_frequency=16000, frame_length=0.02, frame_stride=0.02,
+                                        filter=lambda x: np.ones((x,)), zero_padding=True)
+    assert frames.shape[0] == int(np.ceil((signal.shape[0] - 320) / 320))
+    fv = rng.random((50, 100))
+    norm = sp.processing.cmvn(fv, variance_normalization=True)
+    assert norm.shape == fv.shape
+    assert np.allclose(np.mean(norm, axis=0), 0, atol=1e-6) and np.allclose(np.std(norm, axis=0), 1, atol=1e-5)
+    assert sp.feature.mfcc(signal, sampling_frequency=16000, frame_length=0.020, num_cepstral=13, frame_stride=0.01,
+                           num_filters=40, fft_length=512, low_frequency=0, high_frequency=None).shape[1] == 13
+    for mod, names in ((sp.processing, "preemphasis stack_frames fft_spectrum power_spectrum log_power_spectrum "
+                                       "derivative_extraction cmvn cmvnw"),
+                       (sp.feature, "filterbanks mfcc mfe lmfe extract_derivative_feature"),
+                       (sp.functions, "frequency_to_mel mel_to_frequency triangle zero_handling")):
+        for name in names.split():
+            assert hasattr(mod, name)
+
+
+def test_postprocessing(sp, golden):
+    g = golden["speechpy"]
+    base = g["mfcc_A"]
+    np.testing.assert_allclose(sp.processing.cmvn(base, False), g["cmvn_mean"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(sp.processing.cmvn(base, True), g["cmvn_var"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(sp.processing.cmvn(g["cmvn_wide_in"], True), g["cmvn_wide_var"], rtol=1e-4, atol=1e-5)
+    out = sp.processing.cmvnw(base, win_size=301, variance_normalization=True)
+    assert out.dtype == np.float32
+    np.testing.assert_allclose(out, g["cmvnw_var"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(sp.processing.cmvnw(base, 31, True), g["cmvnw_var_w31"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(sp.processing.cmvnw(base, 301, False), g["cmvnw_mean"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(sp.processing.derivative_extraction(base, 2), g["deriv_w2"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(sp.feature.extract_derivative_feature(g["lmfe_A"]), g["deriv_cube"], rtol=1e-5,
+                               atol=1e-5)
+    with pytest.raises(AssertionError):
+        sp.processing.cmvnw(base, win_size=300)
+
+
+def test_cmvn_batched_ragged(eng):
+    rng = np.random.default_rng(3)
+    feat = rng.standard_normal((5, 60, 13)).astype(np.float32) * 3 + 1
+    nf = np.array([60, 1, 17, 0, 59], dtype=np.int32)
+    dev = eng.to_device(feat).clone()
+    eng.cmvn_(dev, nf, variance=True)
+    got = dev.cpu().numpy()
+    for i, n in enumerate(nf):
+        if n:
+            np.testing.assert_allclose(got[i, :n], ref.cmvn(feat[i, :n].astype(np.float64), True), rtol=1e-4, atol=1e-5)
+        np.testing.assert_array_equal(got[i, n:], feat[i, n:])               # rows past n_frames untouched
+
+
+# ---- VAD: bit-exact ---------------------------------------------------------------------------------
+def test_vad_bit_exact(eng, golden):
+    g = golden["vad"]
+    thr = int(g["threshold"][0])
+    clips = [synth.speaker_clip(s, u) for s, u in ((0, 0), (1, 4), (7, 2), (3, 3), (9, 1))]
+    clips += [synth.noise_clip(3, 48000, 3000.0), synth.noise_clip(4, 48000, 100.0)]
+    pat = np.zeros(48000, dtype=np.int16)
+    pat[:g["pattern_pcm"].size] = g["pattern_pcm"][:48000]
+    clips.append(pat)
+    pcm = np.stack(clips)
+    res = eng.vad_energy(pcm, thr, want_segments=True)
+    keep, seg = res["keep"].cpu().numpy(), res["seg"].cpu().numpy()
+    voiced, vlen = res["voiced"].cpu().numpy(), res["voiced_len"].cpu().numpy()
+    assert (res["n_vad_frames"].cpu().numpy() == 99).all()                      # Q12
+    for i in range(pcm.shape[0]):
+        k, s, v = vad_ref.vad_energy(pcm[i], 16000, 30, 300, thr)
+        np.testing.assert_array_equal(keep[i].astype(bool), k)                     # Q13
+        np.testing.assert_array_equal(seg[i], s)
+        assert vlen[i] == v.size
+        np.testing.assert_array_equal(voiced[i, :v.size], v)
+    np.testing.assert_array_equal(keep[0].astype(bool), g["spk_0_0_keep"])         # the reference's own collector
+    np.testing.assert_array_equal(keep[1].astype(bool), g["spk_1_4_keep"])
+    np.testing.assert_array_equal(seg[2], g["spk_7_2_seg"])
+
+
+def test_vad_edge_lengths_and_long_clip(eng, golden):
+    g = golden["vad"]
+    thr = int(g["threshold"][0])
+    long = synth.speaker_clip(5, 0, 112000)
+    res = eng.vad_energy(long[None], thr, want_segments=True)
+    np.testing.assert_array_equal(res["keep"][0].cpu().numpy().astype(bool), g["spk_5_0_long_keep"])
+    np.testing.assert_array_equal(res["seg"][0].cpu().numpy(), g["spk_5_0_long_seg"])
+    for n, name in ((47999, "len_47999"), (48001, "len_48001"), (480, "len_480"), (481, "len_481"), (100, "len_100")):
+        clip = synth.speaker_clip(2, 1 if n == 47999 else 2, n) if n > 1000 else synth.noise_clip(6, n)
+        res = eng.vad_energy(clip[None], thr)
+        nf = int(res["n_vad_frames"][0].item())
+        assert nf == int(g[name + "_nframes"][0])
+        np.testing.assert_array_equal(res["keep"][0].cpu().numpy()[:nf].astype(bool), g[name + "_keep"])
+    # ragged batch through `lengths`
+    pcm = np.zeros((2, 48000), dtype=np.int16)
+    pcm[0] = synth.speaker_clip(0, 0)
+    pcm[1, :30000] = synth.speaker_clip(1, 4)[:30000]
+    res = eng.vad_energy(pcm, thr, lengths=np.array([48000, 30000], dtype=np.int32))
+    k1, _, v1 = vad_ref.vad_energy(pcm[1, :30000], 16000, 30, 300, thr)
+    assert int(res["n_vad_frames"][1].item()) == k1.size
+    np.testing.assert_array_equal(res["keep"][1].cpu().numpy()[:k1.size].astype(bool), k1)
+    assert int(res["voiced_len"][1].item()) == v1.size
+
+
+def test_vad_dropin_collector(golden):
+    from speaker_verification_amd import vad
+    pcm = synth.speaker_clip(1, 4)
+    frames = list(vad.frame_generator(30, pcm.tobytes(), 16000))
+    assert len(frames) == 99 and len(frames[0].bytes) == 960
+    segs = list(vad.vad_collector(16000, 30, 300, vad.EnergyVad(250000), frames))
+    np.testing.assert_array_equal([len(s) // 2 for s in segs], golden["vad"]["spk_1_4_seglens"])
+    _, _, voiced = vad_ref.vad_energy(pcm, 16000, 30, 300, 250000)
+    assert b"".join(segs) == voiced.tobytes()
+    assert vad.EnergyVad(250000).is_speech(frames[0].bytes, 16000) == vad_ref.energy_is_speech(
+        np.frombuffer(frames[0].bytes, dtype=np.int16), 250000)
+
+
+# ---- cube, model, scoring ----------------------------------------------------------------------------
+def test_cube_gather(eng, golden):
+    g = golden["c3d2_embed"]
+    feat = np.random.default_rng(int(g["cube_feat_seed"][0])).standard_normal((297, 40))
+    cube = eng.cube_gather(feat[None].astype(np.float32), g["cube_idx"][None].astype(np.int32)).cpu().numpy()
+    assert cube.shape == (1, 1, 20, 80, 40)
+    np.testing.assert_array_equal(cube[0], g["cube_out"])                     # float32 copy: bit-exact
+    # batched, T not a multiple of anything
+    feats = np.random.default_rng(1).standard_normal((3, 123, 40)).astype(np.float32)
+    idx = np.random.default_rng(2).integers(0, 123 - 80, size=(3, 20)).astype(np.int32)
+    cube = eng.cube_gather(feats, idx).cpu().numpy()
+    for u in range(3):
+        np.testing.assert_array_equal(cube[u], model_ref.feature_cube(feats[u], idx[u]))
+
+
+def test_c3d2_embedding_on_gpu(eng, golden):
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    g = golden["c3d2_embed"]
+    model = seeded_model(int(g["init_seed"][0]), int(g["n_labels"][0]), 1)
+    model.load_state_dict(perturb_inference_state(model.state_dict(), int(g["perturb_seed"][0])))
+    cubes = (np.random.default_rng(int(g["cube_seed"][0])).standard_normal((3, 1, 20, 80, 40)) * 2.0 - 6.0
+             ).astype(np.float32)
+    model = model.to(eng.device).eval()
+    x = torch.from_numpy(cubes).to(eng.device)
+    with torch.no_grad():
+        plain = model(x, development=False).cpu().numpy()
+    fused = model.fused_inference()(x).cpu().numpy()
+    scale = np.abs(g["embed"]).max()
+    np.testing.assert_allclose(plain, g["embed"], rtol=1e-3, atol=1e-4 * scale)
+    np.testing.assert_allclose(fused, g["embed"], rtol=1e-3, atol=1e-4 * scale)
+    np.testing.assert_allclose(model.create_Speaker_Model(x[1:2]).detach().cpu().numpy(), g["speaker_model"],
+                               rtol=1e-3, atol=1e-4 * scale)
+
+
+def test_cosine_scores(eng, golden):
+    g = golden["scoring"]
+    got = eng.cosine_scores(g["test"], g["enroll"]).cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == (42, 6)
+    np.testing.assert_allclose(got, g["sims"], rtol=0, atol=1e-5)             # the reference's own scores
+    rng = np.random.default_rng(8)
+    for nt, ns, d in ((4874, 40, 128), (33, 17, 128), (5, 3, 100), (16, 16, 64), (1, 1, 7)):
+        t = rng.standard_normal((nt, d)).astype(np.float32)
+        e = rng.standard_normal((ns, d)).astype(np.float32)
+        t[0] = 0                                                              # zero row: sklearn gives 0, not NaN
+        got = eng.cosine_scores(t, e).cpu().numpy()
+        np.testing.assert_allclose(got, scoring_ref.cosine_matrix(t, e), rtol=0, atol=1e-5)
+        assert not got[0].any()
+
+
+def test_evaluation_dropin(eng, golden):
+    from speaker_verification_amd import evaluation
+    g = golden["scoring"]
+
+    class Fixed(torch.nn.Module):
+        def forward(self, utterance, development=False):
+            return utterance
+
+    ev = evaluation.Evaluation(Fixed(), {f"id{j:05d}": g["enroll"][j:j + 1] for j in range(6)})
+    for i in (0, 5, 41):
+        sims, assigned = ev.compute_Similarity(torch.from_numpy(g["test"][i:i + 1]))
+        assert sims.dtype == np.float64
+        np.testing.assert_allclose(sims, g["sims"][i], rtol=0, atol=1e-5)
+        np.testing.assert_array_equal(assigned, g["assigned"][i])
+    scores = evaluation.score_matrix(g["test"], g["enroll"]).cpu().numpy().astype(np.float64)
+    eer, auc, _, _ = evaluation.get_eer_auc(g["labels"].flatten(), scores.flatten())
+    assert eer == pytest.approx(float(g["eer"][0]), abs=1e-9)                 # EER equal to the reference's
+    assert auc == pytest.approx(float(g["auc"][0]), abs=1e-9)
+    eer2, auc2, _, _ = evaluation.get_eer_auc(g["big_labels"], g["big_scores"])
+    assert eer2 == float(g["big_eer"][0]) and auc2 == float(g["big_auc"][0])
+
+
+def test_siamese(eng, golden):
+    from speaker_verification_amd.siamese import Siamese
+    g = golden["scoring"]
+    sia = Siamese(LAMBDA=0.001, M=2.0)
+    o1, o2 = torch.from_numpy(g["l2_o1"]).to(eng.device), torch.from_numpy(g["l2_o2"]).to(eng.device)
+    np.testing.assert_allclose(sia.l2_dist(o1, o2).cpu().numpy(), g["l2_dist"], rtol=1e-6)
+    lin = torch.nn.Linear(4, 3).to(eng.device)
+    y = torch.tensor([1, 0, 1, 0, 1, 0, 1, 0, 1], dtype=torch.float32, device=eng.device)
+    loss = sia(lin, y, o1.requires_grad_(), o2)
+    norms = [float(torch.norm(p)) for p in lin.parameters()]
+    want = scoring_ref.contrastive_loss(y.cpu().numpy(), g["l2_o1"], g["l2_o2"], norms, 0.001, 2.0)
+    assert float(loss) == pytest.approx(want, rel=1e-5)
+    loss.backward()
+    assert o1.grad is not None and torch.isfinite(o1.grad).all()
+
+
+# ---- whole path -------------------------------------------------------------------------------------------
+def test_pipeline_end_to_end_and_eer(eng):
+    from speaker_verification_amd import evaluation
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    from speaker_verification_amd.pipeline import VerificationPipeline, enroll_last_utterance
+    n_spk, per = 6, 4
+    pcm, spk = synth.corpus(n_spk, per)
+    model = seeded_model(11, n_labels=32)
+    model.load_state_dict(perturb_inference_state(model.state_dict(), 12))
+    pipe = VerificationPipeline(model, use_vad=True, micro_batch=16)
+    emb, inter = pipe.embed(pcm, return_intermediates=True)
+    emb = emb.cpu().numpy()
+    crops = np.concatenate([d["crop_idx"] for d in inter])
+    # crop draws follow the reference's RNG protocol (utils.py:15,372)
+    rs = np.random.RandomState(12345)
+    nfr = np.concatenate([d["n_frames"].cpu().numpy() for d in inter])
+    want_crops = np.stack([rs.randint(int(T) - 80, size=20) for T in nfr])
+    np.testing.assert_array_equal(crops, want_crops)
+
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref_emb = []
+    for i in range(pcm.shape[0]):
+        _, _, voiced = vad_ref.vad_energy(pcm[i], 16000, c.VAD_FRAME_MS, c.VAD_PADDING_MS, c.VAD_ENERGY_THRESHOLD)
+        feat = ref.lmfe(voiced, 16000, c.FRAME_LEN, c.FRAME_STEP, c.NUM_COEF, c.NUM_FFT)
+        assert feat.shape[0] == nfr[i]
+        ref_emb.append(model_ref.c3d2_embed(state, model_ref.feature_cube(feat, crops[i])[None]).numpy()[0])
+    ref_emb = np.stack(ref_emb)
+    scale = np.abs(ref_emb).max()
+    np.testing.assert_allclose(emb, ref_emb, rtol=2e-3, atol=2e-4 * scale)
+
+    ids, last = enroll_last_utterance(emb, spk)                                # Q17
+    scores = pipe.score(emb, emb[last]).cpu().numpy()
+    ref_scores = scoring_ref.cosine_matrix(ref_emb, ref_emb[last])
+    np.testing.assert_allclose(scores, scoring_ref.cosine_matrix(emb, emb[last]), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(scores, ref_scores, rtol=0, atol=2e-3)
+    labels = (spk[:, None] == ids[None, :]).astype(np.float64)
+    eer_gpu, auc_gpu, _, _ = evaluation.get_eer_auc(labels.flatten(), scores.astype(np.float64).flatten())
+    eer_ref, auc_ref, _, _ = scoring_ref.get_eer_auc(labels.flatten(), ref_scores.astype(np.float64).flatten())
+    assert eer_gpu == pytest.approx(eer_ref, abs=1e-4)                          # EER parity
+    assert auc_gpu == pytest.approx(auc_ref, abs=1e-4)

@@ -1,0 +1,84 @@
+"""Host-side logic of the drop-in layer that needs no GPU: table builders, frame
+bookkeeping, sharding arithmetic, the synthetic corpus, model plumbing."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import speechpy_ref as ref
+from speaker_verification_amd import distributed as svdist, synth
+from speaker_verification_amd._lib import OUT_LMFE, OUT_MFCC
+from speaker_verification_amd.engine import spec_from_seconds
+from speaker_verification_amd.speechpy import feature, functions
+
+
+def test_filterbank_tables_match_reference(golden):
+    g = golden["speechpy"]
+    np.testing.assert_array_equal(feature.filterbanks(40, 257, 16000, 0, 8000), g["fb_A"])
+    np.testing.assert_array_equal(feature.filterbanks(40, 513, 16000, 0, 8000), g["fb_B"])
+    np.testing.assert_array_equal(feature.filterbanks(26, 257, 16000, 100.0, 7000.0), g["fb_C"])
+    np.testing.assert_array_equal(feature.filterbanks(20, 129, 8000, None, None), g["fb_D"])
+    with pytest.raises(AssertionError):
+        feature.filterbanks(40, 257, 16000, 0, 9000)
+    np.testing.assert_array_equal(functions.frequency_to_mel(g["fn_hz"]), g["fn_mel"])
+    np.testing.assert_array_equal(functions.mel_to_frequency(g["fn_mel"]), g["fn_hz_back"])
+    np.testing.assert_array_equal(functions.triangle(g["fn_tri_x"], 5, 9, 15), g["fn_tri"])
+    np.testing.assert_array_equal(functions.zero_handling(g["fn_zh_in"]), g["fn_zh"])
+
+
+def test_frontend_spec_frame_counts():
+    a = spec_from_seconds(16000, 0.020, 0.01, 512, 40, 13, OUT_MFCC)
+    b = spec_from_seconds(16000, 0.025, 0.01, 1024, 40, 40, OUT_LMFE)
+    assert (a.frame_len, a.frame_stride, a.num_frames(48000), a.num_cols) == (320, 160, 298, 13)
+    assert (b.frame_len, b.frame_stride, b.num_frames(48000), b.num_cols) == (400, 160, 297, 40)
+    for n in (0, 100, 319, 320, 479, 480, 481, 16000, 47999, 48001):
+        want = max(0, ref.frame_geometry(n, 16000, 0.020, 0.01, False)[2])
+        assert a.num_frames(n) == want, n
+    assert a.key() == spec_from_seconds(16000, 0.020, 0.01, 512, 40, 13, OUT_MFCC).key()
+    assert a.key() != b.key()
+
+
+def test_shard_bounds_cover_everything():
+    for n, w in ((148642, 8), (148642, 1), (4874, 4), (7, 8), (0, 2), (16, 2)):
+        spans = [svdist.shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(hi - lo for lo, hi in spans) <= svdist.shard_rows(n, w)
+    assert svdist.shard_rows(148642, 8) == 18581
+    assert svdist.shard_bounds(148642, 8, 7) == (130067, 148642)
+
+
+def test_synth_is_deterministic_and_vad_friendly():
+    from oracle import vad_ref
+    a, b = synth.speaker_clip(3, 2), synth.speaker_clip(3, 2)
+    assert a.dtype == np.int16 and a.shape == (48000,) and np.array_equal(a, b)
+    assert not np.array_equal(a, synth.speaker_clip(3, 3))
+    pcm, spk = synth.corpus(3, 2)
+    assert pcm.shape == (6, 48000) and list(spk) == [0, 0, 1, 1, 2, 2]
+    for s in range(12):
+        keep, _, voiced = vad_ref.vad_energy(synth.speaker_clip(s, 0))
+        assert keep.any(), s
+        assert ref.frame_geometry(voiced.size, 16000, 0.025, 0.01, False)[2] > 80, s   # enough frames for the cube
+
+
+def test_model_matches_reference_layout():
+    from speaker_verification_amd.model import C3D2, seeded_model
+    m = seeded_model(1, n_labels=10)
+    assert sum(p.numel() for p in C3D2(100, 1).parameters()) == 1164413
+    keys = list(m.state_dict().keys())
+    assert keys[0] == "conv1_1.weight" and "batch_norm4_2.running_var" in keys and "FC6.bias" in keys
+    x = torch.randn(2, 1, 20, 80, 40)
+    with torch.no_grad():
+        assert m(x, development=False).shape == (2, 128)
+        probs = m(x)
+        assert probs.shape == (2, 10) and torch.allclose(probs.sum(1), torch.ones(2), atol=1e-5)
+    # checkpoint format of the reference: {'state_dict': ...} with DataParallel prefixes (model.py:177-186)
+    ckpt = {"state_dict": {"module." + k: v for k, v in m.state_dict().items()}}
+    m2 = C3D2(10, 1).load_checkpoint(ckpt).cpu().eval()
+    with torch.no_grad():
+        assert torch.equal(m2(x, development=False), m(x, development=False))
+
+
+def test_enroll_last_utterance():
+    from speaker_verification_amd.pipeline import enroll_last_utterance
+    ids, last = enroll_last_utterance(None, np.array([5, 5, 2, 5, 2, 9]))
+    assert list(ids) == [2, 5, 9] and list(last) == [4, 3, 5]                    # Q17: last one wins
