@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X (contract: see the task prompt / DESIGN.md section 6).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One STEP = one pass of the whole path over this rank's shard of synthetic clips:
+    int16 PCM (resident in HBM) -> energy VAD -> fused pre-emphasis + log-mel(40) front end -> CMVN
+    -> 20x80x40 cube -> C3D2 embedding (PyTorch-ROCm, f32) -> all-gather of the [clips,128] shards
+    (RCCL) -> 4 874 x 40 cosine score matrix (MFMA).
+Per-rank work is fixed (weak scaling): 18 581 clips = ceil(148 642 / 8), the per-GPU shard of
+BASELINE.json's 148 642-clip corpus.  value = clips processed by all ranks / max-over-ranks time.
+
+The JSON line also carries
+  roofline      -- the fused front-end kernel (the dominant hand-written kernel): algorithmic
+                   HBM bytes / launch over its HIP-event duration inside the timed region;
+  frontend_A    -- BASELINE config 2 measured beside it: 1 024 clips, SpeechPy defaults
+                   (pre-emph + MFCC-13 + CMVN), utterances/s and roofline fraction;
+  cpu_baseline  -- the CPU oracle (NumPy/torch-CPU restatement of the reference, kind "port")
+                   timed on a bounded sample on rank 0, N = 1 only;
+  parity        -- GPU vs oracle on that sample + EER of the 4 874 x 40 score matrix.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+N_TEST, N_TEST_SPK = 4874, 40    # VoxCeleb1 verification split (README.md:4-7)
+UTTS_PER_SPK = 123
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=18581, help="clips per rank and step")
+    ap.add_argument("--micro-batch", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=48, help="clips of the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--no-vad", action="store_true")
+    ap.add_argument("--no-cmvn", action="store_true")
+    ap.add_argument("--no-preemph", action="store_true")
+    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--frontend-only", action="store_true", help="time BASELINE config 2 only (for rocprof)")
+    return ap.parse_args()
+
+
+def frontend_A_bench(eng, torch, reps=20, n_clips=1024):
+    """BASELINE config 2: batched MFCC pipeline, 1 024 x 3 s clips, SpeechPy defaults."""
+    from speaker_verification_amd import _lib, synth
+    from speaker_verification_amd.engine import spec_from_seconds
+    spec = spec_from_seconds(16000, 0.020, 0.01, 512, 40, 13, _lib.OUT_MFCC, preemph=True, preemph_cof=0.98)
+    base = np.stack([synth.noise_clip(s) for s in range(16)])
+    pcm = eng.to_device(np.tile(base, (n_clips // 16, 1)))
+    for _ in range(3):
+        feat, nf, _ = eng.features(pcm, spec)
+        eng.cmvn_(feat, nf, variance=True)
+    torch.cuda.synchronize()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+    for a, b, c in ev:
+        a.record()
+        feat, nf, _ = eng.features(pcm, spec)
+        b.record()
+        eng.cmvn_(feat, nf, variance=True)
+        c.record()
+    torch.cuda.synchronize()
+    t_fe = float(np.median([a.elapsed_time(b) for a, b, _ in ev])) * 1e-3
+    t_all = float(np.median([a.elapsed_time(c) for a, _, c in ev])) * 1e-3
+    bytes_per_utt = 48000 * 2 + 298 * 13 * 4          # 111 496 B
+    gbs = n_clips * bytes_per_utt / t_fe / 1e9
+    return {"workload": "configs[1]: 1024 x 3 s clips, pre-emph + MFCC-13 (nfft 512) + CMVN",
+            "utt_per_s": n_clips / t_all, "frontend_kernel_ms": t_fe * 1e3, "with_cmvn_ms": t_all * 1e3,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "frontend_kernel<int16,nfft512>",
+                         "bytes_per_utt": bytes_per_utt}}
+
+
+def cpu_baseline(pcm_host, crop_idx, state, preemph, cmvn, use_vad):
+    """The oracle (kind 'port') doing exactly the reference's per-utterance sequence on the host:
+    vad -> preemphasis -> lmfe -> cmvn -> cube -> C3D2 at batch 1 -> per-pair cosine."""
+    import torch
+    from oracle import model_ref, scoring_ref, speechpy_ref, vad_ref
+    from speaker_verification_amd import constants as c
+    t0 = time.perf_counter()
+    embs = []
+    for i in range(pcm_host.shape[0]):
+        clip = pcm_host[i]
+        if use_vad:
+            _, _, clip = vad_ref.vad_energy(clip, c.SAMPLE_RATE, c.VAD_FRAME_MS, c.VAD_PADDING_MS,
+                                            c.VAD_ENERGY_THRESHOLD)
+        sig = speechpy_ref.preemphasis(clip, cof=0.98) if preemph else clip
+        feat = speechpy_ref.lmfe(sig, c.SAMPLE_RATE, c.FRAME_LEN, c.FRAME_STEP, c.NUM_COEF, c.NUM_FFT)
+        if cmvn:
+            feat = speechpy_ref.cmvn(feat, variance_normalization=True)
+        cube = model_ref.feature_cube(feat, crop_idx[i])[None]
+        embs.append(model_ref.c3d2_embed(state, cube).numpy()[0])
+    embs = np.stack(embs)
+    enroll = embs[::max(1, len(embs) // 8)]
+    for i in range(len(embs)):
+        scoring_ref.compute_similarity(embs[i], enroll)
+    dt = time.perf_counter() - t0
+    return embs, dt, torch.get_num_threads()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from speaker_verification_amd import constants as c, distributed as svdist, evaluation, synth
+    from speaker_verification_amd.engine import get_engine
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    from speaker_verification_amd.pipeline import VerificationPipeline, enroll_last_utterance
+
+    eng = get_engine(local_rank)
+    dev = eng.device
+
+    if args.frontend_only:
+        res = frontend_A_bench(eng, torch, reps=max(args.steps, 5))
+        print(json.dumps(res))
+        return
+
+    n_local = args.clips
+    n_total = n_local * world
+    pcm, speakers_local = synth.corpus_device(n_local, dev, first_clip=rank * n_local, utts_per_speaker=UTTS_PER_SPK)
+    model = seeded_model(2024, n_labels=1211)
+    model.load_state_dict(perturb_inference_state(model.state_dict(), 99))
+    pipe = VerificationPipeline(model, use_vad=not args.no_vad, normalize=not args.no_cmvn,
+                                preemph_cof=None if args.no_preemph else 0.98, crop_rng="device",
+                                micro_batch=args.micro_batch, channels_last=args.channels_last)
+    n_test = min(N_TEST, n_total)
+    spk_all = (np.arange(n_total) // UTTS_PER_SPK).astype(np.int32)
+    ids, last = enroll_last_utterance(None, spk_all[:n_test])                  # Q17: last utterance enrols
+    last_dev = torch.from_numpy(last).to(dev)
+
+    fe_events = []
+
+    def one_step(record):
+        # timed region: everything from resident PCM to the score matrix
+        outs = []
+        for lo in range(0, n_local, pipe.micro_batch):
+            chunk = pcm[lo:lo + pipe.micro_batch]
+            voiced, vlen = pipe.voiced(chunk)
+            if record:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+            feat, n_frames, _ = eng.features(voiced, pipe.spec, lengths=vlen)
+            if record:
+                b.record()
+                fe_events.append((a, b, chunk.shape[0]))
+            if pipe.normalize:
+                eng.cmvn_(feat, n_frames, variance=True)
+            idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, rank * n_local + lo,
+                                 pipe.bad_clips)
+            outs.append(pipe.embed_cubes(pipe.cubes(feat, idx)))
+        local = torch.cat(outs, dim=0)
+        full = svdist.all_gather_embeddings(local, n_total)
+        scores = pipe.score(full[:n_test], full[:n_test][last_dev])
+        return full, scores
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full, scores = one_step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    bad = int(pipe.bad_clips.item())
+
+    result = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = n_total * args.steps / dt
+        # roofline of the fused front-end kernel, from HIP events on the launch stream
+        fe_ms = np.array([a.elapsed_time(b) for a, b, _ in fe_events])
+        fe_clips = np.array([n for _, _, n in fe_events])
+        bytes_per_utt = 48000 * 2 + 297 * 40 * 4                 # SURVEY 8(d) front end B: 143 520 B
+        avg_launch_s = float(fe_ms.mean()) * 1e-3
+        gbs = float(fe_clips.mean()) * bytes_per_utt / avg_launch_s / 1e9
+        labels = (spk_all[:n_test, None] == ids[None, :]).astype(np.float64)
+        sc = scores.cpu().numpy().astype(np.float64)
+        eer, auc, _, _ = evaluation.get_eer_auc(labels.flatten(), sc.flatten())
+        result = {
+            "metric": "utterances/sec (MFCC->embed->cosine)", "value": value, "unit": "utterances/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded formant 'voices', 3 s / 16 kHz int16, generated on device; random-init C3D2)",
+            "config": {"workload": "configs[4] per-GPU shard: %d clips/rank x %d rank(s): energy-VAD -> pre-emph + "
+                                   "lmfe(25ms/10ms/1024/40) -> CMVN -> 20x80x40 cube -> C3D2(f32) -> all-gather -> "
+                                   "%dx%d cosine" % (n_local, world, n_test, len(ids)),
+                       "clips_per_rank": n_local, "micro_batch": pipe.micro_batch, "vad": pipe.use_vad,
+                       "cmvn": pipe.normalize, "preemph": not args.no_preemph, "parallelism": "dp%d" % world,
+                       "crop_rng": "device"},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "frontend_kernel<int16,nfft1024>", "avg_launch_ms": avg_launch_s * 1e3,
+                         "clips_per_launch": float(fe_clips.mean()), "bytes_per_utt": bytes_per_utt,
+                         "frontend_share_of_step": float(fe_ms.sum()) / args.steps / ms_per_step},
+            "eer": {"eer": eer, "auc": auc, "pairs": int(labels.size), "short_clips": bad},
+        }
+
+    if rank == 0 and world == 1:
+        result["frontend_A"] = frontend_A_bench(eng, torch)
+        if args.cpu_sample > 0:
+            ns = min(args.cpu_sample, n_local)
+            sample = pcm[:ns]
+            emb, inter = pipe.embed(sample, return_intermediates=True)
+            crops = np.concatenate([d["crop_idx"].cpu().numpy() for d in inter])
+            state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            ref_emb, cpu_dt, threads = cpu_baseline(sample.cpu().numpy(), crops, state, not args.no_preemph,
+                                                    pipe.normalize, pipe.use_vad)
+            got = emb.cpu().numpy()
+            from oracle import scoring_ref
+            lab = (spk_all[:ns, None] == np.unique(spk_all[:ns])[None, :]).astype(np.float64)
+            _, last_s = enroll_last_utterance(None, spk_all[:ns])
+            s_gpu = pipe.score(emb, emb[torch.from_numpy(last_s).to(dev)]).cpu().numpy().astype(np.float64)
+            s_ref = scoring_ref.cosine_matrix(ref_emb, ref_emb[last_s]).astype(np.float64)
+            par = {"sample_clips": ns, "embed_max_abs_diff": float(np.abs(got - ref_emb).max()),
+                   "embed_scale": float(np.abs(ref_emb).max()),
+                   "score_max_abs_diff": float(np.abs(s_gpu - s_ref).max())}
+            if lab.shape[1] > 1:
+                par["eer_gpu"] = float(evaluation.get_eer_auc(lab.flatten(), s_gpu.flatten())[0])
+                par["eer_cpu_ref"] = float(scoring_ref.get_eer_auc(lab.flatten(), s_ref.flatten())[0])
+            # full-size check: oracle cosine + EER on the SAME embeddings must give the same EER
+            fe = full[:n_test].cpu().numpy()
+            s_or = scoring_ref.cosine_matrix(fe, fe[last]).astype(np.float64)
+            par["full_matrix_score_max_abs_diff"] = float(np.abs(s_or - sc).max())
+            par["full_matrix_eer_cpu_ref"] = float(scoring_ref.get_eer_auc(labels.flatten(), s_or.flatten())[0])
+            result["parity"] = par
+            result["cpu_baseline"] = {"value": ns / cpu_dt, "unit": "utterances/s", "cores": threads, "kind": "port",
+                                      "sample": "%d clips of the same shard through oracle/ (vad -> preemph -> lmfe "
+                                                "-> cmvn -> cube -> C3D2 batch 1 -> per-pair cosine), %.1f s" %
+                                                (ns, cpu_dt)}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void cube_gather_kernel(const float* __restric
   for (int64_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
     const int64_t utt = job / n_crops;
     int start = crop[job];
-    start = start < 0 ? 0 : (start > max_frames ? max_frames : start);
+    const bool none = start < 0;  // svk_cube_draw_crops marks clips that are too short
+    start = none ? max_frames : (start > max_frames ? max_frames : start);
     const float* src = feat + (utt * max_frames + start) * ncols;
     float* dst = out + job * run;
     const int avail = (max_frames - start) * ncols;  // never read past the clip's rows
@@ -221,6 +222,33 @@ __global__ __launch_bounds__(256) void cube_gather_kernel(const float* __restric
     } else {
       for (int i = threadIdx.x; i < run; i += blockDim.x) dst[i] = i < avail ? src[i] : 0.f;
     }
+  }
+}
+
+// ---- crop starts drawn on device ---------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void draw_crops_kernel(const int32_t* __restrict__ n_frames, int n_utt,
+                                                         int64_t first_utt, int n_crops, int crop_frames,
+                                                         uint64_t seed, int32_t* __restrict__ crop,
+                                                         int32_t* __restrict__ bad) {
+  const int64_t total = (int64_t)n_utt * n_crops;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int u = (int)(i / n_crops), c = (int)(i - (int64_t)u * n_crops);
+    const int range = n_frames[u] - crop_frames;
+    int v = -1;
+    if (range > 0) {
+      const uint64_t r = splitmix64(splitmix64(seed ^ (uint64_t)(first_utt + u)) + (uint64_t)c);
+      v = (int)__umul64hi(r, (uint64_t)range);  // floor(r / 2^64 * range)
+    } else if (c == 0 && bad) {
+      atomicAdd(bad, 1);
+    }
+    crop[i] = v;
   }
 }
 
@@ -325,6 +353,20 @@ int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int
   SVK_REQUIRE(ctx, d_feat, "NULL buffer");
   hipLaunchKernelGGL(cmvn_kernel, dim3(n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols, d_n_frames,
                      variance);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+int svk_cube_draw_crops(svk_ctx* ctx, const int32_t* d_n_frames, int32_t n_utt, int64_t first_utt,
+                        int32_t n_crops, int32_t crop_frames, uint64_t seed, int32_t* d_crop_idx,
+                        int32_t* d_bad_count) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_utt >= 0 && n_crops >= 0 && crop_frames >= 0, "negative shape");
+  const int64_t total = (int64_t)n_utt * n_crops;
+  if (total == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_n_frames && d_crop_idx, "NULL buffer");
+  hipLaunchKernelGGL(draw_crops_kernel, dim3(capped_grid(ctx, total, 256)), dim3(256), 0, ctx->stream, d_n_frames,
+                     n_utt, first_utt, n_crops, crop_frames, seed, d_crop_idx, d_bad_count);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }

@@ -249,6 +249,17 @@ class Engine:
         return {"keep": keep, "n_vad_frames": nvf, "voiced": voiced, "voiced_len": vlen, "seg": seg,
                 "frame_samples": fsamp}
 
+    def draw_crops(self, n_frames, n_crops=20, crop_frames=80, seed=12345, first_utt=0, bad_count=None):
+        """[n] i32 frame counts (device) -> [n, n_crops] i32 crop starts drawn on the device."""
+        torch = _torch()
+        nf = self.to_device(n_frames, torch.int32)
+        idx = torch.empty((nf.numel(), n_crops), dtype=torch.int32, device=self.device)
+        self._stream()
+        check(self.lib.svk_cube_draw_crops(self.ctx, self._ptr(nf), nf.numel(), int(first_utt), n_crops,
+                                           crop_frames, int(seed) & 0xFFFFFFFFFFFFFFFF, self._ptr(idx),
+                                           self._ptr(bad_count)), self.ctx)
+        return idx
+
     def cube_gather(self, feat, crop_idx, crop_frames=80, out=None):
         """feat [n, T, C] + crop_idx [n, n_crops] -> [n, 1, n_crops, crop_frames, C] (utils.py:364-379)."""
         torch = _torch()

@@ -18,7 +18,12 @@ from .engine import get_engine, spec_from_seconds
 
 class VerificationPipeline:
     def __init__(self, model, use_vad=True, vad_threshold=c.VAD_ENERGY_THRESHOLD, normalize=c.NORMALIZE,
-                 fused_model=True, crop_seed=12345, micro_batch=1024, channels_last=False):
+                 fused_model=True, crop_seed=12345, micro_batch=1024, channels_last=False, preemph_cof=None,
+                 crop_rng="reference"):
+        """crop_rng: "reference" draws crop starts on the host exactly like utils.py:372 (needs the
+        per-clip frame counts on the host: one small D2H per micro-batch); "device" draws them
+        in a kernel keyed by (crop_seed, global clip index) -- no host round trip.
+        preemph_cof: fuse processing.preemphasis(clip, cof=...) in front of the log-mel stage."""
         self.eng = get_engine()
         self.model = model.to(self.eng.device).eval()
         self.embedder = self.model.fused_inference(channels_last=channels_last) if fused_model else None
@@ -26,7 +31,11 @@ class VerificationPipeline:
         self.micro_batch = int(micro_batch)
         # model front end: lmfe(signal, 16000, 0.025, 0.01, 40, 1024)  (load_data.py:64-70, Q14)
         self.spec = spec_from_seconds(c.SAMPLE_RATE, c.FRAME_LEN, c.FRAME_STEP, c.NUM_FFT, c.NUM_COEF, c.NUM_COEF,
-                                      _lib.OUT_LMFE)
+                                      _lib.OUT_LMFE, preemph=preemph_cof is not None,
+                                      preemph_cof=0.0 if preemph_cof is None else preemph_cof)
+        assert crop_rng in ("reference", "device")
+        self.crop_rng, self.crop_seed = crop_rng, int(crop_seed)
+        self.bad_clips = torch.zeros((1,), dtype=torch.int32, device=self.eng.device)
         # the reference seeds the global NumPy RNG at utils import (utils.py:15) and draws
         # the crop starts from it (utils.py:372); a private RandomState keeps that sequence
         self.rng = np.random.RandomState(crop_seed)
@@ -68,16 +77,20 @@ class VerificationPipeline:
             return self.model(cubes, development=False)
 
     # ---- whole path ---------------------------------------------------------------------
-    def embed(self, pcm, crop_idx=None, return_intermediates=False):
+    def embed(self, pcm, crop_idx=None, return_intermediates=False, first_utt=0):
         """[n, L] int16 PCM (NumPy or CUDA tensor) -> [n, 128] float32 embeddings (device).
-        `crop_idx` [n, 20] overrides the RNG draw (parity tests feed both sides the same crops)."""
+        `crop_idx` [n, 20] overrides the RNG draw (parity tests feed both sides the same crops);
+        `first_utt` is the global index of row 0 (keys the device-side crop draw)."""
         pcm = self.eng.to_device(pcm)
         outs, inter = [], []
         for lo in range(0, pcm.shape[0], self.micro_batch):
             chunk = pcm[lo:lo + self.micro_batch]
             voiced, vlen = self.voiced(chunk)
             feat, n_frames = self.features(voiced, vlen)
-            if crop_idx is None:
+            if crop_idx is None and self.crop_rng == "device":
+                idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed,
+                                          first_utt + lo, self.bad_clips)
+            elif crop_idx is None:
                 idx = self.draw_crops(n_frames.to("cpu").numpy())      # tiny D2H: T per utterance
             else:
                 idx = np.asarray(crop_idx[lo:lo + self.micro_batch], dtype=np.int32)

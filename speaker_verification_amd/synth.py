@@ -73,3 +73,69 @@ def corpus(n_speakers, utts_per_speaker, n_samples=CLIP_SAMPLES, first_speaker=0
             pcm[row] = speaker_clip(first_speaker + s, u, n_samples)
             spk[row] = first_speaker + s
     return pcm, spk
+
+
+# --------------------------------------------------------------------------------------
+# Device-side generator for the big benchmark corpus (148 642 clips do not fit a NumPy loop)
+# --------------------------------------------------------------------------------------
+def corpus_device(n_clips, device, first_clip=0, utts_per_speaker=123, n_samples=CLIP_SAMPLES, seed=2024,
+                  chunk=512, fs=SAMPLE_RATE):
+    """[n_clips, n_samples] int16 CUDA tensor + speaker id per clip (NumPy int32).
+
+    Same recipe as `speaker_clip` (per-speaker formants from `_speaker_voice`, on/off bursts,
+    syllable modulation, noise floor) but synthesised with torch on the GPU, so the bytes are
+    NOT those of `speaker_clip`; parity checks copy the clips they need back to the host.
+    Clip g (global index first_clip + row) belongs to speaker g // utts_per_speaker and its
+    parameters depend only on (seed, g)."""
+    import torch
+    out = torch.empty((n_clips, n_samples), dtype=torch.int16, device=device)
+    gids = np.arange(first_clip, first_clip + n_clips)
+    speakers = (gids // utts_per_speaker).astype(np.int32)
+    t = torch.arange(n_samples, device=device, dtype=torch.float32) / float(fs)
+    K, NB = 6, 5                                   # formants (padded), bursts per clip
+    voices = {}
+    for lo in range(0, n_clips, chunk):
+        hi = min(n_clips, lo + chunk)
+        m = hi - lo
+        f = np.zeros((m, K), dtype=np.float32)
+        a = np.zeros((m, K), dtype=np.float32)
+        ph = np.zeros((m, K), dtype=np.float32)
+        start = np.zeros((m, NB), dtype=np.float32)
+        stop = np.zeros((m, NB), dtype=np.float32)
+        syl = np.zeros((m, 2), dtype=np.float32)
+        for r in range(m):
+            s = int(speakers[lo + r])
+            if s not in voices:
+                voices[s] = _speaker_voice(s)
+            fr, am = voices[s]
+            rng = np.random.default_rng([seed, int(gids[lo + r])])
+            k = fr.shape[0]
+            f[r, :k] = fr * (1.0 + 0.01 * rng.standard_normal(k))
+            a[r, :k] = am
+            ph[r, :k] = rng.uniform(0, 2 * np.pi, k)
+            pos = rng.uniform(0.0, 0.15)
+            for b in range(NB):
+                on = rng.uniform(0.5, 1.2)
+                start[r, b], stop[r, b] = pos, pos + on
+                pos += on + rng.uniform(0.12, 0.6)
+            syl[r] = (rng.uniform(3.0, 5.0), rng.uniform(0, 2 * np.pi))
+        f_d, a_d, ph_d = (torch.from_numpy(x).to(device) for x in (f, a, ph))
+        st_d, sp_d, syl_d = (torch.from_numpy(x).to(device) for x in (start, stop, syl))
+        voice = torch.zeros((m, n_samples), device=device)
+        for k in range(K):
+            voice += a_d[:, k:k + 1] * torch.sin(2 * np.pi * f_d[:, k:k + 1] * t[None, :] + ph_d[:, k:k + 1])
+        voice *= 3000.0 / torch.sqrt((a_d * a_d).sum(1, keepdim=True) / 2.0).clamp_min(1e-6)
+        gate = torch.zeros((m, n_samples), device=device)
+        for b in range(NB):
+            rise = ((t[None, :] - st_d[:, b:b + 1]) / 0.01).clamp(0, 1)
+            fall = ((sp_d[:, b:b + 1] - t[None, :]) / 0.01).clamp(0, 1)
+            gate += rise * fall
+        gate.clamp_(0, 1)
+        mod = 0.75 + 0.25 * torch.sin(2 * np.pi * syl_d[:, 0:1] * t[None, :] + syl_d[:, 1:2])
+        gen = torch.Generator(device=device)
+        gen.manual_seed(int(seed) * 1000003 + int(gids[lo]))
+        noise = torch.randn((m, n_samples), device=device, generator=gen)
+        breath = torch.randn((m, n_samples), device=device, generator=gen)
+        x = gate * mod * voice + 500.0 * gate * breath + 60.0 * noise
+        out[lo:hi] = x.round().clamp(-32768, 32767).to(torch.int16)
+    return out, speakers
