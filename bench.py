@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-vad", action="store_true")
     ap.add_argument("--no-cmvn", action="store_true")
     ap.add_argument("--no-preemph", action="store_true")
-    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-channels-last", action="store_true")
     ap.add_argument("--frontend-only", action="store_true", help="time BASELINE config 2 only (for rocprof)")
     return ap.parse_args()
 
@@ -125,7 +125,7 @@ def main():
 
     from speaker_verification_amd import constants as c, distributed as svdist, evaluation, synth
     from speaker_verification_amd.engine import get_engine
-    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    from speaker_verification_amd.model import calibrate_batchnorm, seeded_model
     from speaker_verification_amd.pipeline import VerificationPipeline, enroll_last_utterance
 
     eng = get_engine(local_rank)
@@ -140,10 +140,16 @@ def main():
     n_total = n_local * world
     pcm, speakers_local = synth.corpus_device(n_local, dev, first_clip=rank * n_local, utts_per_speaker=UTTS_PER_SPK)
     model = seeded_model(2024, n_labels=1211)
-    model.load_state_dict(perturb_inference_state(model.state_dict(), 99))
     pipe = VerificationPipeline(model, use_vad=not args.no_vad, normalize=not args.no_cmvn,
                                 preemph_cof=None if args.no_preemph else 0.98, crop_rng="device",
-                                micro_batch=args.micro_batch, channels_last=args.channels_last)
+                                micro_batch=args.micro_batch, channels_last=not args.no_channels_last)
+    # random-init weights (no checkpoint ships) with BatchNorm statistics calibrated on 256 clips of
+    # rank 0's shard, identically on every rank (model.calibrate_batchnorm explains why)
+    cal_pcm, _ = synth.corpus_device(256, dev, first_clip=0, utts_per_speaker=UTTS_PER_SPK)
+    _, cal = pipe.embed(cal_pcm, return_intermediates=True)
+    calibrate_batchnorm(pipe.model, torch.cat([d["cube"] for d in cal]))
+    pipe.refresh_model()
+    del cal_pcm, cal
     n_test = min(N_TEST, n_total)
     spk_all = (np.arange(n_total) // UTTS_PER_SPK).astype(np.int32)
     ids, last = enroll_last_utterance(None, spk_all[:n_test])                  # Q17: last utterance enrols
@@ -153,9 +159,9 @@ def main():
 
     def one_step(record):
         # timed region: everything from resident PCM to the score matrix
-        outs = []
-        for lo in range(0, n_local, pipe.micro_batch):
-            chunk = pcm[lo:lo + pipe.micro_batch]
+        local = torch.empty((n_local, 128), dtype=torch.float32, device=dev)
+        for lo, hi in pipe.chunks(n_local):
+            chunk = pcm[lo:hi]
             voiced, vlen = pipe.voiced(chunk)
             if record:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -163,13 +169,12 @@ def main():
             feat, n_frames, _ = eng.features(voiced, pipe.spec, lengths=vlen)
             if record:
                 b.record()
-                fe_events.append((a, b, chunk.shape[0]))
+                fe_events.append((a, b, hi - lo))
             if pipe.normalize:
                 eng.cmvn_(feat, n_frames, variance=True)
             idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, rank * n_local + lo,
                                  pipe.bad_clips)
-            outs.append(pipe.embed_cubes(pipe.cubes(feat, idx)))
-        local = torch.cat(outs, dim=0)
+            local[lo:hi] = pipe.embed_cubes(pipe.cubes(feat, idx))
         full = svdist.all_gather_embeddings(local, n_total)
         scores = pipe.score(full[:n_test], full[:n_test][last_dev])
         return full, scores
@@ -214,7 +219,7 @@ def main():
             "config": {"workload": "configs[4] per-GPU shard: %d clips/rank x %d rank(s): energy-VAD -> pre-emph + "
                                    "lmfe(25ms/10ms/1024/40) -> CMVN -> 20x80x40 cube -> C3D2(f32) -> all-gather -> "
                                    "%dx%d cosine" % (n_local, world, n_test, len(ids)),
-                       "clips_per_rank": n_local, "micro_batch": pipe.micro_batch, "vad": pipe.use_vad,
+                       "clips_per_rank": n_local, "micro_batch": pipe.chunks(n_local)[0][1], "vad": pipe.use_vad,
                        "cmvn": pipe.normalize, "preemph": not args.no_preemph, "parallelism": "dp%d" % world,
                        "crop_rng": "device"},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -231,7 +236,9 @@ def main():
             ns = min(args.cpu_sample, n_local)
             sample = pcm[:ns]
             emb, inter = pipe.embed(sample, return_intermediates=True)
-            crops = np.concatenate([d["crop_idx"].cpu().numpy() for d in inter])
+            crops = np.zeros((ns, c.CUBE_CROPS), dtype=np.int32)
+            for d in inter:
+                crops[d["lo"]:d["hi"]] = d["crop_idx"].cpu().numpy()
             state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             ref_emb, cpu_dt, threads = cpu_baseline(sample.cpu().numpy(), crops, state, not args.no_preemph,
                                                     pipe.normalize, pipe.use_vad)

@@ -127,6 +127,29 @@ def seeded_model(seed, n_labels=1211, num_channels=1):
     return model.eval()
 
 
+def calibrate_batchnorm(model, cubes, batch=64):
+    """Set every BatchNorm3d's running statistics to the statistics of `cubes` (cumulative
+    average over batches), as a trained network's would be.  A fresh random-init C3D2 has
+    running mean 0 / var 1 while its activations are far from that, which makes the 128-d
+    output almost input-independent (all cosine scores within 1e-3 of 1.0) and the EER a coin
+    flip decided by rounding noise; calibrated statistics give a well-conditioned, still
+    untrained, embedding.  Deterministic given the weights and `cubes`."""
+    norms = [m for m in model.modules() if isinstance(m, nn.BatchNorm3d)]
+    saved = [(m.momentum, m.training) for m in norms]
+    was_training = model.training
+    for m in norms:
+        m.reset_running_stats()
+        m.momentum = None                      # cumulative moving average
+    model.train()
+    with torch.no_grad():
+        for lo in range(0, cubes.shape[0], batch):
+            model(cubes[lo:lo + batch], development=False)
+    for m, (momentum, _) in zip(norms, saved):
+        m.momentum = momentum
+    model.train(was_training)
+    return model
+
+
 def perturb_inference_state(state_dict, seed):
     """Give BatchNorm running statistics, affine terms and PReLU slopes
     non-trivial values (a fresh init has mean 0 / var 1 / slope 0.25, which

@@ -388,21 +388,25 @@ def test_siamese(eng, golden):
 # ---- whole path -------------------------------------------------------------------------------------------
 def test_pipeline_end_to_end_and_eer(eng):
     from speaker_verification_amd import evaluation
-    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    from speaker_verification_amd.model import calibrate_batchnorm, perturb_inference_state, seeded_model
     from speaker_verification_amd.pipeline import VerificationPipeline, enroll_last_utterance
     n_spk, per = 6, 4
     pcm, spk = synth.corpus(n_spk, per)
     model = seeded_model(11, n_labels=32)
     model.load_state_dict(perturb_inference_state(model.state_dict(), 12))
     pipe = VerificationPipeline(model, use_vad=True, micro_batch=16)
-    emb, inter = pipe.embed(pcm, return_intermediates=True)
-    emb = emb.cpu().numpy()
+    _, inter = pipe.embed(pcm, return_intermediates=True)
     crops = np.concatenate([d["crop_idx"] for d in inter])
     # crop draws follow the reference's RNG protocol (utils.py:15,372)
     rs = np.random.RandomState(12345)
     nfr = np.concatenate([d["n_frames"].cpu().numpy() for d in inter])
     want_crops = np.stack([rs.randint(int(T) - 80, size=20) for T in nfr])
     np.testing.assert_array_equal(crops, want_crops)
+    # BatchNorm statistics calibrated on the data (a well-conditioned embedding, see
+    # model.calibrate_batchnorm), then the same crops again through the final weights
+    calibrate_batchnorm(pipe.model, torch.cat([d["cube"] for d in inter]))
+    pipe.refresh_model()
+    emb = pipe.embed(pcm, crop_idx=crops).cpu().numpy()
 
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ref_emb = []
@@ -420,8 +424,20 @@ def test_pipeline_end_to_end_and_eer(eng):
     ref_scores = scoring_ref.cosine_matrix(ref_emb, ref_emb[last])
     np.testing.assert_allclose(scores, scoring_ref.cosine_matrix(emb, emb[last]), rtol=0, atol=1e-5)
     np.testing.assert_allclose(scores, ref_scores, rtol=0, atol=2e-3)
+    assert scores.std() > 0.05                                                  # well-conditioned scores
     labels = (spk[:, None] == ids[None, :]).astype(np.float64)
     eer_gpu, auc_gpu, _, _ = evaluation.get_eer_auc(labels.flatten(), scores.astype(np.float64).flatten())
     eer_ref, auc_ref, _, _ = scoring_ref.get_eer_auc(labels.flatten(), ref_scores.astype(np.float64).flatten())
     assert eer_gpu == pytest.approx(eer_ref, abs=1e-4)                          # EER parity
     assert auc_gpu == pytest.approx(auc_ref, abs=1e-4)
+    # device-side crop draw: in range, reproducible, keyed by the global clip index
+    nf_dev = eng.to_device(nfr.astype(np.int32))
+    d1 = eng.draw_crops(nf_dev, 20, 80, seed=7, first_utt=100).cpu().numpy()
+    d2 = eng.draw_crops(nf_dev[4:], 20, 80, seed=7, first_utt=104).cpu().numpy()
+    assert (d1 >= 0).all() and (d1 < (nfr - 80)[:, None]).all() and len(np.unique(d1)) > 50
+    np.testing.assert_array_equal(d1[4:], d2)
+    bad = torch.zeros(1, dtype=torch.int32, device=eng.device)
+    short = eng.draw_crops(eng.to_device(np.array([80, 300, 10], dtype=np.int32)), 20, 80, 7, 0, bad).cpu().numpy()
+    assert (short[0] == -1).all() and (short[2] == -1).all() and (short[1] >= 0).all() and int(bad.item()) == 2
+    z = eng.cube_gather(eng.to_device(np.ones((3, 300, 40), dtype=np.float32)), short).cpu().numpy()
+    assert not z[0].any() and not z[2].any() and (z[1] == 1).all()

@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-channels-last", action="store_true")
     args = ap.parse_args()
     import torch
     from speaker_verification_amd import constants as c, synth
@@ -26,7 +26,7 @@ def main():
     pcm, _ = synth.corpus_device(args.batch, eng.device)
     model = seeded_model(1)
     pipe = VerificationPipeline(model, normalize=True, preemph_cof=0.98, crop_rng="device",
-                                micro_batch=args.batch, channels_last=args.channels_last)
+                                micro_batch=args.batch, channels_last=not args.no_channels_last)
 
     def run():
         marks = [("start", torch.cuda.Event(enable_timing=True))]
