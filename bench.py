@@ -52,6 +52,22 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_frontend_pmc.json, written by tools/summarize_prof.py from separate --pmc
+    passes over `bench.py --frontend-only`: 1 024 full 3 s clips per launch, FETCH_SIZE doubled
+    per the gfx950 correction).  None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_frontend_pmc.json")))
+    if not files:
+        return None, None
+    try:
+        rec = json.load(open(files[-1])).get(kernel, {})
+    except (OSError, ValueError):
+        return None, None
+    return rec.get("hbm_traffic_bytes_per_launch"), os.path.basename(files[-1])
+
+
 def frontend_A_bench(eng, torch, reps=20, n_clips=1024):
     """BASELINE config 2: batched MFCC pipeline, 1 024 x 3 s clips, SpeechPy defaults."""
     from speaker_verification_amd import _lib, synth
@@ -75,11 +91,13 @@ def frontend_A_bench(eng, torch, reps=20, n_clips=1024):
     t_all = float(np.median([a.elapsed_time(c) for a, _, c in ev])) * 1e-3
     bytes_per_utt = 48000 * 2 + 298 * 13 * 4          # 111 496 B
     gbs = n_clips * bytes_per_utt / t_fe / 1e9
+    traffic, src = pmc_traffic("frontend_kernel<int16,nfft512>")
     return {"workload": "configs[1]: 1024 x 3 s clips, pre-emph + MFCC-13 (nfft 512) + CMVN",
             "utt_per_s": n_clips / t_all, "frontend_kernel_ms": t_fe * 1e3, "with_cmvn_ms": t_all * 1e3,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "frontend_kernel<int16,nfft512>",
-                         "bytes_per_utt": bytes_per_utt}}
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                         "algorithmic_bytes_per_launch": n_clips * bytes_per_utt,
+                         "kernel": "frontend_kernel<int16,nfft512>", "bytes_per_utt": bytes_per_utt}}
 
 
 def frontend_B_bench(eng, torch, reps=20, n_clips=1024):
@@ -101,11 +119,13 @@ def frontend_B_bench(eng, torch, reps=20, n_clips=1024):
     t = float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e-3
     bytes_per_utt = 48000 * 2 + 297 * 40 * 4
     gbs = n_clips * bytes_per_utt / t / 1e9
+    traffic, src = pmc_traffic("frontend_kernel<int16,nfft1024>")
     return {"workload": "1024 x 3 s clips, pre-emph + lmfe-40 (nfft 1024)", "utt_per_s": n_clips / t,
             "frontend_kernel_ms": t * 1e3,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "frontend_kernel<int16,nfft1024>",
-                         "bytes_per_utt": bytes_per_utt}}
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                         "algorithmic_bytes_per_launch": n_clips * bytes_per_utt,
+                         "kernel": "frontend_kernel<int16,nfft1024>", "bytes_per_utt": bytes_per_utt}}
 
 
 def cpu_baseline(pcm_host, crop_idx, state, preemph, cmvn, use_vad):
@@ -235,6 +255,7 @@ def main():
         bytes_per_utt = 48000 * 2 + 297 * 40 * 4                 # SURVEY 8(d) front end B: 143 520 B
         avg_launch_s = float(fe_ms.mean()) * 1e-3
         gbs = float(fe_clips.mean()) * bytes_per_utt / avg_launch_s / 1e9
+        traffic, traffic_src = pmc_traffic("frontend_kernel<int16,nfft1024>")
         labels = (spk_all[:n_test, None] == ids[None, :]).astype(np.float64)
         sc = scores.cpu().numpy().astype(np.float64)
         eer, auc, _, _ = evaluation.get_eer_auc(labels.flatten(), sc.flatten())
@@ -250,7 +271,9 @@ def main():
                        "cmvn": pipe.normalize, "preemph": not args.no_preemph, "parallelism": "dp%d" % world,
                        "crop_rng": "device"},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_note": "PMC pass ran this kernel on 1 024 FULL 3 s clips per launch "
+                                         "(algorithmic 146 964 480 B); launches here carry VAD-shortened clips",
                          "kernel": "frontend_kernel<int16,nfft1024>", "avg_launch_ms": avg_launch_s * 1e3,
                          "clips_per_launch": float(fe_clips.mean()), "bytes_per_utt": bytes_per_utt,
                          "frontend_share_of_step": float(fe_ms.sum()) / args.steps / ms_per_step},

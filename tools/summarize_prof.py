@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (gpurun_out/...) into the small files kept under profiles/.
+
+    python tools/summarize_prof.py <round-tag>      e.g.  r01
+
+Reads  gpurun_out/prof_bench/**/_kernel_stats.csv          (rocprofv3 --kernel-trace --stats -- bench.py)
+       gpurun_out/pmc_{fetch,write,sq}/**/_counter_collection.csv   (one --pmc pass each, bench.py --frontend-only)
+Writes profiles/<tag>_bench_kernel_stats.csv   (verbatim top rows of the stats table)
+       profiles/<tag>_frontend_pmc.json        (per-launch averages for our kernels + derived HBM traffic)
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide
+coalesced reads, so read bytes = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM section).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OURS = ("frontend_kernel", "cmvn_kernel", "vad_kernel", "cube_gather_kernel", "cosine_kernel", "draw_crops_kernel")
+
+
+def short(name):
+    for k in OURS:
+        if k in name:
+            extra = ""
+            if "frontend_kernel" in name:
+                extra = "<int16,nfft1024>" if "short, true" in name else "<int16,nfft512>" if "short, false" in name \
+                    else "<f32,nfft1024>" if "float, true" in name else "<f32,nfft512>"
+            return k + extra
+    return None
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    out_dir = os.path.join(REPO, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    stats = glob.glob(os.path.join(REPO, "gpurun_out", "prof_bench", "**", "*_kernel_stats.csv"), recursive=True)
+    if stats:
+        rows = list(csv.reader(open(stats[0])))
+        keep = [rows[0]] + [r for r in rows[1:] if float(r[4]) >= 0.05 or short(r[0])]
+        for r in keep[1:]:
+            if len(r[0]) > 160:
+                r[0] = r[0][:157] + "..."
+        with open(os.path.join(out_dir, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as fh:
+            csv.writer(fh).writerows(keep)
+        print("wrote", f"profiles/{tag}_bench_kernel_stats.csv", len(keep) - 1, "kernels")
+    summary = defaultdict(lambda: defaultdict(list))
+    meta = {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        for path in glob.glob(os.path.join(REPO, "gpurun_out", sub, "**", "*_counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(path)):
+                k = short(row["Kernel_Name"])
+                if not k:
+                    continue
+                summary[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                summary[k].setdefault("duration_ns_" + sub, []).append(
+                    int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+                meta[k] = {"grid_size": int(row["Grid_Size"]), "workgroup_size": int(row["Workgroup_Size"]),
+                           "vgpr": int(row["VGPR_Count"]), "accum_vgpr": int(row["Accum_VGPR_Count"]),
+                           "sgpr": int(row["SGPR_Count"]), "lds_block_size": int(row["LDS_Block_Size"])}
+    result = {}
+    for k, counters in summary.items():
+        rec = {name: sum(v) / len(v) for name, v in counters.items()}
+        rec["launches_seen"] = max(len(v) for v in counters.values())
+        rec.update(meta[k])
+        if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+            rec["hbm_read_bytes_per_launch"] = 2.0 * rec["FETCH_SIZE"] * 1024.0
+            rec["hbm_write_bytes_per_launch"] = rec["WRITE_SIZE"] * 1024.0
+            rec["hbm_traffic_bytes_per_launch"] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in rec and "SQ_BUSY_CYCLES" in rec and rec["SQ_BUSY_CYCLES"]:
+            rec["mfma_busy_over_sq_busy"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] / rec["SQ_BUSY_CYCLES"]
+        if "SQ_LDS_BANK_CONFLICT" in rec and rec.get("SQ_LDS_IDX_ACTIVE"):
+            rec["lds_conflict_fraction"] = rec["SQ_LDS_BANK_CONFLICT"] / rec["SQ_LDS_IDX_ACTIVE"]
+        result[k] = rec
+    if result:
+        result["_note"] = ("per-launch averages from separate rocprofv3 --pmc passes over `bench.py --frontend-only` "
+                           "(1024 x 3 s clips per launch); FETCH_SIZE/WRITE_SIZE in KiB, read side doubled per the "
+                           "gfx950 correction")
+        with open(os.path.join(out_dir, f"{tag}_frontend_pmc.json"), "w") as fh:
+            json.dump(result, fh, indent=1, sort_keys=True)
+        print(json.dumps(result, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
