@@ -25,6 +25,7 @@
 //   5. results go straight to HBM.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -37,7 +38,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int TILE = 16;     // frames per wave tile (= MFMA N)
+constexpr int MAX_TILE = 16;  // frames per wave tile: 8 or 16 (MFMA N = 16; an 8-frame tile leaves half of N idle)
+constexpr int RAW_OFF = 8;    // int16 staging: samples start 16 bytes in, slot RAW_OFF-1 holds the sample before the span
 constexpr int MAX_FT = 4;    // 16-filter tiles  (<= 64 filters)
 constexpr int MAX_CT = 4;    // 16-cepstrum tiles
 constexpr int PT_PAD = 8;    // ptile row padding (floats): conflict-free ds_read_b128
@@ -53,7 +55,7 @@ struct FrontendParams {
   int32_t flen, flen_eff, stride, nfilt, ncols, out_kind, dc_elim, preemph, pre_shift;
   float pre_cof;
   int32_t kp;        // power bins kept for the mel product, multiple of 16
-  int32_t span_pad;  // floats reserved for the staged samples
+  int32_t sig_bytes; // LDS bytes reserved for the staged samples (multiple of 16)
   int32_t n_ft, n_ct;
   int32_t chunk_lo[MAX_FT], chunk_hi[MAX_FT];
   const float2* tw1;    // [8][64]  W512^(lane*r)
@@ -111,11 +113,52 @@ __device__ __forceinline__ void stage_span(const FrontendParams& p, const PcmT* 
   }
 }
 
-template <typename PcmT, bool SPLIT1024>
+// int16 clips with no pre-emphasis or the usual shift of 1: park the RAW samples (2 bytes each,
+// half the LDS of the f32 form) and pre-emphasise when a frame is read: x[n] - c * x[n-1] needs
+// one extra sample in front of the span (the clip's LAST sample when the span starts the clip:
+// np.roll wraps, Q5).
+__device__ __forceinline__ void stage_raw16(const FrontendParams& p, const int16_t* x, int64_t s0, int need, int len,
+                                            int16_t* sigh, int lane) {
+  typedef short vec_t __attribute__((ext_vector_type(8)));
+  const bool fast = (reinterpret_cast<uintptr_t>(x + s0) & 15) == 0;
+  for (int i = lane * 8; i < need; i += 64 * 8) {
+    const int64_t idx = s0 + i;
+    vec_t raw;
+    if (fast && idx + 8 <= len) {
+      raw = *reinterpret_cast<const vec_t*>(x + idx);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) raw[e] = idx + e < len ? x[idx + e] : (short)0;
+    }
+    *reinterpret_cast<vec_t*>(sigh + RAW_OFF + i) = raw;
+  }
+  if (lane == 0 && p.preemph) sigh[RAW_OFF - 1] = s0 == 0 ? x[len - 1] : x[s0 - 1];
+}
+
+// Wave sum with DPP moves only (no LDS crossbar): an inclusive scan inside each 16-lane row
+// (row_shr 1, 2, 4, 8), then row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3
+// (row_bcast:31).  The total is in LANE 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v = dpp_add<0x111, 0xf>(v);
+  v = dpp_add<0x112, 0xf>(v);
+  v = dpp_add<0x114, 0xf>(v);
+  v = dpp_add<0x118, 0xf>(v);
+  v = dpp_add<0x142, 0xa>(v);
+  v = dpp_add<0x143, 0xc>(v);
+  return v;
+}
+
+template <typename PcmT, bool SPLIT1024, int TILE, bool RAW16>
 __global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sig = reinterpret_cast<float*>(smem);
-  float* ptile = sig + p.span_pad;
+  int16_t* sigh = reinterpret_cast<int16_t*>(smem);
+  float* ptile = reinterpret_cast<float*>(smem + p.sig_bytes);
   const int prow = p.kp + PT_PAD;
   float2* scr = reinterpret_cast<float2*>(ptile + TILE * prow);
   float* elds = reinterpret_cast<float*>(scr + SCR);
@@ -134,7 +177,7 @@ __global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
   }
   const float inv_scale = SPLIT1024 ? (1.0f / 1024.0f) : (1.0f / (4.0f * 512.0f));
   const int mirror = (64 - lane) & 63;
-  const bool lane0 = lane == 0;
+  const bool lane0 = lane == 0, lane63 = lane == 63;
   const int nchunks = p.kp >> 4;
   const int64_t total = (int64_t)p.n_utt * p.tiles_per_utt;
 
@@ -154,14 +197,49 @@ __global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
       const PcmT* x = reinterpret_cast<const PcmT*>(p.pcm) + off;
       const int need = (nvalid - 1) * p.stride + p.flen_eff;
       __syncthreads();  // previous tile's readers of sig / ptile are done
-      stage_span<PcmT>(p, x, (int64_t)f0 * p.stride, need, len, sig, lane);
+      if constexpr (RAW16)
+        stage_raw16(p, reinterpret_cast<const int16_t*>(x), (int64_t)f0 * p.stride, need, len, sigh, lane);
+      else
+        stage_span<PcmT>(p, x, (int64_t)f0 * p.stride, need, len, sig, lane);
       __syncthreads();
 
       // ---- spectra -----------------------------------------------------------
       constexpr int FR_PER_FFT = SPLIT1024 ? 1 : 2;
       for (int fa = 0; fa < nvalid; fa += FR_PER_FFT) {
         float2 v[8];
-        if (SPLIT1024) {
+        const bool hasb = !SPLIT1024 && fa + 1 < nvalid;
+        if constexpr (RAW16) {
+          // raw int16 in LDS; x[n] - c * x[n-1] on the way in (c = 0 when pre-emphasis is off)
+          const int16_t* sa = sigh + RAW_OFF + fa * p.stride;
+          const int16_t* sb = sigh + RAW_OFF + (hasb ? fa + 1 : fa) * p.stride;
+          const bool pre = p.preemph != 0;
+          const float c = pre ? p.pre_cof : 0.f;
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            if (SPLIT1024) {
+              const int i0 = 2 * (lane + 64 * a);
+              float e0 = 0.f, e1 = 0.f;
+              if (i0 < p.flen_eff) {
+                const float x0 = (float)sa[i0];
+                e0 = pre ? x0 - c * (float)sa[i0 - 1] : x0;
+                if (i0 + 1 < p.flen_eff) e1 = (float)sa[i0 + 1] - c * x0;
+              }
+              v[a] = make_float2(e0, e1);
+            } else {
+              const int n = lane + 64 * a;
+              float ea_ = 0.f, eb_ = 0.f;
+              if (n < p.flen_eff) {
+                ea_ = (float)sa[n];
+                if (hasb) eb_ = (float)sb[n];
+                if (pre) {
+                  ea_ -= c * (float)sa[n - 1];
+                  if (hasb) eb_ -= c * (float)sb[n - 1];
+                }
+              }
+              v[a] = make_float2(ea_, eb_);
+            }
+          }
+        } else if (SPLIT1024) {
           const float* s = sig + fa * p.stride;
 #pragma unroll
           for (int a = 0; a < 8; ++a) {
@@ -171,7 +249,6 @@ __global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
           }
         } else {
           const float* sa = sig + fa * p.stride;
-          const bool hasb = fa + 1 < nvalid;
           const float* sb = sig + (hasb ? fa + 1 : fa) * p.stride;
 #pragma unroll
           for (int a = 0; a < 8; ++a) {
@@ -224,9 +301,9 @@ __global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
             eb += (4.f * z.y * z.y) * inv_scale;
           }
         }
-        ea = wave_sum(ea);
-        if (!SPLIT1024) eb = wave_sum(eb);
-        if (lane0) {
+        ea = wave_sum_lane63(ea);
+        if (!SPLIT1024) eb = wave_sum_lane63(eb);
+        if (lane63) {
           elds[fa] = ea == 0.f ? EPS64 : ea;  // feature.py:205
           if (!SPLIT1024) elds[fa + 1] = eb == 0.f ? EPS64 : eb;
         }
@@ -237,7 +314,7 @@ __global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
       f32x4 acc[MAX_FT];
 #pragma unroll
       for (int t = 0; t < MAX_FT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const float* pb = ptile + jf * prow + 4 * g;
+      const float* pb = ptile + (jf & (TILE - 1)) * prow + 4 * g;  // an 8-frame tile repeats its rows in N = 8..15
 #pragma unroll
       for (int t = 0; t < MAX_FT; ++t) {
         if (t < p.n_ft) {
@@ -281,7 +358,7 @@ __global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
         }
       } else {
         // ---- cepstra^T = DCT x log(mel)^T: acc[t][r] is already the B operand ------
-        const float le = logf(elds[jf]);
+        const float le = logf(elds[jf & (TILE - 1)]);
 #pragma unroll
         for (int c = 0; c < MAX_CT; ++c) {
           if (c < p.n_ct) {
@@ -304,7 +381,7 @@ __global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
           }
         }
       }
-      if (p.energy && row_ok && g == 0) p.energy[(int64_t)utt * p.max_frames + f0 + jf] = elds[jf];
+      if (p.energy && row_ok && g == 0) p.energy[(int64_t)utt * p.max_frames + f0 + jf] = elds[jf & (TILE - 1)];
     }
 
     // rows of this tile past the clip's last frame: defined (zero) output
@@ -325,14 +402,40 @@ __global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
 struct svk_frontend_plan {
   svk_frontend_cfg cfg;
   int device;
-  int kp, n_ft, n_ct, ncols, flen_eff, span_pad;
+  int kp, n_ft, n_ct, ncols, flen_eff;
+  int tile;  // frames per wave tile (8 or 16), chosen for residency
   int chunk_lo[MAX_FT], chunk_hi[MAX_FT];
-  size_t lds_bytes;
   void* d_tables;  // one allocation: tw1 | tw2 | tw3 | fbfrag | dctfrag
   const float2 *tw1, *tw2, *tw3;
   const f32x4* fbfrag;
   const float* dctfrag;
 };
+
+namespace {
+
+// LDS carve of one wave: staged samples | power tile [tile][kp + PT_PAD] | FFT scratch | energies
+struct LdsLayout {
+  int sig_bytes;
+  size_t total;
+};
+LdsLayout lds_layout(const svk_frontend_plan* plan, int tile, bool raw16) {
+  const int span = (tile - 1) * plan->cfg.frame_stride + plan->flen_eff;
+  LdsLayout l;
+  if (raw16)
+    l.sig_bytes = (((RAW_OFF + span + 8) * 2 + 15) / 16) * 16;  // whole 16-byte groups per lane
+  else
+    l.sig_bytes = (((span + 8) * 4 + 15) / 16) * 16;
+  l.total = (size_t)l.sig_bytes + sizeof(float) * (size_t)(tile * (plan->kp + PT_PAD) + 2 * SCR + MAX_TILE);
+  return l;
+}
+
+template <typename PcmT, bool RAW16>
+void (*pick_kernel(bool split, int tile))(const FrontendParams) {
+  if (split) return tile == 8 ? frontend_kernel<PcmT, true, 8, RAW16> : frontend_kernel<PcmT, true, 16, RAW16>;
+  return tile == 8 ? frontend_kernel<PcmT, false, 8, RAW16> : frontend_kernel<PcmT, false, 16, RAW16>;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -399,13 +502,22 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
     plan->chunk_lo[t] = lo;
     plan->chunk_hi[t] = hi;
   }
-  const int span = (TILE - 1) * cfg->frame_stride + plan->flen_eff;
-  plan->span_pad = ((span + 31) / 32) * 32 + 32;  // staging writes whole 16-byte groups per lane
-  plan->lds_bytes = sizeof(float) * (size_t)(plan->span_pad + TILE * (plan->kp + PT_PAD) + 2 * SCR + TILE);
-  if (plan->lds_bytes > 160 * 1024) {
+  // Tile size: the kernel is latency-bound, so residency (waves per CU, set by LDS per wave) matters
+  // more than the half-idle MFMA N of an 8-frame tile.  SVK_FRONTEND_TILE=8|16 overrides (tuning).
+  {
+    const size_t l16 = lds_layout(plan, 16, true).total, l8 = lds_layout(plan, 8, true).total;
+    const int w16 = (int)std::min<size_t>(12, 160 * 1024 / l16), w8 = (int)std::min<size_t>(12, 160 * 1024 / l8);
+    plan->tile = w8 > w16 ? 8 : 16;
+    if (const char* env = getenv("SVK_FRONTEND_TILE")) {
+      const int t = atoi(env);
+      if (t == 8 || t == 16) plan->tile = t;
+    }
+  }
+  if (lds_layout(plan, plan->tile, false).total > 160 * 1024) {
+    const size_t need = lds_layout(plan, plan->tile, false).total;
     delete plan;
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "frame stride %d needs %zu bytes of LDS per wave (limit 160 KiB)",
-                    cfg->frame_stride, plan->lds_bytes);
+                    cfg->frame_stride, need);
   }
 
   // ---- host tables (float64 maths, rounded once to f32) ----
@@ -502,7 +614,9 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.clip_len = clip_len;
   p.n_utt = n_utt;
   p.max_frames = max_frames;
-  p.tiles_per_utt = (max_frames + TILE - 1) / TILE;
+  const bool raw16 = pcm_dtype == SVK_PCM_I16 && (!plan->cfg.preemph || plan->cfg.preemph_shift == 1);
+  const LdsLayout lds = lds_layout(plan, plan->tile, raw16);
+  p.tiles_per_utt = (max_frames + plan->tile - 1) / plan->tile;
   p.flen = plan->cfg.frame_len;
   p.flen_eff = plan->flen_eff;
   p.stride = plan->cfg.frame_stride;
@@ -514,7 +628,7 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.pre_shift = plan->cfg.preemph_shift;
   p.pre_cof = plan->cfg.preemph_cof;
   p.kp = plan->kp;
-  p.span_pad = plan->span_pad;
+  p.sig_bytes = lds.sig_bytes;
   p.n_ft = plan->n_ft;
   p.n_ct = plan->n_ct;
   for (int t = 0; t < MAX_FT; ++t) {
@@ -531,17 +645,17 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.n_frames = d_n_frames;
 
   const int64_t total = (int64_t)n_utt * p.tiles_per_utt;
-  const int waves_per_cu = std::max(1, std::min(32, (int)(ctx->lds_per_cu / plan->lds_bytes)));
+  const int waves_per_cu = std::max(1, std::min(12, (int)(ctx->lds_per_cu / lds.total)));  // 12: VGPR limit
   int64_t grid = std::min<int64_t>(total, (int64_t)ctx->num_cu * waves_per_cu * 2);
   const bool split = plan->cfg.nfft == 1024;
   void (*kern)(const FrontendParams) = nullptr;
   if (pcm_dtype == SVK_PCM_I16)
-    kern = split ? frontend_kernel<int16_t, true> : frontend_kernel<int16_t, false>;
+    kern = raw16 ? pick_kernel<int16_t, true>(split, plan->tile) : pick_kernel<int16_t, false>(split, plan->tile);
   else
-    kern = split ? frontend_kernel<float, true> : frontend_kernel<float, false>;
+    kern = pick_kernel<float, false>(split, plan->tile);
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)plan->lds_bytes));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), plan->lds_bytes, ctx->stream, p);
+                                   (int)lds.total));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds.total, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }

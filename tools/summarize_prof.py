@@ -26,8 +26,8 @@ def short(name):
         if k in name:
             extra = ""
             if "frontend_kernel" in name:
-                extra = "<int16,nfft1024>" if "short, true" in name else "<int16,nfft512>" if "short, false" in name \
-                    else "<f32,nfft1024>" if "float, true" in name else "<f32,nfft512>"
+                extra = "<int16,nfft1024>" if "<short, true" in name else "<int16,nfft512>" if "<short, false" in name \
+                    else "<f32,nfft1024>" if "<float, true" in name else "<f32,nfft512>"
             return k + extra
     return None
 
