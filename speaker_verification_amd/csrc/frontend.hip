@@ -154,7 +154,7 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 }
 
 template <typename PcmT, bool SPLIT1024, int TILE, bool RAW16>
-__global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
+__global__ __launch_bounds__(64, 4) void frontend_kernel(const FrontendParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sig = reinterpret_cast<float*>(smem);
   int16_t* sigh = reinterpret_cast<int16_t*>(smem);
@@ -258,47 +258,55 @@ __global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
             v[a].y = (in && hasb) ? sb[n] : 0.f;
           }
         }
-        fft512_wave(v, scr, lane, t1, t2);
-
-        float2 s7 = shfl2(v[7], mirror), s6 = shfl2(v[6], mirror), s5 = shfl2(v[5], mirror),
-               s4 = shfl2(v[4], mirror);
-        float2 zm[4] = {lane0 ? v[0] : s7, lane0 ? s7 : s6, lane0 ? s6 : s5, lane0 ? s5 : s4};
+        // Frame energy = sum over ALL nfft/2+1 power bins (feature.py:202).  By Parseval that is
+        // sum(x^2)/2 + (X[0]^2 + X[nfft/2]^2) / (2 nfft), so only the bins the mel filters read
+        // (k < kp) have to be untangled.
         float ea = 0.f, eb = 0.f;
-        float* rowa = ptile + fa * prow;
-        float* rowb = rowa + prow;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float2 zk = v[j], zn = zm[j];
-          const int k = lane + 64 * j;
+        for (int a = 0; a < 8; ++a) {
           if (SPLIT1024) {
-            // X[k] = E + W^k O, X[512-k] = conj(E - W^k O)
-            const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-            const float2 O = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-            const float2 Tw = cmul(t3[j], O);
-            const float2 xp = E + Tw, xm = E - Tw;
-            const float pk = (xp.x * xp.x + xp.y * xp.y) * inv_scale;
-            const float pm = (xm.x * xm.x + xm.y * xm.y) * inv_scale;
-            ea += pk + pm;
-            if (k < p.kp) rowa[k] = pk;
+            ea += v[a].x * v[a].x + v[a].y * v[a].y;
           } else {
-            const float ar = zk.x + zn.x, ai = zk.y - zn.y, br = zk.y + zn.y, bi = zk.x - zn.x;
-            const float pa = (ar * ar + ai * ai) * inv_scale;
-            const float pb = (br * br + bi * bi) * inv_scale;
-            ea += pa;
-            eb += pb;
-            if (k < p.kp) {
-              rowa[k] = pa;
-              rowb[k] = pb;
-            }
+            ea += v[a].x * v[a].x;
+            eb += v[a].y * v[a].y;
           }
         }
-        if (lane0) {  // bin nfft/2 (k = 256 of the complex FFT), its own partner
-          const float2 z = v[4];
-          if (SPLIT1024) {
-            ea += (z.x * z.x + z.y * z.y) * inv_scale;  // |E + (-i) O|^2 with E, O real
-          } else {
-            ea += (4.f * z.x * z.x) * inv_scale;
-            eb += (4.f * z.y * z.y) * inv_scale;
+        ea *= 0.5f;
+        eb *= 0.5f;
+
+        fft512_wave(v, scr, lane, t1, t2);
+
+        if (lane0) {
+          if (SPLIT1024) {  // X[0] = Re + Im, X[512] = Re - Im of Z[0]
+            ea += (v[0].x * v[0].x + v[0].y * v[0].y) * (1.0f / 1024.0f);
+          } else {          // X1[0], X1[256] = Re Z[0], Re Z[256];  X2: the imaginary parts
+            ea += (v[0].x * v[0].x + v[4].x * v[4].x) * (1.0f / 1024.0f);
+            eb += (v[0].y * v[0].y + v[4].y * v[4].y) * (1.0f / 1024.0f);
+          }
+        }
+        float* rowa = ptile + fa * prow;
+        float* rowb = rowa + prow;
+        float2 carry = v[0];  // lane 0 pairs bin 64 j with bin 64 (8 - j): one register later
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (64 * j < p.kp) {
+            const float2 sm = shfl2(v[7 - j], mirror);
+            const float2 zk = v[j], zn = lane0 ? carry : sm;
+            carry = sm;
+            const int k = lane + 64 * j;
+            if (SPLIT1024) {
+              // X[k] = E + W^k O  with  E = (Zk + conj Zn)/2,  O = (Zk - conj Zn)/(2i)
+              const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+              const float2 O = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+              const float2 xp = E + cmul(t3[j], O);
+              if (k < p.kp) rowa[k] = (xp.x * xp.x + xp.y * xp.y) * inv_scale;
+            } else {
+              const float ar = zk.x + zn.x, ai = zk.y - zn.y, br = zk.y + zn.y, bi = zk.x - zn.x;
+              if (k < p.kp) {
+                rowa[k] = (ar * ar + ai * ai) * inv_scale;
+                rowb[k] = (br * br + bi * bi) * inv_scale;
+              }
+            }
           }
         }
         ea = wave_sum_lane63(ea);
@@ -312,21 +320,32 @@ __global__ __launch_bounds__(64) void frontend_kernel(const FrontendParams p) {
 
       // ---- mel^T = fb x P^T (f32 MFMA), block-sparse over 16-bin chunks ---------
       f32x4 acc[MAX_FT];
-#pragma unroll
-      for (int t = 0; t < MAX_FT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* pb = ptile + (jf & (TILE - 1)) * prow + 4 * g;  // an 8-frame tile repeats its rows in N = 8..15
 #pragma unroll
       for (int t = 0; t < MAX_FT; ++t) {
+        // two accumulators per filter tile: back-to-back MFMAs never wait on their own result
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
         if (t < p.n_ft) {
-          for (int u = p.chunk_lo[t]; u < p.chunk_hi[t]; ++u) {
-            const f32x4 a = p.fbfrag[((int64_t)t * nchunks + u) * 64 + lane];
-            const f32x4 b = *reinterpret_cast<const f32x4*>(pb + 16 * u);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc[t], 0, 0, 0);
+          const f32x4* frag = p.fbfrag + (int64_t)t * nchunks * 64 + lane;
+          for (int u = p.chunk_lo[t]; u < p.chunk_hi[t]; u += 2) {
+            const bool two = u + 1 < p.chunk_hi[t];
+            const f32x4 a0 = frag[(int64_t)u * 64];
+            const f32x4 a1 = two ? frag[(int64_t)(u + 1) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(pb + 16 * u);
+            const f32x4 b1 = two ? *reinterpret_cast<const f32x4*>(pb + 16 * (u + 1)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], b0[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1], b0[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[2], b0[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[3], b0[3], acc1, 0, 0, 0);
+            if (two) {
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], b1[0], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1], b1[1], acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[2], b1[2], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[3], b1[3], acc1, 0, 0, 0);
+            }
           }
         }
+        acc[t] = acc0 + acc1;
       }
       // lane (jf, g) now holds mel[filter 16 t + 4 g + reg][frame jf]
       const bool row_ok = jf < nvalid;
@@ -506,7 +525,7 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
   // more than the half-idle MFMA N of an 8-frame tile.  SVK_FRONTEND_TILE=8|16 overrides (tuning).
   {
     const size_t l16 = lds_layout(plan, 16, true).total, l8 = lds_layout(plan, 8, true).total;
-    const int w16 = (int)std::min<size_t>(12, 160 * 1024 / l16), w8 = (int)std::min<size_t>(12, 160 * 1024 / l8);
+    const int w16 = (int)std::min<size_t>(16, 160 * 1024 / l16), w8 = (int)std::min<size_t>(16, 160 * 1024 / l8);
     plan->tile = w8 > w16 ? 8 : 16;
     if (const char* env = getenv("SVK_FRONTEND_TILE")) {
       const int t = atoi(env);
@@ -645,7 +664,7 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.n_frames = d_n_frames;
 
   const int64_t total = (int64_t)n_utt * p.tiles_per_utt;
-  const int waves_per_cu = std::max(1, std::min(12, (int)(ctx->lds_per_cu / lds.total)));  // 12: VGPR limit
+  const int waves_per_cu = std::max(1, std::min(16, (int)(ctx->lds_per_cu / lds.total)));  // 16: 128 VGPRs
   int64_t grid = std::min<int64_t>(total, (int64_t)ctx->num_cu * waves_per_cu * 2);
   const bool split = plan->cfg.nfft == 1024;
   void (*kern)(const FrontendParams) = nullptr;
