@@ -162,26 +162,31 @@ __global__ __launch_bounds__(64, 4) void frontend_kernel(const FrontendParams p)
   const int prow = p.kp + PT_PAD;
   float2* scr = reinterpret_cast<float2*>(ptile + TILE * prow);
   float* elds = reinterpret_cast<float*>(scr + SCR);
-  const int lane = threadIdx.x;
-  const int jf = lane & 15, g = lane >> 4;
+  const int lane_id = threadIdx.x;
 
   float2 t1[8], t2[8], t3[5];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    t1[r] = p.tw1[r * 64 + lane];
-    t2[r] = p.tw2[r * 64 + lane];
+    t1[r] = p.tw1[r * 64 + lane_id];
+    t2[r] = p.tw2[r * 64 + lane_id];
   }
   if (SPLIT1024) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) t3[q] = p.tw3[q * 64 + lane];
+    for (int q = 0; q < 5; ++q) t3[q] = p.tw3[q * 64 + lane_id];
   }
   const float inv_scale = SPLIT1024 ? (1.0f / 1024.0f) : (1.0f / (4.0f * 512.0f));
-  const int mirror = (64 - lane) & 63;
-  const bool lane0 = lane == 0, lane63 = lane == 63;
   const int nchunks = p.kp >> 4;
   const int64_t total = (int64_t)p.n_utt * p.tiles_per_utt;
 
   for (int64_t tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    // An opaque per-tile copy of the lane id: without it the compiler hoists every lane-derived
+    // address and predicate of the tile body out of this loop and pins ~40 VGPRs for the whole
+    // kernel (172 -> 3 waves per SIMD become 2); recomputing them per tile is a few dozen VALU.
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    const int jf = lane & 15, g = lane >> 4;
+    const int mirror = (64 - lane) & 63;
+    const bool lane0 = lane == 0, lane63 = lane == 63;
     const int utt = (int)(tile / p.tiles_per_utt);
     const int f0 = (int)(tile % p.tiles_per_utt) * TILE;
     const int64_t off = p.offsets ? p.offsets[utt] : (int64_t)utt * p.clip_stride;
@@ -378,25 +383,21 @@ __global__ __launch_bounds__(64, 4) void frontend_kernel(const FrontendParams p)
       } else {
         // ---- cepstra^T = DCT x log(mel)^T: acc[t][r] is already the B operand ------
         const float le = logf(elds[jf & (TILE - 1)]);
+        for (int c = 0; c < p.n_ct; ++c) {  // runtime loop: keeps the table loads of one cepstral tile in flight, not four
+          f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const float* dfrag = p.dctfrag + (int64_t)c * p.n_ft * 4 * 64 + lane;
 #pragma unroll
-        for (int c = 0; c < MAX_CT; ++c) {
-          if (c < p.n_ct) {
-            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int t = 0; t < MAX_FT; ++t) {
+            if (t < p.n_ft) {
 #pragma unroll
-            for (int t = 0; t < MAX_FT; ++t) {
-              if (t < p.n_ft) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const float a = p.dctfrag[(((int64_t)c * p.n_ft + t) * 4 + r) * 64 + lane];
-                  o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[t][r], o, 0, 0, 0);
-                }
-              }
+              for (int r = 0; r < 4; ++r)
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(dfrag[(t * 4 + r) * 64], acc[t][r], o, 0, 0, 0);
             }
+          }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int cep = 16 * c + 4 * g + r;
-              if (row_ok && cep < p.ncols) orow[cep] = (cep == 0 && p.dc_elim) ? le : o[r];  // feature.py:151-152
-            }
+          for (int r = 0; r < 4; ++r) {
+            const int cep = 16 * c + 4 * g + r;
+            if (row_ok && cep < p.ncols) orow[cep] = (cep == 0 && p.dc_elim) ? le : o[r];  // feature.py:151-152
           }
         }
       }
@@ -664,7 +665,7 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.n_frames = d_n_frames;
 
   const int64_t total = (int64_t)n_utt * p.tiles_per_utt;
-  const int waves_per_cu = std::max(1, std::min(16, (int)(ctx->lds_per_cu / lds.total)));  // 16: 128 VGPRs
+  const int waves_per_cu = std::max(1, std::min(16, (int)(ctx->lds_per_cu / lds.total)));  // 16: <= 128 VGPRs = 4 waves per SIMD
   int64_t grid = std::min<int64_t>(total, (int64_t)ctx->num_cu * waves_per_cu * 2);
   const bool split = plan->cfg.nfft == 1024;
   void (*kern)(const FrontendParams) = nullptr;
