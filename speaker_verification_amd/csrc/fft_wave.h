@@ -3,14 +3,22 @@
 //
 // 8 points per lane, three radix-8 passes in registers, two transposes through a 576-entry
 // float2 LDS scratch whose paddings (row stride 72, then 9) make every ds_read_b64 /
-// ds_write_b64 of the transposes bank-conflict free.  The workgroup must be exactly one
-// wave (blockDim.x == 64): __syncthreads() then only orders this wave's LDS traffic.
+// ds_write_b64 of the transposes bank-conflict free.  Only this wave touches its scratch, and
+// the LDS unit executes one wave's DS instructions in order, so the transposes need no
+// s_barrier: wave_sync() merely stops the compiler from moving LDS accesses across it.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace svk_fft {
 
 constexpr int SCR = 576;  // float2 entries of scratch the caller provides
+
+// Order this wave's LDS accesses (compiler fence + wave-level barrier; no instruction cost).
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -41,20 +49,20 @@ __device__ __forceinline__ void fft512_wave(float2 (&v)[8], float2* scr, int lan
   dft8(v);
 #pragma unroll
   for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], t1[r]);
-  __syncthreads();  // scratch free (previous readers done)
+  wave_sync();  // scratch free (previous readers done)
 #pragma unroll
   for (int r = 0; r < 8; ++r) scr[r * 72 + lane] = v[r];
-  __syncthreads();
+  wave_sync();
   const int r2 = lane >> 3, p = lane & 7;
 #pragma unroll
   for (int b = 0; b < 8; ++b) v[b] = scr[r2 * 72 + 8 * b + p];
   dft8(v);
 #pragma unroll
   for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], t2[r]);
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int r1 = 0; r1 < 8; ++r1) scr[(8 * r1 + r2) * 9 + p] = v[r1];
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int q = 0; q < 8; ++q) v[q] = scr[lane * 9 + q];
   dft8(v);

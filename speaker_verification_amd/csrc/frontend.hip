@@ -6,8 +6,11 @@
 //   processing.py:142-174 (|rfft|^2 / nfft)       feature.py:202-205 (frame energy, 0 -> eps)
 //   feature.py:216-217 (mel projection, 0 -> eps) feature.py:146-153 (log, DCT-II ortho, c0 := log E)
 //
-// Work decomposition (one 64-lane wave per workgroup, no cross-wave traffic):
-//   a wave owns a TILE of 16 consecutive frames of one clip and loops over tiles.
+// Work decomposition: one workgroup per CU, as many waves as LDS allows (up to 16); the
+// workgroup copies the filterbank / DCT operand fragments into LDS once (they are re-read
+// for every tile: fetching them from L2 per tile cost 4x the PCM traffic and its latency),
+// then every wave works on its own: it owns a TILE of 8 or 16 consecutive frames of one
+// clip, a private LDS slice, and loops over tiles with no further workgroup barrier.
 //   1. the tile's sample span is read from HBM once with 16-byte loads, pre-emphasised
 //      in flight and parked in LDS as f32 (frames overlap, so each sample feeds 2+ frames);
 //   2. a 512-point complex FFT runs across the wave: 8 points per lane, three radix-8
@@ -41,7 +44,6 @@ namespace {
 constexpr int MAX_TILE = 16;  // frames per wave tile: 8 or 16 (MFMA N = 16; an 8-frame tile leaves half of N idle)
 constexpr int RAW_OFF = 8;    // int16 staging: samples start 16 bytes in, slot RAW_OFF-1 holds the sample before the span
 constexpr int MAX_FT = 4;    // 16-filter tiles  (<= 64 filters)
-constexpr int MAX_CT = 4;    // 16-cepstrum tiles
 constexpr int PT_PAD = 8;    // ptile row padding (floats): conflict-free ds_read_b128
 constexpr float EPS64 = 2.220446049250313e-16f;  // np.finfo(float).eps, functions.py:62
 
@@ -61,8 +63,10 @@ struct FrontendParams {
   const float2* tw1;    // [8][64]  W512^(lane*r)
   const float2* tw2;    // [8][64]  W64^((lane&7)*r)
   const float2* tw3;    // [5][64]  W1024^(lane+64q), q<4; [4][0] = W1024^256
-  const f32x4* fbfrag;  // [n_ft][kp/16][64]
+  const f32x4* fbfrag;  // [n_slots][64]: only the non-zero (filter tile, 16-bin chunk) blocks
   const float* dctfrag; // [n_ct][n_ft][4][64]
+  int32_t n_slots, slot_base[MAX_FT];  // block (t, u) lives in slot slot_base[t] + u - chunk_lo[t]
+  int32_t table_bytes, wave_bytes;     // LDS: shared tables, then one slice per wave
   float* feat;
   float* energy;
   int32_t* n_frames;
@@ -154,15 +158,24 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 }
 
 template <typename PcmT, bool SPLIT1024, int TILE, bool RAW16>
-__global__ __launch_bounds__(64, 4) void frontend_kernel(const FrontendParams p) {
+__global__ __launch_bounds__(1024) void frontend_kernel(const FrontendParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sig = reinterpret_cast<float*>(smem);
-  int16_t* sigh = reinterpret_cast<int16_t*>(smem);
-  float* ptile = reinterpret_cast<float*>(smem + p.sig_bytes);
+  // shared by the workgroup: mel and DCT operand fragments
+  f32x4* fb_lds = reinterpret_cast<f32x4*>(smem);
+  float* dct_lds = reinterpret_cast<float*>(smem + (size_t)p.n_slots * 64 * sizeof(f32x4));
+  for (int i = threadIdx.x; i < p.n_slots * 64; i += blockDim.x) fb_lds[i] = p.fbfrag[i];
+  for (int i = threadIdx.x; i < p.n_ct * p.n_ft * 4 * 64; i += blockDim.x) dct_lds[i] = p.dctfrag[i];
+  __syncthreads();  // the only workgroup-wide barrier; from here on waves never wait for each other
+  // private to this wave
+  const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  char* mine = smem + p.table_bytes + (size_t)wave * p.wave_bytes;
+  float* sig = reinterpret_cast<float*>(mine);
+  int16_t* sigh = reinterpret_cast<int16_t*>(mine);
+  float* ptile = reinterpret_cast<float*>(mine + p.sig_bytes);
   const int prow = p.kp + PT_PAD;
   float2* scr = reinterpret_cast<float2*>(ptile + TILE * prow);
   float* elds = reinterpret_cast<float*>(scr + SCR);
-  const int lane_id = threadIdx.x;
+  const int lane_id = threadIdx.x & 63;
 
   float2 t1[8], t2[8], t3[5];
 #pragma unroll
@@ -175,10 +188,10 @@ __global__ __launch_bounds__(64, 4) void frontend_kernel(const FrontendParams p)
     for (int q = 0; q < 5; ++q) t3[q] = p.tw3[q * 64 + lane_id];
   }
   const float inv_scale = SPLIT1024 ? (1.0f / 1024.0f) : (1.0f / (4.0f * 512.0f));
-  const int nchunks = p.kp >> 4;
   const int64_t total = (int64_t)p.n_utt * p.tiles_per_utt;
 
-  for (int64_t tile = blockIdx.x; tile < total; tile += gridDim.x) {
+  // consecutive tiles go to the waves of one workgroup: neighbours share the overlapping PCM in L1
+  for (int64_t tile = (int64_t)blockIdx.x * n_waves + wave; tile < total; tile += (int64_t)gridDim.x * n_waves) {
     // An opaque per-tile copy of the lane id: without it the compiler hoists every lane-derived
     // address and predicate of the tile body out of this loop and pins ~40 VGPRs for the whole
     // kernel (172 -> 3 waves per SIMD become 2); recomputing them per tile is a few dozen VALU.
@@ -201,12 +214,12 @@ __global__ __launch_bounds__(64, 4) void frontend_kernel(const FrontendParams p)
     if (nvalid > 0) {
       const PcmT* x = reinterpret_cast<const PcmT*>(p.pcm) + off;
       const int need = (nvalid - 1) * p.stride + p.flen_eff;
-      __syncthreads();  // previous tile's readers of sig / ptile are done
+      wave_sync();  // previous tile's readers of sig / ptile are done
       if constexpr (RAW16)
         stage_raw16(p, reinterpret_cast<const int16_t*>(x), (int64_t)f0 * p.stride, need, len, sigh, lane);
       else
         stage_span<PcmT>(p, x, (int64_t)f0 * p.stride, need, len, sig, lane);
-      __syncthreads();
+      wave_sync();
 
       // ---- spectra -----------------------------------------------------------
       constexpr int FR_PER_FFT = SPLIT1024 ? 1 : 2;
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(64, 4) void frontend_kernel(const FrontendParams p)
           if (!SPLIT1024) elds[fa + 1] = eb == 0.f ? EPS64 : eb;
         }
       }
-      __syncthreads();
+      wave_sync();
 
       // ---- mel^T = fb x P^T (f32 MFMA), block-sparse over 16-bin chunks ---------
       f32x4 acc[MAX_FT];
@@ -331,11 +344,11 @@ __global__ __launch_bounds__(64, 4) void frontend_kernel(const FrontendParams p)
         // two accumulators per filter tile: back-to-back MFMAs never wait on their own result
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
         if (t < p.n_ft) {
-          const f32x4* frag = p.fbfrag + (int64_t)t * nchunks * 64 + lane;
+          const f32x4* frag = fb_lds + (p.slot_base[t] - p.chunk_lo[t]) * 64 + lane;
           for (int u = p.chunk_lo[t]; u < p.chunk_hi[t]; u += 2) {
             const bool two = u + 1 < p.chunk_hi[t];
-            const f32x4 a0 = frag[(int64_t)u * 64];
-            const f32x4 a1 = two ? frag[(int64_t)(u + 1) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 a0 = frag[u * 64];
+            const f32x4 a1 = two ? frag[(u + 1) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(pb + 16 * u);
             const f32x4 b1 = two ? *reinterpret_cast<const f32x4*>(pb + 16 * (u + 1)) : (f32x4){0.f, 0.f, 0.f, 0.f};
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], b0[0], acc0, 0, 0, 0);
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(64, 4) void frontend_kernel(const FrontendParams p)
         const float le = logf(elds[jf & (TILE - 1)]);
         for (int c = 0; c < p.n_ct; ++c) {  // runtime loop: keeps the table loads of one cepstral tile in flight, not four
           f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-          const float* dfrag = p.dctfrag + (int64_t)c * p.n_ft * 4 * 64 + lane;
+          const float* dfrag = dct_lds + c * p.n_ft * 4 * 64 + lane;
 #pragma unroll
           for (int t = 0; t < MAX_FT; ++t) {
             if (t < p.n_ft) {
@@ -424,6 +437,8 @@ struct svk_frontend_plan {
   int device;
   int kp, n_ft, n_ct, ncols, flen_eff;
   int tile;  // frames per wave tile (8 or 16), chosen for residency
+  int n_slots, slot_base[MAX_FT];
+  int table_bytes;
   int chunk_lo[MAX_FT], chunk_hi[MAX_FT];
   void* d_tables;  // one allocation: tw1 | tw2 | tw3 | fbfrag | dctfrag
   const float2 *tw1, *tw2, *tw3;
@@ -433,19 +448,23 @@ struct svk_frontend_plan {
 
 namespace {
 
-// LDS carve of one wave: staged samples | power tile [tile][kp + PT_PAD] | FFT scratch | energies
+// LDS carve: [shared tables] then per wave [staged samples | power tile [tile][kp + PT_PAD] | FFT scratch | energies]
 struct LdsLayout {
-  int sig_bytes;
+  int sig_bytes, wave_bytes, waves;
   size_t total;
 };
-LdsLayout lds_layout(const svk_frontend_plan* plan, int tile, bool raw16) {
+LdsLayout lds_layout(const svk_frontend_plan* plan, int tile, bool raw16, int lds_per_cu) {
   const int span = (tile - 1) * plan->cfg.frame_stride + plan->flen_eff;
   LdsLayout l;
   if (raw16)
     l.sig_bytes = (((RAW_OFF + span + 8) * 2 + 15) / 16) * 16;  // whole 16-byte groups per lane
   else
     l.sig_bytes = (((span + 8) * 4 + 15) / 16) * 16;
-  l.total = (size_t)l.sig_bytes + sizeof(float) * (size_t)(tile * (plan->kp + PT_PAD) + 2 * SCR + MAX_TILE);
+  l.wave_bytes = l.sig_bytes + (int)sizeof(float) * (tile * (plan->kp + PT_PAD) + 2 * SCR + MAX_TILE);
+  l.wave_bytes = ((l.wave_bytes + 15) / 16) * 16;
+  const int room = lds_per_cu - plan->table_bytes;
+  l.waves = room >= l.wave_bytes ? std::min(16, room / l.wave_bytes) : 0;  // 16 waves = 1024 threads = 128 VGPRs
+  l.total = (size_t)plan->table_bytes + (size_t)l.waves * l.wave_bytes;
   return l;
 }
 
@@ -522,27 +541,33 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
     plan->chunk_lo[t] = lo;
     plan->chunk_hi[t] = hi;
   }
-  // Tile size: the kernel is latency-bound, so residency (waves per CU, set by LDS per wave) matters
-  // more than the half-idle MFMA N of an 8-frame tile.  SVK_FRONTEND_TILE=8|16 overrides (tuning).
+  plan->n_slots = 0;
+  for (int t = 0; t < MAX_FT; ++t) {
+    plan->slot_base[t] = plan->n_slots;
+    plan->n_slots += plan->chunk_hi[t] - plan->chunk_lo[t];
+  }
+  plan->table_bytes = plan->n_slots * 64 * (int)sizeof(f32x4) +
+                      std::max(plan->n_ct, 0) * plan->n_ft * 4 * 64 * (int)sizeof(float);
+  plan->table_bytes = ((plan->table_bytes + 15) / 16) * 16;
+  // Tile size: 8 frames leave half of the MFMA N dimension idle but halve the per-wave LDS slice,
+  // i.e. double the waves a CU can hold.  SVK_FRONTEND_TILE=8|16 overrides (tuning).
   {
-    const size_t l16 = lds_layout(plan, 16, true).total, l8 = lds_layout(plan, 8, true).total;
-    const int w16 = (int)std::min<size_t>(16, 160 * 1024 / l16), w8 = (int)std::min<size_t>(16, 160 * 1024 / l8);
+    const int w16 = lds_layout(plan, 16, true, ctx->lds_per_cu).waves, w8 = lds_layout(plan, 8, true, ctx->lds_per_cu).waves;
     plan->tile = w8 > w16 ? 8 : 16;
     if (const char* env = getenv("SVK_FRONTEND_TILE")) {
       const int t = atoi(env);
       if (t == 8 || t == 16) plan->tile = t;
     }
   }
-  if (lds_layout(plan, plan->tile, false).total > 160 * 1024) {
-    const size_t need = lds_layout(plan, plan->tile, false).total;
+  if (lds_layout(plan, plan->tile, false, ctx->lds_per_cu).waves < 1) {
     delete plan;
-    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "frame stride %d needs %zu bytes of LDS per wave (limit 160 KiB)",
-                    cfg->frame_stride, need);
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "frame stride %d / %d filters need more than %d bytes of LDS per CU",
+                    cfg->frame_stride, cfg->num_filters, ctx->lds_per_cu);
   }
 
   // ---- host tables (float64 maths, rounded once to f32) ----
   const size_t n_tw = 8 * 64, n_tw3 = 5 * 64;
-  const size_t n_fb = (size_t)plan->n_ft * nchunks * 64 * 4;
+  const size_t n_fb = (size_t)std::max(plan->n_slots, 1) * 64 * 4;
   const size_t n_dct = (size_t)std::max(plan->n_ct, 1) * plan->n_ft * 4 * 64;
   std::vector<float> host(2 * n_tw * 2 + n_tw3 * 2 + n_fb + n_dct, 0.f);
   float* h_tw1 = host.data();
@@ -569,12 +594,12 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
   // A-operand fragments of the filterbank: lane l = (i = l & 15, kk = l >> 4), element e of
   // chunk u is fb[16 t + i][16 u + 4 kk + e]
   for (int t = 0; t < plan->n_ft; ++t)
-    for (int u = 0; u < nchunks; ++u)
+    for (int u = plan->chunk_lo[t]; u < plan->chunk_hi[t]; ++u)
       for (int l = 0; l < 64; ++l)
         for (int e = 0; e < 4; ++e) {
           const int filt = 16 * t + (l & 15), bin = 16 * u + 4 * (l >> 4) + e;
           double w = (filt < nf && bin < nbins) ? h_filterbank[(size_t)filt * nbins + bin] : 0.0;
-          h_fb[(((size_t)t * nchunks + u) * 64 + l) * 4 + e] = (float)w;
+          h_fb[(((size_t)plan->slot_base[t] + (u - plan->chunk_lo[t])) * 64 + l) * 4 + e] = (float)w;
         }
   // A-operand fragments of the DCT-II (ortho) matrix, k-step (t, r) <-> filter 16 t + 4 (l >> 4) + r
   // scipy.fftpack.dct(type=2, norm='ortho'): D[k][n] = sqrt(2/N) cos(pi k (2n+1) / 2N), D[0][n] = sqrt(1/N)
@@ -635,7 +660,7 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.n_utt = n_utt;
   p.max_frames = max_frames;
   const bool raw16 = pcm_dtype == SVK_PCM_I16 && (!plan->cfg.preemph || plan->cfg.preemph_shift == 1);
-  const LdsLayout lds = lds_layout(plan, plan->tile, raw16);
+  const LdsLayout lds = lds_layout(plan, plan->tile, raw16, ctx->lds_per_cu);
   p.tiles_per_utt = (max_frames + plan->tile - 1) / plan->tile;
   p.flen = plan->cfg.frame_len;
   p.flen_eff = plan->flen_eff;
@@ -649,6 +674,10 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.pre_cof = plan->cfg.preemph_cof;
   p.kp = plan->kp;
   p.sig_bytes = lds.sig_bytes;
+  p.wave_bytes = lds.wave_bytes;
+  p.table_bytes = plan->table_bytes;
+  p.n_slots = plan->n_slots;
+  for (int t = 0; t < MAX_FT; ++t) p.slot_base[t] = plan->slot_base[t];
   p.n_ft = plan->n_ft;
   p.n_ct = plan->n_ct;
   for (int t = 0; t < MAX_FT; ++t) {
@@ -665,8 +694,10 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.n_frames = d_n_frames;
 
   const int64_t total = (int64_t)n_utt * p.tiles_per_utt;
-  const int waves_per_cu = std::max(1, std::min(16, (int)(ctx->lds_per_cu / lds.total)));  // 16: <= 128 VGPRs = 4 waves per SIMD
-  int64_t grid = std::min<int64_t>(total, (int64_t)ctx->num_cu * waves_per_cu * 2);
+  // one workgroup of lds.waves waves per CU (it owns the CU's LDS); fewer when there is little work
+  const int waves = (int)std::max<int64_t>(1, std::min<int64_t>(lds.waves, (total + ctx->num_cu - 1) / ctx->num_cu));
+  const int64_t grid = std::min<int64_t>((total + waves - 1) / waves, ctx->num_cu);
+  const size_t lds_total = (size_t)plan->table_bytes + (size_t)waves * lds.wave_bytes;
   const bool split = plan->cfg.nfft == 1024;
   void (*kern)(const FrontendParams) = nullptr;
   if (pcm_dtype == SVK_PCM_I16)
@@ -674,8 +705,8 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   else
     kern = pick_kernel<float, false>(split, plan->tile);
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds.total));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds.total, ctx->stream, p);
+                                   (int)lds_total));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * waves), lds_total, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }
