@@ -67,6 +67,8 @@ struct FrontendParams {
   const float* dctfrag; // [n_ct][n_ft][4][64]
   int32_t n_slots, slot_base[MAX_FT];  // block (t, u) lives in slot slot_base[t] + u - chunk_lo[t]
   int32_t table_bytes, wave_bytes;     // LDS: shared tables, then one slice per wave
+  int32_t n_steps; // register steps a frame reaches: ceil(flen_eff / 64), or / 128 for nfft 1024
+  int32_t ablate;  // tuning only (SVK_FE_ABLATE): 1 skip staging, 2 skip the FFT loop, 4 skip mel/DCT/output
   float* feat;
   float* energy;
   int32_t* n_frames;
@@ -157,8 +159,62 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
+// Frame samples -> the 8 complex registers of a lane.  NSTEPS = how many of the 8 register steps
+// the frame reaches (frame_len / 64, or / 128 for the even-odd packing, rounded up); steps
+// before the last are read unconditionally, the last one clamps its address and masks, the
+// rest are the zero padding up to nfft (Q6).  Straight-line code: per-lane `if (n < frame_len)`
+// around every read cost 28 exec-mask branches and as many serialised LDS round trips per FFT.
+template <bool SPLIT1024, bool RAW16>
+struct FrameReader {
+  const float* sig;
+  const int16_t* sigh;
+  int off_a, off_b, flen;
+  bool pre;
+  float cof;
+  bool hasb;
+  int lane;
+
+  __device__ __forceinline__ float sample(int off, int idx) const {
+    if constexpr (RAW16) {
+      const int16_t* s = sigh + RAW_OFF + off + idx;
+      const float x0 = (float)s[0];
+      return pre ? x0 - cof * (float)s[-1] : x0;  // x[n] - c x[n-1] (shift 1), Q5
+    } else {
+      return sig[off + idx];
+    }
+  }
+
+  template <int NSTEPS>
+  __device__ __forceinline__ void read(float2 (&v)[8]) const {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int first = SPLIT1024 ? 2 * (lane + 64 * a) : lane + 64 * a;
+      if (a + 1 < NSTEPS) {
+        if (SPLIT1024) {
+          v[a] = make_float2(sample(off_a, first), sample(off_a, first + 1));
+        } else {
+          const float yb = sample(off_b, first);
+          v[a] = make_float2(sample(off_a, first), hasb ? yb : 0.f);
+        }
+      } else if (a + 1 == NSTEPS) {
+        if (SPLIT1024) {
+          const bool in0 = first < flen, in1 = first + 1 < flen;
+          const float x0 = sample(off_a, in0 ? first : 0), x1 = sample(off_a, in1 ? first + 1 : 0);
+          v[a] = make_float2(in0 ? x0 : 0.f, in1 ? x1 : 0.f);
+        } else {
+          const bool in = first < flen;
+          const float xa = sample(off_a, in ? first : 0), xb = sample(off_b, in ? first : 0);
+          v[a] = make_float2(in ? xa : 0.f, (in && hasb) ? xb : 0.f);
+        }
+      } else {
+        v[a] = make_float2(0.f, 0.f);
+      }
+    }
+  }
+};
+
 template <typename PcmT, bool SPLIT1024, int TILE, bool RAW16>
-__global__ __launch_bounds__(1024) void frontend_kernel(const FrontendParams p) {
+__global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // shared by the workgroup: mel and DCT operand fragments
   f32x4* fb_lds = reinterpret_cast<f32x4*>(smem);
@@ -215,7 +271,8 @@ __global__ __launch_bounds__(1024) void frontend_kernel(const FrontendParams p) 
       const PcmT* x = reinterpret_cast<const PcmT*>(p.pcm) + off;
       const int need = (nvalid - 1) * p.stride + p.flen_eff;
       wave_sync();  // previous tile's readers of sig / ptile are done
-      if constexpr (RAW16)
+      if (p.ablate & 1) {
+      } else if constexpr (RAW16)
         stage_raw16(p, reinterpret_cast<const int16_t*>(x), (int64_t)f0 * p.stride, need, len, sigh, lane);
       else
         stage_span<PcmT>(p, x, (int64_t)f0 * p.stride, need, len, sig, lane);
@@ -223,57 +280,21 @@ __global__ __launch_bounds__(1024) void frontend_kernel(const FrontendParams p) 
 
       // ---- spectra -----------------------------------------------------------
       constexpr int FR_PER_FFT = SPLIT1024 ? 1 : 2;
-      for (int fa = 0; fa < nvalid; fa += FR_PER_FFT) {
+      for (int fa = 0; fa < ((p.ablate & 2) ? 0 : nvalid); fa += FR_PER_FFT) {
         float2 v[8];
         const bool hasb = !SPLIT1024 && fa + 1 < nvalid;
-        if constexpr (RAW16) {
-          // raw int16 in LDS; x[n] - c * x[n-1] on the way in (c = 0 when pre-emphasis is off)
-          const int16_t* sa = sigh + RAW_OFF + fa * p.stride;
-          const int16_t* sb = sigh + RAW_OFF + (hasb ? fa + 1 : fa) * p.stride;
-          const bool pre = p.preemph != 0;
-          const float c = pre ? p.pre_cof : 0.f;
-#pragma unroll
-          for (int a = 0; a < 8; ++a) {
-            if (SPLIT1024) {
-              const int i0 = 2 * (lane + 64 * a);
-              float e0 = 0.f, e1 = 0.f;
-              if (i0 < p.flen_eff) {
-                const float x0 = (float)sa[i0];
-                e0 = pre ? x0 - c * (float)sa[i0 - 1] : x0;
-                if (i0 + 1 < p.flen_eff) e1 = (float)sa[i0 + 1] - c * x0;
-              }
-              v[a] = make_float2(e0, e1);
-            } else {
-              const int n = lane + 64 * a;
-              float ea_ = 0.f, eb_ = 0.f;
-              if (n < p.flen_eff) {
-                ea_ = (float)sa[n];
-                if (hasb) eb_ = (float)sb[n];
-                if (pre) {
-                  ea_ -= c * (float)sa[n - 1];
-                  if (hasb) eb_ -= c * (float)sb[n - 1];
-                }
-              }
-              v[a] = make_float2(ea_, eb_);
-            }
-          }
-        } else if (SPLIT1024) {
-          const float* s = sig + fa * p.stride;
-#pragma unroll
-          for (int a = 0; a < 8; ++a) {
-            const int i0 = 2 * (lane + 64 * a);
-            v[a].x = i0 < p.flen_eff ? s[i0] : 0.f;
-            v[a].y = i0 + 1 < p.flen_eff ? s[i0 + 1] : 0.f;
-          }
-        } else {
-          const float* sa = sig + fa * p.stride;
-          const float* sb = sig + (hasb ? fa + 1 : fa) * p.stride;
-#pragma unroll
-          for (int a = 0; a < 8; ++a) {
-            const int n = lane + 64 * a;
-            const bool in = n < p.flen_eff;
-            v[a].x = in ? sa[n] : 0.f;
-            v[a].y = (in && hasb) ? sb[n] : 0.f;
+        {
+          const FrameReader<SPLIT1024, RAW16> rd{sig, sigh, fa * p.stride, (hasb ? fa + 1 : fa) * p.stride, p.flen_eff,
+                                                 RAW16 && p.preemph != 0, p.pre_cof, hasb, lane};
+          switch (p.n_steps) {  // wave-uniform; each case is straight-line code
+            case 1: rd.template read<1>(v); break;
+            case 2: rd.template read<2>(v); break;
+            case 3: rd.template read<3>(v); break;
+            case 4: rd.template read<4>(v); break;
+            case 5: rd.template read<5>(v); break;
+            case 6: rd.template read<6>(v); break;
+            case 7: rd.template read<7>(v); break;
+            default: rd.template read<8>(v); break;
           }
         }
         // Frame energy = sum over ALL nfft/2+1 power bins (feature.py:202).  By Parseval that is
@@ -317,10 +338,10 @@ __global__ __launch_bounds__(1024) void frontend_kernel(const FrontendParams p) 
               const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
               const float2 O = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
               const float2 xp = E + cmul(t3[j], O);
-              if (k < p.kp) rowa[k] = (xp.x * xp.x + xp.y * xp.y) * inv_scale;
+              if (64 * (j + 1) <= p.kp || k < p.kp) rowa[k] = (xp.x * xp.x + xp.y * xp.y) * inv_scale;
             } else {
               const float ar = zk.x + zn.x, ai = zk.y - zn.y, br = zk.y + zn.y, bi = zk.x - zn.x;
-              if (k < p.kp) {
+              if (64 * (j + 1) <= p.kp || k < p.kp) {  // uniform for all but a ragged last step
                 rowa[k] = (ar * ar + ai * ai) * inv_scale;
                 rowb[k] = (br * br + bi * bi) * inv_scale;
               }
@@ -336,6 +357,7 @@ __global__ __launch_bounds__(1024) void frontend_kernel(const FrontendParams p) 
       }
       wave_sync();
 
+      if (p.ablate & 4) continue;
       // ---- mel^T = fb x P^T (f32 MFMA), block-sparse over 16-bin chunks ---------
       f32x4 acc[MAX_FT];
       const float* pb = ptile + (jf & (TILE - 1)) * prow + 4 * g;  // an 8-frame tile repeats its rows in N = 8..15
@@ -463,7 +485,7 @@ LdsLayout lds_layout(const svk_frontend_plan* plan, int tile, bool raw16, int ld
   l.wave_bytes = l.sig_bytes + (int)sizeof(float) * (tile * (plan->kp + PT_PAD) + 2 * SCR + MAX_TILE);
   l.wave_bytes = ((l.wave_bytes + 15) / 16) * 16;
   const int room = lds_per_cu - plan->table_bytes;
-  l.waves = room >= l.wave_bytes ? std::min(16, room / l.wave_bytes) : 0;  // 16 waves = 1024 threads = 128 VGPRs
+  l.waves = room >= l.wave_bytes ? std::min(12, room / l.wave_bytes) : 0;  // 12 waves = 768 threads: up to 168 VGPRs each, no spills
   l.total = (size_t)plan->table_bytes + (size_t)l.waves * l.wave_bytes;
   return l;
 }
@@ -676,6 +698,11 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.sig_bytes = lds.sig_bytes;
   p.wave_bytes = lds.wave_bytes;
   p.table_bytes = plan->table_bytes;
+  {
+    const int per = plan->cfg.nfft == 1024 ? 128 : 64;
+    p.n_steps = std::max(1, std::min(8, (plan->flen_eff + per - 1) / per));
+  }
+  p.ablate = getenv("SVK_FE_ABLATE") ? atoi(getenv("SVK_FE_ABLATE")) : 0;
   p.n_slots = plan->n_slots;
   for (int t = 0; t < MAX_FT; ++t) p.slot_base[t] = plan->slot_base[t];
   p.n_ft = plan->n_ft;
