@@ -60,9 +60,9 @@ struct FrontendParams {
   int32_t sig_bytes; // LDS bytes reserved for the staged samples (multiple of 16)
   int32_t n_ft, n_ct;
   int32_t chunk_lo[MAX_FT], chunk_hi[MAX_FT];
-  const float2* tw1;    // [8][64]  W512^(lane*r)
-  const float2* tw2;    // [8][64]  W64^((lane&7)*r)
-  const float2* tw3;    // [5][64]  W1024^(lane+64q), q<4; [4][0] = W1024^256
+  const cplx* tw1;    // [8][64]  W512^(lane*r)
+  const cplx* tw2;    // [8][64]  W64^((lane&7)*r)
+  const cplx* tw3;    // [5][64]  W1024^(lane+64q), q<4; [4][0] = W1024^256
   const f32x4* fbfrag;  // [n_slots][64]: only the non-zero (filter tile, 16-bin chunk) blocks
   const float* dctfrag; // [n_ct][n_ft][4][64]
   int32_t n_slots, slot_base[MAX_FT];  // block (t, u) lives in slot slot_base[t] + u - chunk_lo[t]
@@ -185,29 +185,29 @@ struct FrameReader {
   }
 
   template <int NSTEPS>
-  __device__ __forceinline__ void read(float2 (&v)[8]) const {
+  __device__ __forceinline__ void read(cplx (&v)[8]) const {
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
       const int first = SPLIT1024 ? 2 * (lane + 64 * a) : lane + 64 * a;
       if (a + 1 < NSTEPS) {
         if (SPLIT1024) {
-          v[a] = make_float2(sample(off_a, first), sample(off_a, first + 1));
+          v[a] = mk(sample(off_a, first), sample(off_a, first + 1));
         } else {
           const float yb = sample(off_b, first);
-          v[a] = make_float2(sample(off_a, first), hasb ? yb : 0.f);
+          v[a] = mk(sample(off_a, first), hasb ? yb : 0.f);
         }
       } else if (a + 1 == NSTEPS) {
         if (SPLIT1024) {
           const bool in0 = first < flen, in1 = first + 1 < flen;
           const float x0 = sample(off_a, in0 ? first : 0), x1 = sample(off_a, in1 ? first + 1 : 0);
-          v[a] = make_float2(in0 ? x0 : 0.f, in1 ? x1 : 0.f);
+          v[a] = mk(in0 ? x0 : 0.f, in1 ? x1 : 0.f);
         } else {
           const bool in = first < flen;
           const float xa = sample(off_a, in ? first : 0), xb = sample(off_b, in ? first : 0);
-          v[a] = make_float2(in ? xa : 0.f, (in && hasb) ? xb : 0.f);
+          v[a] = mk(in ? xa : 0.f, (in && hasb) ? xb : 0.f);
         }
       } else {
-        v[a] = make_float2(0.f, 0.f);
+        v[a] = mk(0.f, 0.f);
       }
     }
   }
@@ -229,11 +229,11 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
   int16_t* sigh = reinterpret_cast<int16_t*>(mine);
   float* ptile = reinterpret_cast<float*>(mine + p.sig_bytes);
   const int prow = p.kp + PT_PAD;
-  float2* scr = reinterpret_cast<float2*>(ptile + TILE * prow);
+  cplx* scr = reinterpret_cast<cplx*>(ptile + TILE * prow);
   float* elds = reinterpret_cast<float*>(scr + SCR);
   const int lane_id = threadIdx.x & 63;
 
-  float2 t1[8], t2[8], t3[5];
+  cplx t1[8], t2[8], t3[5];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     t1[r] = p.tw1[r * 64 + lane_id];
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
       // ---- spectra -----------------------------------------------------------
       constexpr int FR_PER_FFT = SPLIT1024 ? 1 : 2;
       for (int fa = 0; fa < ((p.ablate & 2) ? 0 : nvalid); fa += FR_PER_FFT) {
-        float2 v[8];
+        cplx v[8];
         const bool hasb = !SPLIT1024 && fa + 1 < nvalid;
         {
           const FrameReader<SPLIT1024, RAW16> rd{sig, sigh, fa * p.stride, (hasb ? fa + 1 : fa) * p.stride, p.flen_eff,
@@ -300,18 +300,11 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         // Frame energy = sum over ALL nfft/2+1 power bins (feature.py:202).  By Parseval that is
         // sum(x^2)/2 + (X[0]^2 + X[nfft/2]^2) / (2 nfft), so only the bins the mel filters read
         // (k < kp) have to be untangled.
-        float ea = 0.f, eb = 0.f;
+        cplx e2 = mk(0.f, 0.f);  // (sum re^2, sum im^2): one packed fma per register
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
-          if (SPLIT1024) {
-            ea += v[a].x * v[a].x + v[a].y * v[a].y;
-          } else {
-            ea += v[a].x * v[a].x;
-            eb += v[a].y * v[a].y;
-          }
-        }
-        ea *= 0.5f;
-        eb *= 0.5f;
+        for (int a = 0; a < 8; ++a) e2 = __builtin_elementwise_fma(v[a], v[a], e2);
+        float ea = SPLIT1024 ? 0.5f * (e2.x + e2.y) : 0.5f * e2.x;
+        float eb = 0.5f * e2.y;
 
         fft512_wave(v, scr, lane, t1, t2);
 
@@ -325,19 +318,19 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         }
         float* rowa = ptile + fa * prow;
         float* rowb = rowa + prow;
-        float2 carry = v[0];  // lane 0 pairs bin 64 j with bin 64 (8 - j): one register later
+        cplx carry = v[0];  // lane 0 pairs bin 64 j with bin 64 (8 - j): one register later
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (64 * j < p.kp) {
-            const float2 sm = shfl2(v[7 - j], mirror);
-            const float2 zk = v[j], zn = lane0 ? carry : sm;
+            const cplx sm = shfl2(v[7 - j], mirror);
+            const cplx zk = v[j], zn = lane0 ? carry : sm;
             carry = sm;
             const int k = lane + 64 * j;
             if (SPLIT1024) {
               // X[k] = E + W^k O  with  E = (Zk + conj Zn)/2,  O = (Zk - conj Zn)/(2i)
-              const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-              const float2 O = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-              const float2 xp = E + cmul(t3[j], O);
+              const cplx E = mk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+              const cplx O = mk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+              const cplx xp = E + cmul(t3[j], O);
               if (64 * (j + 1) <= p.kp || k < p.kp) rowa[k] = (xp.x * xp.x + xp.y * xp.y) * inv_scale;
             } else {
               const float ar = zk.x + zn.x, ai = zk.y - zn.y, br = zk.y + zn.y, bi = zk.x - zn.x;
@@ -463,7 +456,7 @@ struct svk_frontend_plan {
   int table_bytes;
   int chunk_lo[MAX_FT], chunk_hi[MAX_FT];
   void* d_tables;  // one allocation: tw1 | tw2 | tw3 | fbfrag | dctfrag
-  const float2 *tw1, *tw2, *tw3;
+  const cplx *tw1, *tw2, *tw3;
   const f32x4* fbfrag;
   const float* dctfrag;
 };
@@ -646,9 +639,9 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
     return svk_fail(ctx, SVK_ERR_HIP, "upload of front-end tables failed");
   }
   float* d = reinterpret_cast<float*>(plan->d_tables);
-  plan->tw1 = reinterpret_cast<const float2*>(d);
-  plan->tw2 = reinterpret_cast<const float2*>(d + 2 * n_tw);
-  plan->tw3 = reinterpret_cast<const float2*>(d + 4 * n_tw);
+  plan->tw1 = reinterpret_cast<const cplx*>(d);
+  plan->tw2 = reinterpret_cast<const cplx*>(d + 2 * n_tw);
+  plan->tw3 = reinterpret_cast<const cplx*>(d + 4 * n_tw);
   plan->fbfrag = reinterpret_cast<const f32x4*>(d + 4 * n_tw + 2 * n_tw3);
   plan->dctfrag = d + 4 * n_tw + 2 * n_tw3 + n_fb;
   *out = plan;
@@ -681,7 +674,8 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.clip_len = clip_len;
   p.n_utt = n_utt;
   p.max_frames = max_frames;
-  const bool raw16 = pcm_dtype == SVK_PCM_I16 && (!plan->cfg.preemph || plan->cfg.preemph_shift == 1);
+  const bool raw16 = pcm_dtype == SVK_PCM_I16 && (!plan->cfg.preemph || plan->cfg.preemph_shift == 1) &&
+                     !(getenv("SVK_FE_F32STAGE") && atoi(getenv("SVK_FE_F32STAGE")));
   const LdsLayout lds = lds_layout(plan, plan->tile, raw16, ctx->lds_per_cu);
   p.tiles_per_utt = (max_frames + plan->tile - 1) / plan->tile;
   p.flen = plan->cfg.frame_len;

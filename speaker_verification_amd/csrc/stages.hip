@@ -51,14 +51,14 @@ __global__ __launch_bounds__(256) void stack_frames_kernel(const float* __restri
 // One wave per workgroup; nfft = 512 handles two frames per FFT, nfft = 1024 one.
 template <bool SPLIT1024>
 __global__ __launch_bounds__(64) void spectrum_fft_kernel(const float* __restrict__ frames, int nframes, int flen,
-                                                          int power, const float2* __restrict__ tw,
+                                                          int power, const cplx* __restrict__ tw,
                                                           float* __restrict__ out) {
-  __shared__ float2 scr[SCR];
+  __shared__ cplx scr[SCR];
   const int lane = threadIdx.x;
   const int nfft = SPLIT1024 ? 1024 : 512;
   const int nbins = nfft / 2 + 1;
   const int feff = flen < nfft ? flen : nfft;
-  float2 t1[8], t2[8], t3[5];
+  cplx t1[8], t2[8], t3[5];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     t1[r] = tw[r * 64 + lane];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void spectrum_fft_kernel(const float* __restric
     const float* sa = frames + (int64_t)fa * flen;
     const bool hasb = !SPLIT1024 && fa + 1 < nframes;
     const float* sb = frames + (int64_t)(hasb ? fa + 1 : fa) * flen;
-    float2 v[8];
+    cplx v[8];
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
       if (SPLIT1024) {
@@ -88,20 +88,20 @@ __global__ __launch_bounds__(64) void spectrum_fft_kernel(const float* __restric
       }
     }
     fft512_wave(v, scr, lane, t1, t2);
-    float2 s7 = shfl2(v[7], mirror), s6 = shfl2(v[6], mirror), s5 = shfl2(v[5], mirror), s4 = shfl2(v[4], mirror);
-    float2 zm[5] = {lane0 ? v[0] : s7, lane0 ? s7 : s6, lane0 ? s6 : s5, lane0 ? s5 : s4, v[4]};
+    cplx s7 = shfl2(v[7], mirror), s6 = shfl2(v[6], mirror), s5 = shfl2(v[5], mirror), s4 = shfl2(v[4], mirror);
+    cplx zm[5] = {lane0 ? v[0] : s7, lane0 ? s7 : s6, lane0 ? s6 : s5, lane0 ? s5 : s4, v[4]};
     float* oa = out + (int64_t)fa * nbins;
     float* ob = oa + nbins;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       if (j == 4 && !lane0) continue;
-      const float2 zk = v[j], zn = zm[j];
+      const cplx zk = v[j], zn = zm[j];
       const int k = j == 4 ? 256 : lane + 64 * j;
       if (SPLIT1024) {
-        const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-        const float2 O = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-        const float2 Tw = cmul(t3[j], O);
-        const float2 xp = E + Tw, xm = E - Tw;
+        const cplx E = mk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const cplx O = mk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        const cplx Tw = cmul(t3[j], O);
+        const cplx xp = E + Tw, xm = E - Tw;
         float pk = (xp.x * xp.x + xp.y * xp.y) * scale, pm = (xm.x * xm.x + xm.y * xm.y) * scale;
         if (!power) {
           pk = sqrtf(pk);
@@ -253,24 +253,24 @@ __global__ __launch_bounds__(256) void draw_crops_kernel(const int32_t* __restri
 }
 
 // twiddles for spectrum_fft_kernel: tw1 [8][64] | tw2 [8][64] | tw3 [5][64]
-float2* g_spectrum_tables[64] = {nullptr};
+cplx* g_spectrum_tables[64] = {nullptr};
 
-int spectrum_tables(svk_ctx* ctx, const float2** out) {
+int spectrum_tables(svk_ctx* ctx, const cplx** out) {
   if (ctx->device < 0 || ctx->device >= 64) return svk_fail(ctx, SVK_ERR_BAD_ARG, "device index out of range");
-  float2*& d = g_spectrum_tables[ctx->device];
+  cplx*& d = g_spectrum_tables[ctx->device];
   if (!d) {
     const double PI = 3.14159265358979323846;
-    static float2 h[1024 + 5 * 64];
+    static cplx h[1024 + 5 * 64];
     for (int r = 0; r < 8; ++r)
       for (int l = 0; l < 64; ++l) {
         const double a1 = -2.0 * PI * (double)(l * r) / 512.0, a2 = -2.0 * PI * (double)((l & 7) * r) / 64.0;
-        h[r * 64 + l] = make_float2((float)cos(a1), (float)sin(a1));
-        h[512 + r * 64 + l] = make_float2((float)cos(a2), (float)sin(a2));
+        h[r * 64 + l] = mk((float)cos(a1), (float)sin(a1));
+        h[512 + r * 64 + l] = mk((float)cos(a2), (float)sin(a2));
       }
     for (int q = 0; q < 5; ++q)
       for (int l = 0; l < 64; ++l) {
         const double a = -2.0 * PI * (double)(l + 64 * q) / 1024.0;
-        h[1024 + q * 64 + l] = make_float2((float)cos(a), (float)sin(a));
+        h[1024 + q * 64 + l] = mk((float)cos(a), (float)sin(a));
       }
     SVK_HIP(ctx, hipSetDevice(ctx->device));
     SVK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(h)));
@@ -324,7 +324,7 @@ int svk_spectrum(svk_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t 
   if (n_frames == 0) return SVK_OK;
   SVK_REQUIRE(ctx, d_frames && d_out, "NULL buffer");
   if (nfft == 512 || nfft == 1024) {
-    const float2* tw = nullptr;
+    const cplx* tw = nullptr;
     int rc = spectrum_tables(ctx, &tw);
     if (rc != SVK_OK) return rc;
     if (nfft == 512) {
