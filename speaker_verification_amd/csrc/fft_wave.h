@@ -30,34 +30,59 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 __host__ __device__ __forceinline__ cplx mk(float re, float im) { return (cplx){re, im}; }
-// (a.x + i a.y) * (b.x + i b.y) = a.x * (b.x, b.y) + a.y * (-b.y, b.x)
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
-  const cplx ax = __builtin_shufflevector(a, a, 0, 0), ay = __builtin_shufflevector(a, a, 1, 1);
-  const cplx bs = mk(-b.y, b.x);
-  return __builtin_elementwise_fma(ay, bs, ax * b);
-}
-// a + (-i) b  and  a - (-i) b:   (-i) b = (b.y, -b.x)
-__device__ __forceinline__ cplx add_mi(cplx a, cplx b) { return a + mk(b.y, -b.x); }
-__device__ __forceinline__ cplx sub_mi(cplx a, cplx b) { return a - mk(b.y, -b.x); }
 
-// Forward 8-point DFT in place, natural order out (two radix-4 halves + one radix-2 layer).
+// Packed-f32 helpers written as single instructions: hipcc does not fold the swap / negate of a
+// complex operand into the op_sel / neg modifiers of v_pk_*_f32 (it spent 55 of the FFT's 180
+// VALU instructions on v_mov / v_xor for them), so the modifier forms are spelled out.
+// op_sel picks the dword of each 64-bit source that feeds the LOW result, op_sel_hi the HIGH.
+#define SVK_PK2(name, text)                                            \
+  __device__ __forceinline__ cplx name(cplx a, cplx b) {               \
+    cplx r;                                                            \
+    asm(text : "=v"(r) : "v"(a), "v"(b));                              \
+    return r;                                                          \
+  }
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+SVK_PK2(add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")
+// a - (-i) b = (a.x - b.y, a.y + b.x)
+SVK_PK2(sub_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")
+// a + conj(b) = (a.x + b.x, a.y - b.y)
+SVK_PK2(add_conj, "v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]")
+// (a.y + b.y, a.x - b.x)
+SVK_PK2(swap_add_conj, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[0,1]")
+#undef SVK_PK2
+// t (1 - i) = (t.x + t.y, t.y - t.x): W8 up to the factor 1/sqrt 2
+__device__ __forceinline__ cplx rot_w8(cplx t) { return add_mi(t, t); }
+// t (-1 - i) = (t.y - t.x, -t.x - t.y): W8^3 up to the factor 1/sqrt 2
+__device__ __forceinline__ cplx rot_w8_3(cplx t) {
+  cplx r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(t));
+  return r;
+}
+// (a.x + i a.y)(b.x + i b.y): two instructions, no temporaries for the swapped / negated b
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+  cplx t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (a.x b.x, a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=v"(r) : "v"(a), "v"(b), "v"(t));                                                  // (-a.y b.y, a.y b.x) + t
+  return r;
+}
+
+// Forward 8-point DFT in place, natural order out: 26 packed instructions.
 __device__ __forceinline__ void dft8(cplx (&v)[8]) {
-  const float S = 0.70710678118654752440f;
+  const cplx S = mk(0.70710678118654752440f, 0.70710678118654752440f);
   const cplx a0 = v[0] + v[4], a1 = v[0] - v[4], a2 = v[2] + v[6], d26 = v[2] - v[6];
   const cplx a4 = v[1] + v[5], a5 = v[1] - v[5], a6 = v[3] + v[7], d37 = v[3] - v[7];
   const cplx b0 = a0 + a2, b2 = a0 - a2, b1 = add_mi(a1, d26), b3 = sub_mi(a1, d26);
   const cplx c4 = a4 + a6, d46 = a4 - a6, t5 = add_mi(a5, d37), t7 = sub_mi(a5, d37);
-  // t5 * W8 = ((x + y), (y - x)) S ;  t7 * W8^3 = ((y - x), -(x + y)) S
-  const cplx c5 = mk(t5.x + t5.y, t5.y - t5.x) * S;
-  const cplx c7 = mk(t7.y - t7.x, -(t7.x + t7.y)) * S;
+  const cplx c5 = rot_w8(t5), c7 = rot_w8_3(t7);  // still to be scaled by 1/sqrt 2: folded into the fma below
   v[0] = b0 + c4;
   v[4] = b0 - c4;
-  v[1] = b1 + c5;
-  v[5] = b1 - c5;
+  v[1] = __builtin_elementwise_fma(c5, S, b1);
+  v[5] = __builtin_elementwise_fma(c5, -S, b1);
   v[2] = add_mi(b2, d46);
   v[6] = sub_mi(b2, d46);
-  v[3] = b3 + c7;
-  v[7] = b3 - c7;
+  v[3] = __builtin_elementwise_fma(c7, S, b3);
+  v[7] = __builtin_elementwise_fma(c7, -S, b3);
 }
 
 // 512-point forward complex FFT across one wave.

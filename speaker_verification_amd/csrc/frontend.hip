@@ -328,15 +328,20 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
             const int k = lane + 64 * j;
             if (SPLIT1024) {
               // X[k] = E + W^k O  with  E = (Zk + conj Zn)/2,  O = (Zk - conj Zn)/(2i)
-              const cplx E = mk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-              const cplx O = mk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-              const cplx xp = E + cmul(t3[j], O);
-              if (64 * (j + 1) <= p.kp || k < p.kp) rowa[k] = (xp.x * xp.x + xp.y * xp.y) * inv_scale;
+              // 2 E = Zk + conj Zn,  2 O = -i (Zk - conj Zn) = (zk.y + zn.y, -(zk.x - zn.x)); the 1/2's go into inv_scale
+              const cplx E2 = add_conj(zk, zn), Ot = swap_add_conj(zk, zn);  // Ot = (O2.x, -O2.y)
+              const cplx O2 = mk(Ot.x, -Ot.y);
+              cplx xp = E2 + cmul(t3[j], O2);
+              xp *= xp;
+              if (64 * (j + 1) <= p.kp || k < p.kp) rowa[k] = (xp.x + xp.y) * (0.25f * inv_scale);
             } else {
-              const float ar = zk.x + zn.x, ai = zk.y - zn.y, br = zk.y + zn.y, bi = zk.x - zn.x;
+              // 2 X1 = Zk + conj Zn,  2i X2 = Zk - conj Zn  (|.|^2 is what matters)
+              cplx xa = add_conj(zk, zn), xb = swap_add_conj(zk, zn);
+              xa *= xa;
+              xb *= xb;
               if (64 * (j + 1) <= p.kp || k < p.kp) {  // uniform for all but a ragged last step
-                rowa[k] = (ar * ar + ai * ai) * inv_scale;
-                rowb[k] = (br * br + bi * bi) * inv_scale;
+                rowa[k] = (xa.x + xa.y) * inv_scale;
+                rowb[k] = (xb.x + xb.y) * inv_scale;
               }
             }
           }
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
           float m = acc[t][r];
           m = m == 0.f ? EPS64 : m;  // feature.py:217
           const int filt = 16 * t + 4 * g + r;
-          if (p.out_kind != SVK_OUT_MFE) m = filt < p.nfilt ? logf(m) : 0.f;
+          if (p.out_kind != SVK_OUT_MFE) m = filt < p.nfilt ? __logf(m) : 0.f;
           acc[t][r] = m;
         }
       }
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         }
       } else {
         // ---- cepstra^T = DCT x log(mel)^T: acc[t][r] is already the B operand ------
-        const float le = logf(elds[jf & (TILE - 1)]);
+        const float le = __logf(elds[jf & (TILE - 1)]);
         for (int c = 0; c < p.n_ct; ++c) {  // runtime loop: keeps the table loads of one cepstral tile in flight, not four
           f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
           const float* dfrag = dct_lds + c * p.n_ft * 4 * 64 + lane;
