@@ -223,7 +223,8 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
   for (int i = threadIdx.x; i < p.n_ct * p.n_ft * 4 * 64; i += blockDim.x) dct_lds[i] = p.dctfrag[i];
   __syncthreads();  // the only workgroup-wide barrier; from here on waves never wait for each other
   // private to this wave
-  const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  // the wave index is uniform: say so, or every per-tile index computation lands on the VALU
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
   char* mine = smem + p.table_bytes + (size_t)wave * p.wave_bytes;
   float* sig = reinterpret_cast<float*>(mine);
   int16_t* sigh = reinterpret_cast<int16_t*>(mine);
@@ -244,10 +245,18 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
     for (int q = 0; q < 5; ++q) t3[q] = p.tw3[q * 64 + lane_id];
   }
   const float inv_scale = SPLIT1024 ? (1.0f / 1024.0f) : (1.0f / (4.0f * 512.0f));
-  const int64_t total = (int64_t)p.n_utt * p.tiles_per_utt;
-
-  // consecutive tiles go to the waves of one workgroup: neighbours share the overlapping PCM in L1
-  for (int64_t tile = (int64_t)blockIdx.x * n_waves + wave; tile < total; tile += (int64_t)gridDim.x * n_waves) {
+  // Consecutive tiles go to the waves of one workgroup (neighbours share the overlapping PCM in
+  // L1).  (clip, tile-in-clip) advance incrementally: one division here instead of a 64-bit
+  // divide + modulo per tile.
+  const int tpu = p.tiles_per_utt;
+  const int step = (int)gridDim.x * n_waves, step_utt = step / tpu, step_ft = step % tpu;
+  const int first = (int)blockIdx.x * n_waves + wave;
+  int utt = first / tpu, ft = first % tpu;
+  for (; utt < p.n_utt; utt += step_utt, ft += step_ft) {
+    if (ft >= tpu) {
+      ft -= tpu;
+      if (++utt >= p.n_utt) break;
+    }
     // An opaque per-tile copy of the lane id: without it the compiler hoists every lane-derived
     // address and predicate of the tile body out of this loop and pins ~40 VGPRs for the whole
     // kernel (172 -> 3 waves per SIMD become 2); recomputing them per tile is a few dozen VALU.
@@ -256,8 +265,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
     const int jf = lane & 15, g = lane >> 4;
     const int mirror = (64 - lane) & 63;
     const bool lane0 = lane == 0, lane63 = lane == 63;
-    const int utt = (int)(tile / p.tiles_per_utt);
-    const int f0 = (int)(tile % p.tiles_per_utt) * TILE;
+    const int f0 = ft * TILE;
     const int64_t off = p.offsets ? p.offsets[utt] : (int64_t)utt * p.clip_stride;
     const int len = p.lengths ? p.lengths[utt] : p.clip_len;
     const int T = len >= p.flen ? (len - p.flen) / p.stride : 0;  // processing.py:115-116 (Q3)
@@ -721,7 +729,8 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
 
   const int64_t total = (int64_t)n_utt * p.tiles_per_utt;
   // one workgroup of lds.waves waves per CU (it owns the CU's LDS); fewer when there is little work
-  const int waves = (int)std::max<int64_t>(1, std::min<int64_t>(lds.waves, (total + ctx->num_cu - 1) / ctx->num_cu));
+  int waves = (int)std::max<int64_t>(1, std::min<int64_t>(lds.waves, (total + ctx->num_cu - 1) / ctx->num_cu));
+  if (const char* env = getenv("SVK_FE_WAVES")) waves = std::max(1, std::min(waves, atoi(env)));  // tuning only
   const int64_t grid = std::min<int64_t>((total + waves - 1) / waves, ctx->num_cu);
   const size_t lds_total = (size_t)plan->table_bytes + (size_t)waves * lds.wave_bytes;
   const bool split = plan->cfg.nfft == 1024;
