@@ -126,19 +126,41 @@ __device__ __forceinline__ void stage_span(const FrontendParams& p, const PcmT* 
 __device__ __forceinline__ void stage_raw16(const FrontendParams& p, const int16_t* x, int64_t s0, int need, int len,
                                             int16_t* sigh, int lane) {
   typedef short vec_t __attribute__((ext_vector_type(8)));
-  const bool fast = (reinterpret_cast<uintptr_t>(x + s0) & 15) == 0;
-  for (int i = lane * 8; i < need; i += 64 * 8) {
-    const int64_t idx = s0 + i;
-    vec_t raw;
-    if (fast && idx + 8 <= len) {
-      raw = *reinterpret_cast<const vec_t*>(x + idx);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) raw[e] = idx + e < len ? x[idx + e] : (short)0;
-    }
-    *reinterpret_cast<vec_t*>(sigh + RAW_OFF + i) = raw;
-  }
+  constexpr int NV = 3;  // 16-byte loads in flight per lane: an 8-frame tile at a 160-sample hop is 3 x 512 samples
+  const bool fast = (reinterpret_cast<uintptr_t>(x + s0) & 15) == 0 && len - s0 >= 8;
   if (lane == 0 && p.preemph) sigh[RAW_OFF - 1] = s0 == 0 ? x[len - 1] : x[s0 - 1];
+  if (fast) {
+    for (int base = 0; base < need; base += NV * 512) {
+      vec_t raw[NV];
+      // all loads first (a load per loop trip followed by its own wait cost one HBM round trip EACH) ...
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int i = base + k * 512 + lane * 8;
+        const bool full = i < need && s0 + i + 8 <= len;
+        raw[k] = *reinterpret_cast<const vec_t*>(x + (full ? s0 + i : s0));  // clamped: always a valid aligned address
+      }
+      // ... then the LDS writes; a clip that ends inside a vector is patched sample by sample (rare)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int i = base + k * 512 + lane * 8;
+        if (i < need) {
+          vec_t v = raw[k];
+          if (s0 + i + 8 > len) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = s0 + i + e < len ? x[s0 + i + e] : (short)0;
+          }
+          *reinterpret_cast<vec_t*>(sigh + RAW_OFF + i) = v;
+        }
+      }
+    }
+  } else {
+    for (int i = lane * 8; i < need; i += 64 * 8) {
+      vec_t raw;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) raw[e] = s0 + i + e < len ? x[s0 + i + e] : (short)0;
+      *reinterpret_cast<vec_t*>(sigh + RAW_OFF + i) = raw;
+    }
+  }
 }
 
 // Wave sum with DPP moves only (no LDS crossbar): an inclusive scan inside each 16-lane row
@@ -266,8 +288,10 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
     const int mirror = (64 - lane) & 63;
     const bool lane0 = lane == 0, lane63 = lane == 63;
     const int f0 = ft * TILE;
-    const int64_t off = p.offsets ? p.offsets[utt] : (int64_t)utt * p.clip_stride;
-    const int len = p.lengths ? p.lengths[utt] : p.clip_len;
+    int64_t off = (int64_t)utt * p.clip_stride;  // utt is wave-uniform: these are scalar loads
+    if (p.offsets) off = p.offsets[utt];
+    int len = p.clip_len;
+    if (p.lengths) len = p.lengths[utt];
     const int T = len >= p.flen ? (len - p.flen) / p.stride : 0;  // processing.py:115-116 (Q3)
     if (f0 == 0 && lane0 && p.n_frames) p.n_frames[utt] = T < p.max_frames ? T : p.max_frames;
     int nvalid = T - f0;
