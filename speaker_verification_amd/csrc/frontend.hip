@@ -395,7 +395,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
       for (int t = 0; t < MAX_FT; ++t) {
         // two accumulators per filter tile: back-to-back MFMAs never wait on their own result
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-        if (t < p.n_ft) {
+        if (t < p.n_ft && !(p.ablate & 8)) {
           const f32x4* frag = fb_lds + (p.slot_base[t] - p.chunk_lo[t]) * 64 + lane;
           for (int u = p.chunk_lo[t]; u < p.chunk_hi[t]; u += 2) {
             const bool two = u + 1 < p.chunk_hi[t];
@@ -417,6 +417,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         }
         acc[t] = acc0 + acc1;
       }
+      if (p.ablate & 32) continue;
       // lane (jf, g) now holds mel[filter 16 t + 4 g + reg][frame jf]
       const bool row_ok = jf < nvalid;
       float* orow = out_rows + (int64_t)jf * p.ncols;
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
       } else {
         // ---- cepstra^T = DCT x log(mel)^T: acc[t][r] is already the B operand ------
         const float le = __logf(elds[jf & (TILE - 1)]);
-        for (int c = 0; c < p.n_ct; ++c) {  // runtime loop: keeps the table loads of one cepstral tile in flight, not four
+        for (int c = 0; c < ((p.ablate & 16) ? 0 : p.n_ct); ++c) {  // runtime loop: keeps the table loads of one cepstral tile in flight, not four
           f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
           const float* dfrag = dct_lds + c * p.n_ft * 4 * 64 + lane;
 #pragma unroll
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
     const int first_bad = nvalid > 0 ? nvalid : 0;
     int last = p.max_frames - f0;
     last = last > TILE ? TILE : last;
+    if (p.ablate & 64) continue;
     for (int i = first_bad * p.ncols + lane; i < last * p.ncols; i += 64) out_rows[i] = 0.f;
     if (p.energy)
       for (int i = first_bad + lane; i < last; i += 64) p.energy[(int64_t)utt * p.max_frames + f0 + i] = 0.f;
