@@ -36,10 +36,11 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     out_dir = os.path.join(REPO, "profiles")
     os.makedirs(out_dir, exist_ok=True)
-    stats = glob.glob(os.path.join(REPO, "gpurun_out", "prof_bench", "**", "*_kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(os.path.join(REPO, "gpurun_out", "prof_bench", "**", "*_kernel_stats.csv"), recursive=True),
+                   key=os.path.getmtime)
     if stats:
-        rows = list(csv.reader(open(stats[0])))
-        keep = [rows[0]] + [r for r in rows[1:] if float(r[4]) >= 0.05 or short(r[0])]
+        rows = list(csv.reader(open(stats[-1])))          # newest run
+        keep = [rows[0]] + [r for r in rows[1:] if float(r[4]) >= 0.2 or short(r[0])]
         for r in keep[1:]:
             if len(r[0]) > 160:
                 r[0] = r[0][:157] + "..."
@@ -49,7 +50,9 @@ def main():
     summary = defaultdict(lambda: defaultdict(list))
     meta = {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
-        for path in glob.glob(os.path.join(REPO, "gpurun_out", sub, "**", "*_counter_collection.csv"), recursive=True):
+        paths = sorted(glob.glob(os.path.join(REPO, "gpurun_out", sub, "**", "*_counter_collection.csv"),
+                                 recursive=True), key=os.path.getmtime)
+        for path in paths[-1:]:                             # newest run only
             for row in csv.DictReader(open(path)):
                 k = short(row["Kernel_Name"])
                 if not k:
