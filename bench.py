@@ -168,7 +168,19 @@ def main():
     use_dist = world > 1 or os.environ.get("SVK_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL with one rank
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on STDOUT when the communicator comes up; stdout is reserved
+        # for the one JSON line, so fd 1 points at stderr until the first collective has run.
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from speaker_verification_amd import constants as c, distributed as svdist, evaluation, synth
     from speaker_verification_amd.engine import get_engine
