@@ -126,6 +126,21 @@ int svk_spectrum(svk_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t 
 int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
              const int32_t* d_n_frames, int32_t variance);
 
+/* processing.py:274-327 (cmvnw, Q10) per clip: sliding window of `win` (odd) rows, 'symmetric'
+ * padding of (win-1)/2 rows; out = x - window mean; with variance != 0 a second pass divides by
+ * (population std of the window over the MEAN-SUBTRACTED rows, padded the same way, + 2^-30).
+ * d_in / d_out / d_tmp: [n_utt][max_frames][n_cols] float32, all distinct; d_tmp is only needed
+ * (and only written) when variance != 0.  Rows >= n_frames[u] are left untouched in d_out. */
+int svk_cmvnw(svk_ctx* ctx, const float* d_in, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+              const int32_t* d_n_frames, int32_t win, int32_t variance, float* d_tmp, float* d_out);
+/* processing.py:201-236 (derivative_extraction) exactly as the reference computes it, Q11 included:
+ * out[r][c] = sum_{k=1..delta} k * in[r][min(c + k, n_cols - 1)] / sum_{k} 2 k^2  (edge padding along
+ * the FEATURE axis; the subtraction on processing.py:232 is a detached statement). */
+int svk_derivative(svk_ctx* ctx, const float* d_in, int64_t n_rows, int32_t n_cols, int32_t delta, float* d_out);
+/* processing.py:177-198 (log_power_spectrum) on a power spectrum already on the device: in place
+ * p <- 10 log10(max(p, 1e-20)); normalize != 0 then subtracts the global maximum. */
+int svk_log_power(svk_ctx* ctx, float* d_power, int64_t n, int32_t normalize);
+
 /* ---- energy VAD ------------------------------------------------------------
  * vad.py:44-57 (framer, Q12) + vad.py:60-129 (ring-buffer hysteresis, Q13) with
  * the per-frame decision  sum(x^2) > threshold * frame_samples  (int64) in place of

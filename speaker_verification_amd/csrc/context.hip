@@ -22,11 +22,19 @@ int svk_create(int device_id, svk_ctx** out) {
   ctx->num_cu = prop.multiProcessorCount;
   ctx->clock_khz = prop.clockRate;
   ctx->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (hipMalloc(&ctx->scratch, 256) != hipSuccess) {
+    delete ctx;
+    return SVK_ERR_OOM;
+  }
   *out = ctx;
   return SVK_OK;
 }
 
-void svk_destroy(svk_ctx* ctx) { delete ctx; }
+void svk_destroy(svk_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  delete ctx;
+}
 
 const char* svk_last_error(const svk_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 

@@ -200,6 +200,87 @@ __global__ __launch_bounds__(256) void cmvn_kernel(float* __restrict__ feat, int
   }
 }
 
+// ---- sliding-window CMVN (cmvnw, Q10) ------------------------------------------------------
+// 'symmetric' padding = reflect INCLUDING the edge sample, repeated when the window is longer
+// than the clip: index k maps to m = k mod 2T, then m < T ? m : 2T - 1 - m.
+__device__ __forceinline__ int sym_index(int k, int T) {
+  int m = k % (2 * T);
+  if (m < 0) m += 2 * T;
+  return m < T ? m : 2 * T - 1 - m;
+}
+
+// pass 0: out = x - mean(window);  pass 1: out = src / (std(window of src) + 2^-30), src = pass-0 result
+__global__ __launch_bounds__(256) void cmvnw_kernel(const float* __restrict__ src, int max_frames, int ncols,
+                                                    const int32_t* __restrict__ n_frames, int win, int pass,
+                                                    float* __restrict__ dst) {
+  const int utt = blockIdx.y;
+  int T = n_frames ? n_frames[utt] : max_frames;
+  T = T < max_frames ? T : max_frames;
+  const int half = (win - 1) / 2;
+  const float* base = src + (int64_t)utt * max_frames * ncols;
+  float* out = dst + (int64_t)utt * max_frames * ncols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < T * ncols; i += gridDim.x * blockDim.x) {
+    const int r = i / ncols, c = i - r * ncols;
+    double s = 0.0, q = 0.0;
+    for (int k = r - half; k <= r + half; ++k) {
+      const double v = (double)base[(int64_t)sym_index(k, T) * ncols + c];
+      s += v;
+      q += v * v;
+    }
+    const double mean = s / (double)win;
+    if (pass == 0) {
+      out[i] = (float)((double)base[i] - mean);
+    } else {
+      double var = q / (double)win - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      out[i] = (float)((double)base[i] / (sqrt(var) + 9.313225746154785e-10));
+    }
+  }
+}
+
+// ---- 'derivative' features, bug-compatible (Q11) -------------------------------------------------
+__global__ __launch_bounds__(256) void derivative_kernel(const float* __restrict__ in, int64_t total, int ncols,
+                                                         int delta, float inv_scale, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ncols;
+    const int c = (int)(i - r * ncols);
+    const float* row = in + r * ncols;
+    float acc = 0.f;
+    for (int k = 1; k <= delta; ++k) acc += (float)k * row[min(c + k, ncols - 1)];
+    out[i] = acc * inv_scale;
+  }
+}
+
+// ---- log power spectrum ---------------------------------------------------------------------------
+// order-preserving float <-> uint map so that atomicMax on the integers is a max on the floats
+__device__ __forceinline__ unsigned flip(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unflip(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__global__ __launch_bounds__(256) void log_power_kernel(float* __restrict__ p, int64_t n, unsigned* __restrict__ gmax) {
+  float m = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = p[i];
+    v = v <= 1e-20f ? 1e-20f : v;            // processing.py:192
+    v = 10.0f * log10f(v);
+    p[i] = v;
+    m = fmaxf(m, v);
+  }
+  if (gmax) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(gmax, flip(m));
+  }
+}
+__global__ __launch_bounds__(256) void sub_max_kernel(float* __restrict__ p, int64_t n, const unsigned* __restrict__ gmax) {
+  const float m = unflip(*gmax);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] -= m;
+}
+
 // ---- feature cube: each crop is one contiguous run of crop_frames * ncols floats ---------------
 __global__ __launch_bounds__(256) void cube_gather_kernel(const float* __restrict__ feat, int max_frames, int ncols,
                                                           const int32_t* __restrict__ crop, int n_crops,
@@ -354,6 +435,57 @@ int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int
   hipLaunchKernelGGL(cmvn_kernel, dim3(n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols, d_n_frames,
                      variance);
   SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+int svk_cmvnw(svk_ctx* ctx, const float* d_in, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+              const int32_t* d_n_frames, int32_t win, int32_t variance, float* d_tmp, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 0 && n_cols >= 0, "negative shape");
+  SVK_REQUIRE(ctx, win >= 1 && (win & 1) == 1, "win must be odd");
+  if (n_utt == 0 || max_frames == 0 || n_cols == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_in && d_out && d_in != d_out, "NULL or aliased buffer");
+  SVK_REQUIRE(ctx, !variance || (d_tmp && d_tmp != d_in && d_tmp != d_out), "variance pass needs a distinct d_tmp");
+  const int64_t per = (int64_t)max_frames * n_cols;
+  const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((per + 255) / 256, ctx->num_cu * 4)), (unsigned)n_utt);
+  hipLaunchKernelGGL(cmvnw_kernel, grid, dim3(256), 0, ctx->stream, d_in, max_frames, n_cols, d_n_frames, win, 0,
+                     variance ? d_tmp : d_out);
+  SVK_LAUNCH_CHECK(ctx);
+  if (variance) {
+    hipLaunchKernelGGL(cmvnw_kernel, grid, dim3(256), 0, ctx->stream, d_tmp, max_frames, n_cols, d_n_frames, win, 1,
+                       d_out);
+    SVK_LAUNCH_CHECK(ctx);
+  }
+  return SVK_OK;
+}
+
+int svk_derivative(svk_ctx* ctx, const float* d_in, int64_t n_rows, int32_t n_cols, int32_t delta, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_rows >= 0 && n_cols >= 0 && delta >= 1, "shape / delta");
+  const int64_t total = n_rows * n_cols;
+  if (total == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_in && d_out && d_in != d_out, "NULL or aliased buffer");
+  double scale = 0.0;
+  for (int k = 1; k <= delta; ++k) scale += 2.0 * k * k;  // processing.py:233
+  hipLaunchKernelGGL(derivative_kernel, dim3(capped_grid(ctx, total, 256)), dim3(256), 0, ctx->stream, d_in, total,
+                     n_cols, delta, (float)(1.0 / scale), d_out);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+int svk_log_power(svk_ctx* ctx, float* d_power, int64_t n, int32_t normalize) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n >= 0, "n negative");
+  if (n == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_power, "NULL buffer");
+  unsigned* gmax = normalize ? reinterpret_cast<unsigned*>(ctx->scratch) : nullptr;
+  if (gmax) SVK_HIP(ctx, hipMemsetAsync(gmax, 0, sizeof(unsigned), ctx->stream));  // flip() of anything is > 0
+  hipLaunchKernelGGL(log_power_kernel, dim3(capped_grid(ctx, n, 256)), dim3(256), 0, ctx->stream, d_power, n, gmax);
+  SVK_LAUNCH_CHECK(ctx);
+  if (gmax) {
+    hipLaunchKernelGGL(sub_max_kernel, dim3(capped_grid(ctx, n, 256)), dim3(256), 0, ctx->stream, d_power, n, gmax);
+    SVK_LAUNCH_CHECK(ctx);
+  }
   return SVK_OK;
 }
 

@@ -14,6 +14,7 @@ struct svk_ctx {
   int num_cu = 256;
   int clock_khz = 0;
   int lds_per_cu = 160 * 1024;
+  void* scratch = nullptr;  // 256 bytes of device memory for tiny reductions (svk_log_power)
   char err[512] = {0};
 };
 

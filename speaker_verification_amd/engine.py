@@ -221,6 +221,34 @@ class Engine:
                                 int(bool(variance))), self.ctx)
         return feat
 
+    def cmvnw(self, feat, win_size=301, variance=False, n_frames=None):
+        """Sliding-window CMVN of feat [n_utt, max_frames, cols] (or [rows, cols]); returns a new tensor."""
+        torch = _torch()
+        x = self.to_device(feat, torch.float32)
+        shape = x.shape if x.dim() == 3 else (1,) + tuple(x.shape)
+        nf = self.to_device(n_frames, torch.int32) if n_frames is not None else None
+        out = x.clone()                         # rows past n_frames keep the input
+        tmp = torch.empty_like(x) if variance else None
+        self._stream()
+        check(self.lib.svk_cmvnw(self.ctx, self._ptr(x), shape[0], shape[1], shape[2], self._ptr(nf), int(win_size),
+                                 int(bool(variance)), self._ptr(tmp), self._ptr(out)), self.ctx)
+        return out
+
+    def derivative(self, feat, delta):
+        torch = _torch()
+        x = self.to_device(feat, torch.float32)
+        out = torch.empty_like(x)
+        self._stream()
+        check(self.lib.svk_derivative(self.ctx, self._ptr(x), x.numel() // x.shape[-1], x.shape[-1], int(delta),
+                                      self._ptr(out)), self.ctx)
+        return out
+
+    def log_power_(self, power, normalize=True):
+        """In place: 10 log10(max(p, 1e-20)) [- global max]."""
+        self._stream()
+        check(self.lib.svk_log_power(self.ctx, self._ptr(power), power.numel(), int(bool(normalize))), self.ctx)
+        return power
+
     def vad_energy(self, pcm, threshold, fs=16000, frame_ms=30, padding_ms=300, lengths=None, compact=True,
                    want_segments=False, frame_samples=None, ring_len=None):
         """pcm [n_utt, L] int16 -> dict(keep [n, F] u8, n_vad_frames [n] i32, voiced [n, L] i16,

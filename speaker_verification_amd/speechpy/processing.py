@@ -74,29 +74,18 @@ def power_spectrum(frames, fft_points=512):
 def log_power_spectrum(frames, fft_points=512, normalize=True):
     """10 log10 of the power spectrum floored at 1e-20; with `normalize` the
     global maximum is shifted to 0 dB (processing.py:177-198)."""
-    import torch
-    p = get_engine().spectrum(np.asarray(frames), fft_points, power=True)
-    lp = 10.0 * torch.log10(torch.clamp(p, min=1e-20))
-    if normalize and lp.numel():
-        lp = lp - lp.max()
-    return _host(lp)
+    eng = get_engine()
+    p = eng.spectrum(np.asarray(frames), fft_points, power=True)
+    return _host(eng.log_power_(p, normalize=normalize))
 
 
 def derivative_extraction(feat, DeltaWindows):
     """Derivative features exactly as the reference computes them, bug included
     (Q11, processing.py:201-236): edge-pad DeltaWindows columns on both sides of
     the FEATURE axis; DIF = sum_r r * FEAT[:, D + r : D + r + cols]; / sum_r 2 r^2."""
-    import torch
-    eng = get_engine()
-    x = eng.to_device(np.asarray(feat), torch.float32)
-    rows, cols = x.shape
-    padded = torch.nn.functional.pad(x[None], (DeltaWindows, DeltaWindows), mode="replicate")[0]
-    dif = torch.zeros_like(x)
-    scale = 0
-    for r in range(1, DeltaWindows + 1):
-        dif += r * padded[:, DeltaWindows + r:DeltaWindows + r + cols]
-        scale += 2 * r * r
-    return _host(dif / scale)
+    feat = np.asarray(feat)
+    rows, cols = feat.shape
+    return _host(get_engine().derivative(feat, DeltaWindows))
 
 
 def cmvn(vec, variance_normalization=False):
@@ -115,29 +104,9 @@ def cmvnw(vec, win_size=301, variance_normalization=False):
     """Sliding-window CMVN, float32 output (Q10, processing.py:274-327):
     'symmetric' padding of (win_size - 1) / 2 rows, window mean removed; the
     variance pass windows over the mean-subtracted array padded the same way."""
-    import torch
-    eps = 2 ** -30
     vec = np.asarray(vec)
     rows, cols = vec.shape
     assert isinstance(win_size, int), "Size must be of type 'int'!"
     assert win_size % 2 == 1, "Windows size must be odd!"
-    eng = get_engine()
-    pad = int((win_size - 1) / 2)
-
-    def sym_pad(t):
-        idx = np.pad(np.arange(t.shape[0]), (pad, pad), 'symmetric')
-        return t[torch.from_numpy(idx).to(t.device)]
-
-    def window_sum(t):                          # (rows + 2 pad, cols) -> (rows, cols) sums over win_size rows
-        c = torch.cumsum(torch.cat([torch.zeros_like(t[:1]), t]), dim=0)
-        return c[win_size:] - c[:-win_size]
-
-    x = eng.to_device(vec, torch.float64)
-    centred = (x - window_sum(sym_pad(x)) / win_size).to(torch.float32)
-    if not variance_normalization:
-        return _host(centred, np.float32)
-    p = sym_pad(centred.to(torch.float64))
-    mean = window_sum(p) / win_size
-    var = torch.clamp(window_sum(p * p) / win_size - mean * mean, min=0.0)
-    out = (centred.to(torch.float64) / (torch.sqrt(var) + eps)).to(torch.float32)
+    out = get_engine().cmvnw(vec, win_size=win_size, variance=variance_normalization)
     return _host(out, np.float32)

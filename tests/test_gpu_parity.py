@@ -223,6 +223,27 @@ def test_postprocessing(sp, golden):
         sp.processing.cmvnw(base, win_size=300)
 
 
+def test_cmvnw_derivative_batched(eng):
+    rng = np.random.default_rng(4)
+    feat = (rng.standard_normal((3, 120, 13)) * 2 + 0.5).astype(np.float32)
+    nf = np.array([120, 37, 5], dtype=np.int32)
+    for win, var in ((31, True), (301, False), (9, True)):
+        got = eng.cmvnw(feat, win_size=win, variance=var, n_frames=nf).cpu().numpy()
+        for i, n in enumerate(nf):
+            want = ref.cmvnw(feat[i, :n].astype(np.float64), win_size=win, variance_normalization=var)
+            np.testing.assert_allclose(got[i, :n], want, rtol=1e-4, atol=1e-4)
+            np.testing.assert_array_equal(got[i, n:], feat[i, n:])
+    d = eng.derivative(feat, 2).cpu().numpy()
+    for i in range(3):
+        np.testing.assert_allclose(d[i], ref.derivative_extraction(feat[i].astype(np.float64), 2), rtol=1e-5, atol=1e-5)
+    power = np.abs(rng.standard_normal((7, 257))).astype(np.float32) ** 2
+    power[0, :3] = 0.0
+    lp = eng.log_power_(eng.to_device(power).clone(), normalize=True).cpu().numpy()
+    want = 10 * np.log10(np.maximum(power.astype(np.float64), 1e-20))
+    np.testing.assert_allclose(lp, want - want.max(), rtol=0, atol=2e-4)
+    assert lp.max() == 0.0
+
+
 def test_cmvn_batched_ragged(eng):
     rng = np.random.default_rng(3)
     feat = rng.standard_normal((5, 60, 13)).astype(np.float32) * 3 + 1
