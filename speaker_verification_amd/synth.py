@@ -86,10 +86,10 @@ def corpus_device(n_clips, device, first_clip=0, utts_per_speaker=123, n_samples
     syllable modulation, noise floor) but synthesised with torch on the GPU, so the bytes are
     NOT those of `speaker_clip`; parity checks copy the clips they need back to the host.
     Clip g (global index first_clip + row) belongs to speaker g // utts_per_speaker and its
-    parameters depend only on (seed, g).  Unlike `speaker_clip`, every formant also carries a
-    speaker-specific amplitude-modulation rate and depth: per-clip CMVN removes a speaker's static
-    spectral envelope, so without speaker-specific DYNAMICS the normalised features carry no
-    speaker information at all and every scorer sits at EER 0.5."""
+    parameters depend only on (seed, g).  Unlike `speaker_clip`, the formants of a speaker swell in
+    a speaker-specific +-1 pattern: per-clip CMVN removes a speaker's static spectral envelope, so
+    without speaker-specific DYNAMICS the normalised features carry no speaker information at all
+    and every scorer sits at EER 0.5."""
     import torch
     out = torch.empty((n_clips, n_samples), dtype=torch.int16, device=device)
     gids = np.arange(first_clip, first_clip + n_clips)
@@ -125,15 +125,20 @@ def corpus_device(n_clips, device, first_clip=0, utts_per_speaker=123, n_samples
         f_d, a_d, ph_d = (torch.from_numpy(x).to(device) for x in (f, a, ph))
         st_d, sp_d, syl_d = (torch.from_numpy(x).to(device) for x in (start, stop, syl))
         voice = torch.zeros((m, n_samples), device=device)
-        am_r = np.zeros((m, K), dtype=np.float32)
-        am_d = np.zeros((m, K), dtype=np.float32)
+        # speaker identity that survives per-clip CMVN: WHICH formants swell together and which in
+        # opposition (a +-1 pattern per speaker) under one slow per-clip envelope; the pattern shows
+        # up as the sign of band-to-band correlations, whatever the timing of the clip
+        sign = np.zeros((m, K), dtype=np.float32)
+        env = np.zeros((m, 2), dtype=np.float32)
         for r in range(m):
             srng = np.random.default_rng(5000 + int(speakers[lo + r]))        # per SPEAKER
-            am_r[r] = srng.uniform(1.5, 9.0, K)
-            am_d[r] = srng.uniform(0.3, 0.9, K)
-        amr_d, amd_d = torch.from_numpy(am_r).to(device), torch.from_numpy(am_d).to(device)
+            sign[r] = srng.choice([-1.0, 1.0], K)
+            crng = np.random.default_rng([seed + 1, int(gids[lo + r])])       # per clip
+            env[r] = (crng.uniform(2.0, 4.0), crng.uniform(0, 2 * np.pi))
+        sign_d, env_d = torch.from_numpy(sign).to(device), torch.from_numpy(env).to(device)
+        swell = torch.sin(2 * np.pi * env_d[:, 0:1] * t[None, :] + env_d[:, 1:2])
         for k in range(K):
-            am = 1.0 + amd_d[:, k:k + 1] * torch.sin(2 * np.pi * amr_d[:, k:k + 1] * t[None, :] + 3.0 * ph_d[:, k:k + 1])
+            am = 1.0 + 0.8 * sign_d[:, k:k + 1] * swell
             voice += a_d[:, k:k + 1] * am * torch.sin(2 * np.pi * f_d[:, k:k + 1] * t[None, :] + ph_d[:, k:k + 1])
         voice *= 3000.0 / torch.sqrt((a_d * a_d).sum(1, keepdim=True) / 2.0).clamp_min(1e-6)
         gate = torch.zeros((m, n_samples), device=device)
