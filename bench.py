@@ -294,6 +294,18 @@ def main():
         }
 
     if rank == 0 and world == 1:
+        # host-fed variant (PCIe included; NOT `value`): 4 micro-batches of the shard from pageable host memory
+        n_host = min(n_local, 4 * pipe.chunks(n_local)[0][1])
+        host_pcm = pcm[:n_host].cpu().numpy()
+        pipe.embed_host(host_pcm)
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
+        emb_h = pipe.embed_host(host_pcm)
+        torch.cuda.synchronize()
+        t_h = time.perf_counter() - t_h
+        result["host_fed"] = {"utt_per_s": n_host / t_h, "clips": n_host,
+                              "max_abs_diff_vs_resident": float((emb_h - full[:n_host]).abs().max().item()),
+                              "note": "int16 NumPy -> pinned double buffer -> copy stream -> same kernels"}
         result["frontend_A"] = frontend_A_bench(eng, torch)
         if args.cpu_sample > 0:
             ns = min(args.cpu_sample, n_local)

@@ -127,6 +127,51 @@ class VerificationPipeline:
                               "n_frames": n_frames, "crop_idx": idx, "cube": cube})
         return (emb, inter) if return_intermediates else emb
 
+    def embed_host(self, pcm_host, first_utt=0):
+        """Host-fed variant of `embed`: `pcm_host` is a [n, L] int16 NumPy array (e.g. decoded WAVs).
+        Micro-batches go through two pinned staging buffers and a copy stream, so the H2D copy of
+        batch k+1 overlaps the kernels of batch k (96 kB per 3 s clip over PCIe)."""
+        if self.crop_rng != "device":
+            raise ValueError("embed_host overlaps copies with compute and needs crop_rng='device'")
+        n, L = pcm_host.shape
+        dev = self.eng.device
+        spans = self.chunks(n)
+        size = max(hi - lo for lo, hi in spans)
+        pinned = [torch.empty((size, L), dtype=torch.int16).pin_memory() for _ in range(2)]
+        staged = [torch.empty((size, L), dtype=torch.int16, device=dev) for _ in range(2)]
+        copied = [torch.cuda.Event() for _ in range(2)]
+        consumed = [torch.cuda.Event() for _ in range(2)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        emb = torch.empty((n, 128), dtype=torch.float32, device=dev)
+
+        def launch_copy(k):
+            lo, hi = spans[k]
+            slot = k & 1
+            if k >= 2:
+                consumed[slot].synchronize()           # host: the pinned buffer may be refilled
+            pinned[slot][:hi - lo].copy_(torch.from_numpy(pcm_host[lo:hi]))
+            with torch.cuda.stream(copy_stream):
+                if k >= 2:
+                    copy_stream.wait_event(consumed[slot])
+                staged[slot][:hi - lo].copy_(pinned[slot][:hi - lo], non_blocking=True)
+                copied[slot].record(copy_stream)
+
+        launch_copy(0)
+        for k, (lo, hi) in enumerate(spans):
+            if k + 1 < len(spans):
+                launch_copy(k + 1)
+            slot = k & 1
+            main.wait_event(copied[slot])
+            chunk = staged[slot][:hi - lo]
+            voiced, vlen = self.voiced(chunk)
+            feat, n_frames = self.features(voiced, vlen)
+            idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo,
+                                      self.bad_clips)
+            emb[lo:hi] = self.embed_cubes(self.cubes(feat, idx))
+            consumed[slot].record(main)
+        return emb
+
     def score(self, test_emb, enroll_emb):
         return self.eng.cosine_scores(test_emb, enroll_emb)
 

@@ -451,6 +451,11 @@ def test_pipeline_end_to_end_and_eer(eng):
     eer_ref, auc_ref, _, _ = scoring_ref.get_eer_auc(labels.flatten(), ref_scores.astype(np.float64).flatten())
     assert eer_gpu == pytest.approx(eer_ref, abs=1e-4)                          # EER parity
     assert auc_gpu == pytest.approx(auc_ref, abs=1e-4)
+    # host-fed path (pinned double buffer + copy stream) == resident path, bit for bit
+    pipe_dev = VerificationPipeline(pipe.model, use_vad=True, micro_batch=7, crop_rng="device")
+    a = pipe_dev.embed(pcm)
+    b = pipe_dev.embed_host(pcm)
+    assert torch.equal(a, b)
     # device-side crop draw: in range, reproducible, keyed by the global clip index
     nf_dev = eng.to_device(nfr.astype(np.int32))
     d1 = eng.draw_crops(nf_dev, 20, 80, seed=7, first_utt=100).cpu().numpy()
