@@ -159,8 +159,6 @@ class VerificationPipeline:
 
         launch_copy(0)
         for k, (lo, hi) in enumerate(spans):
-            if k + 1 < len(spans):
-                launch_copy(k + 1)
             slot = k & 1
             main.wait_event(copied[slot])
             chunk = staged[slot][:hi - lo]
@@ -170,6 +168,8 @@ class VerificationPipeline:
                                       self.bad_clips)
             emb[lo:hi] = self.embed_cubes(self.cubes(feat, idx))
             consumed[slot].record(main)
+            if k + 1 < len(spans):
+                launch_copy(k + 1)      # the host-side staging copy runs while the GPU works on batch k
         return emb
 
     def score(self, test_emb, enroll_emb):
