@@ -334,6 +334,80 @@ def test_cube_gather(eng, golden):
         np.testing.assert_array_equal(cube[u], model_ref.feature_cube(feats[u], idx[u]))
 
 
+def test_utils_transforms(eng, golden, monkeypatch):
+    """utils.FeatureCube / CMVN / ToTensor with the reference's sample-dict protocol and RNG."""
+    from speaker_verification_amd import constants, utils
+    g = golden["c3d2_embed"]
+    feat = np.random.default_rng(int(g["cube_feat_seed"][0])).standard_normal((297, 40))
+    np.random.seed(int(g["cube_np_seed"][0]))
+    out = utils.FeatureCube((80, 40, 20))({"feature": feat, "label": 5})
+    assert out["label"] == 5 and out["feature"].dtype == np.float32
+    np.testing.assert_array_equal(out["feature"], g["cube_out"])          # the reference's own FeatureCube output
+    assert utils.ToTensor()(out)[1] == 5
+    same = utils.CMVN()({"feature": feat, "label": 1})                    # shipped constants: identity (Q16)
+    assert same["feature"] is feat
+    monkeypatch.setattr(constants, "NORMALIZE", True)
+    normed = utils.CMVN()({"feature": feat, "label": 1})["feature"]
+    np.testing.assert_allclose(normed, ref.cmvn(feat, True), rtol=1e-4, atol=1e-5)
+    monkeypatch.setattr(constants, "DERIVATIVE", True)
+    stacked = utils.CMVN()({"feature": feat, "label": 1})["feature"]
+    want = ref.extract_derivative_feature(feat)
+    for ch in range(3):
+        np.testing.assert_allclose(stacked[:, :, ch], ref.cmvn(want[:, :, ch], True), rtol=1e-3, atol=1e-4)
+    np.random.seed(3)
+    cube3 = utils.FeatureCube3C((80, 40, 20, 3))({"feature": want, "label": 2})["feature"]
+    np.random.seed(3)
+    idx = np.random.randint(297 - 80, size=20)
+    assert cube3.shape == (3, 20, 80, 40)
+    for u in (0, 7, 19):
+        np.testing.assert_array_equal(cube3[:, u], want.transpose(2, 0, 1)[:, idx[u]:idx[u] + 80].astype(np.float32))
+
+
+def test_error_paths(eng):
+    """Unsupported configurations fail loudly with the library's message; nothing falls back."""
+    from speaker_verification_amd._lib import SvkError
+    from speaker_verification_amd.speechpy import feature, processing
+    sig = synth.noise_clip(1, 4000)
+    with pytest.raises(SvkError, match="fft_length 512 or 1024"):
+        feature.mfcc(sig, 16000, fft_length=256)
+    with pytest.raises(SvkError, match="filters"):
+        feature.mfcc(sig, 16000, num_filters=80)
+    with pytest.raises(AssertionError):
+        feature.mfcc(sig, 16000, high_frequency=9000)                     # feature.py:58
+    with pytest.raises(AssertionError):
+        processing.stack_frames(np.zeros((4, 4)), 16000)                  # processing.py:90
+    with pytest.raises(SvkError, match="VAD frames"):
+        eng.vad_energy(np.zeros((1, 480 * 9000), dtype=np.int16), 1000)
+    with pytest.raises(TypeError):
+        eng.vad_energy(np.zeros((1, 4800), dtype=np.float32), 1000)
+
+
+def test_concatenated_ragged_offsets(eng):
+    """The `d_offsets` form of the C-ABI: clips of different lengths back to back in one buffer."""
+    from speaker_verification_amd import _lib
+    from speaker_verification_amd.engine import spec_from_seconds
+    lens = np.array([16000, 5000, 48000, 801], dtype=np.int32)
+    pad = [(-n) % 8 for n in lens]                                        # keep 16-byte alignment of each clip
+    offs, chunks, pos = [], [], 0
+    for i, n in enumerate(lens):
+        offs.append(pos)
+        chunks.append(synth.noise_clip(50 + i, int(n)))
+        chunks.append(np.zeros(pad[i], dtype=np.int16))
+        pos += int(n) + pad[i]
+    buf = np.concatenate(chunks)
+    spec = spec_from_seconds(16000, 0.020, 0.01, 512, 40, 13, _lib.OUT_MFCC)
+    feat, nf, _ = eng.features(buf, spec, lengths=lens, offsets=np.array(offs, dtype=np.int64))
+    feat, nf = feat.cpu().numpy(), nf.cpu().numpy()
+    # one clip deliberately left unaligned exercises the scalar staging path
+    buf2 = np.concatenate([np.zeros(3, dtype=np.int16), chunks[0]])
+    f2, _, _ = eng.features(buf2, spec, lengths=lens[:1], offsets=np.array([3], dtype=np.int64))
+    for i, n in enumerate(lens):
+        want = ref.mfcc(buf[offs[i]:offs[i] + n], 16000)
+        assert nf[i] == want.shape[0]
+        np.testing.assert_allclose(feat[i, :nf[i]], want, **FEAT_TOL)
+    np.testing.assert_allclose(f2[0].cpu().numpy(), ref.mfcc(chunks[0], 16000), **FEAT_TOL)
+
+
 def test_c3d2_embedding_on_gpu(eng, golden):
     from speaker_verification_amd.model import perturb_inference_state, seeded_model
     g = golden["c3d2_embed"]
