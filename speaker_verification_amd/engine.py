@@ -99,7 +99,10 @@ class Engine:
         if isinstance(x, torch.Tensor):
             t = x.to(self.device)
         else:
-            t = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+            x = np.ascontiguousarray(x)
+            if not x.flags.writeable:            # e.g. np.frombuffer views: torch wants a writable array
+                x = x.copy()
+            t = torch.from_numpy(x).to(self.device)
         if dtype is not None and t.dtype != dtype:
             t = t.to(dtype)
         return t.contiguous()

@@ -168,3 +168,27 @@ def perturb_inference_state(state_dict, seed):
         elif "PReLu" in key:
             t.copy_(0.1 + 0.3 * torch.rand(t.shape, generator=gen))
     return state_dict
+
+
+def create_speaker_models(model, cubes, speaker_ids, save_dir=None, batch=256):
+    """Enrolment as `/root/reference/model.py:351-388` does it, on in-memory data (the
+    reference's checkpoint, id lists and WAVs do not ship): every utterance cube is embedded
+    with `development=False`; the speaker model is the embedding of that speaker's LAST listed
+    utterance -- the reference overwrites `{speaker_id}.pt` on each utterance, no averaging
+    (Q17).  Returns `{speaker_id: (1, 128) CPU tensor}` and, with `save_dir`, writes the
+    reference's `{speaker_id}.pt` files (readable by `evaluation.Evaluation`)."""
+    import os
+    device = next(model.parameters()).device
+    model.eval()
+    store = {}
+    with torch.no_grad():
+        for lo in range(0, len(cubes), batch):
+            x = torch.as_tensor(cubes[lo:lo + batch], dtype=torch.float32).to(device)
+            emb = model(x, development=False).cpu()
+            for k in range(emb.shape[0]):
+                store[str(speaker_ids[lo + k])] = emb[k:k + 1].clone()
+    if save_dir is not None:
+        os.makedirs(save_dir, exist_ok=True)
+        for sid, vec in store.items():
+            torch.save(vec, os.path.join(save_dir, f"{sid}.pt"))
+    return store

@@ -464,6 +464,27 @@ def test_evaluation_dropin(eng, golden):
     assert eer2 == float(g["big_eer"][0]) and auc2 == float(g["big_auc"][0])
 
 
+def test_enrolment_store_roundtrip(eng, tmp_path):
+    """model.create_speaker_models -> {id}.pt files -> evaluation.Evaluation, like the reference's
+    enrol-then-evaluate flow (model.py:351-388, evaluation.py:55-65)."""
+    from speaker_verification_amd import evaluation
+    from speaker_verification_amd.model import create_speaker_models, seeded_model
+    model = seeded_model(5, n_labels=8).to(eng.device)
+    cubes = np.random.default_rng(6).standard_normal((6, 1, 20, 80, 40)).astype(np.float32)
+    ids = ["id10001", "id10002", "id10001", "id10003", "id10002", "id10001"]
+    store = create_speaker_models(model, cubes, ids, save_dir=str(tmp_path))
+    assert sorted(store) == ["id10001", "id10002", "id10003"]
+    with torch.no_grad():
+        emb = model(torch.from_numpy(cubes).to(eng.device), development=False).cpu()
+    assert torch.equal(store["id10001"], emb[5:6]) and torch.equal(store["id10002"], emb[4:5])   # last one wins (Q17)
+    ev = evaluation.Evaluation(model, str(tmp_path))
+    assert list(ev.speaker_models) == ["id10001", "id10002", "id10003"]
+    sims, assigned = ev.compute_Similarity(torch.from_numpy(cubes[3:4]))
+    assert np.argmax(sims) == 2 and sims[2] == pytest.approx(1.0, abs=1e-5) and assigned[2] == 1
+    out = evaluation.evaluate(model, cubes, ids, str(tmp_path), plot_path=None)
+    assert out["scores"].shape == (6, 3) and 0.0 <= out["eer"] <= 1.0 and out["accuracy"] >= 50.0
+
+
 def test_siamese(eng, golden):
     from speaker_verification_amd.siamese import Siamese
     g = golden["scoring"]
