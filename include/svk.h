@@ -126,6 +126,14 @@ int svk_spectrum(svk_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t 
 int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
              const int32_t* d_n_frames, int32_t variance);
 
+/* feature.py:202-217 and :146-153 on a power spectrum that is already on the device -- the general
+ * (any fft_length, up to 1024 filters) counterpart of the fused front end, one workgroup per frame:
+ * energy = sum of all bins (0 -> eps), mel = power x bank^T (0 -> eps), then by out_kind nothing /
+ * log / log + DCT-II ortho (+ c0 := log energy).  d_bank [num_filters][n_bins] float32.
+ * d_feat [n_frames][cols], cols = num_filters or num_ceps; d_energy [n_frames] or NULL. */
+int svk_mel_features(svk_ctx* ctx, const float* d_power, int32_t n_frames, int32_t n_bins, const float* d_bank,
+                     int32_t num_filters, int32_t out_kind, int32_t num_ceps, int32_t dc_elimination,
+                     float* d_feat, float* d_energy);
 /* processing.py:274-327 (cmvnw, Q10) per clip: sliding window of `win` (odd) rows, 'symmetric'
  * padding of (win-1)/2 rows; out = x - window mean; with variance != 0 a second pass divides by
  * (population std of the window over the MEAN-SUBTRACTED rows, padded the same way, + 2^-30).

@@ -60,6 +60,7 @@ SIGNATURES = {
     "svk_stack_frames": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "svk_spectrum": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "svk_cmvn": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32]),
+    "svk_mel_features": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "svk_cmvnw": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "svk_derivative": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "svk_log_power": (C.c_int, [_vp, _vp, _i64, _i32]),

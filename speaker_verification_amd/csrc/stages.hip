@@ -200,6 +200,49 @@ __global__ __launch_bounds__(256) void cmvn_kernel(float* __restrict__ feat, int
   }
 }
 
+// ---- general mel / log / DCT stage (any fft length): one workgroup per frame, one thread per filter ----
+__global__ __launch_bounds__(1024) void mel_features_kernel(const float* __restrict__ power, int nbins,
+                                                            const float* __restrict__ bank, int nf, int out_kind,
+                                                            int ncep, int dc_elim, float* __restrict__ feat,
+                                                            float* __restrict__ energy) {
+  extern __shared__ float lmel[];  // [nf] (log) mel energies of this frame, then [blockDim/64] partial sums
+  float* part = lmel + nf;
+  const int t = blockIdx.x, i = threadIdx.x;
+  const float* p = power + (int64_t)t * nbins;
+  const float EPS = 2.220446049250313e-16f;
+  float e = 0.f;
+  for (int k = i; k < nbins; k += blockDim.x) e += p[k];
+  e = wave_sum(e);
+  if ((i & 63) == 0) part[i >> 6] = e;
+  float m = 0.f;
+  if (i < nf) {
+    const float* w = bank + (int64_t)i * nbins;
+    for (int k = 0; k < nbins; ++k) m = fmaf(p[k], w[k], m);
+    m = m == 0.f ? EPS : m;                       // feature.py:217
+    lmel[i] = out_kind == SVK_OUT_MFE ? m : logf(m);
+  }
+  __syncthreads();
+  float etot = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) etot += part[w];
+  etot = etot == 0.f ? EPS : etot;                // feature.py:205
+  if (i == 0 && energy) energy[t] = etot;
+  const int cols = out_kind == SVK_OUT_MFCC ? ncep : nf;
+  if (i < cols) {
+    float v;
+    if (out_kind != SVK_OUT_MFCC) {
+      v = lmel[i];
+    } else if (i == 0 && dc_elim) {
+      v = logf(etot);                             // feature.py:151-152
+    } else {
+      // scipy.fftpack.dct(type=2, norm='ortho'): sqrt(2/N) sum_n x_n cos(pi k (2n+1) / 2N), k = 0: sqrt(1/N)
+      double acc = 0.0;
+      for (int n = 0; n < nf; ++n) acc += (double)lmel[n] * cospi((double)i * (2.0 * n + 1.0) / (2.0 * nf));
+      v = (float)(acc * (i == 0 ? sqrt(1.0 / nf) : sqrt(2.0 / nf)));
+    }
+    feat[(int64_t)t * cols + i] = v;
+  }
+}
+
 // ---- sliding-window CMVN (cmvnw, Q10) ------------------------------------------------------
 // 'symmetric' padding = reflect INCLUDING the edge sample, repeated when the window is longer
 // than the clip: index k maps to m = k mod 2T, then m < T ? m : 2T - 1 - m.
@@ -434,6 +477,24 @@ int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int
   SVK_REQUIRE(ctx, d_feat, "NULL buffer");
   hipLaunchKernelGGL(cmvn_kernel, dim3(n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols, d_n_frames,
                      variance);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+int svk_mel_features(svk_ctx* ctx, const float* d_power, int32_t n_frames, int32_t n_bins, const float* d_bank,
+                     int32_t num_filters, int32_t out_kind, int32_t num_ceps, int32_t dc_elimination, float* d_feat,
+                     float* d_energy) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_frames >= 0 && n_bins >= 1 && num_filters >= 1, "shape");
+  SVK_REQUIRE(ctx, out_kind >= SVK_OUT_MFE && out_kind <= SVK_OUT_MFCC, "out_kind");
+  if (num_filters > 1024) return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "at most 1024 filters, got %d", num_filters);
+  if (out_kind == SVK_OUT_MFCC) SVK_REQUIRE(ctx, num_ceps >= 1 && num_ceps <= num_filters, "1 <= num_ceps <= num_filters");
+  if (n_frames == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_power && d_bank && d_feat, "NULL buffer");
+  const int threads = ((num_filters + 63) / 64) * 64;
+  const size_t lds = sizeof(float) * (size_t)(num_filters + threads / 64);
+  hipLaunchKernelGGL(mel_features_kernel, dim3(n_frames), dim3(threads), lds, ctx->stream, d_power, n_bins, d_bank,
+                     num_filters, out_kind, num_ceps, dc_elimination, d_feat, d_energy);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }

@@ -224,6 +224,22 @@ class Engine:
                                 int(bool(variance))), self.ctx)
         return feat
 
+    def mel_features(self, power, bank, out_kind, num_ceps=13, dc_elimination=True, want_energy=False):
+        """General mel / log / DCT stage on a device power spectrum [T, bins] (any fft length)."""
+        torch = _torch()
+        p = self.to_device(power, torch.float32)
+        b = self.to_device(bank, torch.float32)
+        T, bins = p.shape
+        nf = b.shape[0]
+        cols = num_ceps if out_kind == _lib.OUT_MFCC else nf
+        feat = torch.empty((T, cols), dtype=torch.float32, device=self.device)
+        energy = torch.empty((T,), dtype=torch.float32, device=self.device) if want_energy else None
+        self._stream()
+        check(self.lib.svk_mel_features(self.ctx, self._ptr(p), T, bins, self._ptr(b), nf, int(out_kind),
+                                        int(num_ceps), int(bool(dc_elimination)), self._ptr(feat),
+                                        self._ptr(energy)), self.ctx)
+        return feat, energy
+
     def cmvnw(self, feat, win_size=301, variance=False, n_frames=None):
         """Sliding-window CMVN of feat [n_utt, max_frames, cols] (or [rows, cols]); returns a new tensor."""
         torch = _torch()

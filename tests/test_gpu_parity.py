@@ -363,15 +363,32 @@ def test_utils_transforms(eng, golden, monkeypatch):
         np.testing.assert_array_equal(cube3[:, u], want.transpose(2, 0, 1)[:, idx[u]:idx[u] + 80].astype(np.float32))
 
 
+def test_general_fft_lengths(sp):
+    """fft lengths / filter counts outside the fused kernel go through the stage kernels
+    (framing -> direct-DFT spectrum -> svk_mel_features) and still match the reference."""
+    sig8k = synth.noise_clip(21, 8000)
+    np.testing.assert_allclose(sp.feature.mfcc(sig8k, 8000, fft_length=256),
+                               ref.mfcc(sig8k, 8000, fft_length=256), **FEAT_TOL)
+    sig = synth.speaker_clip(4, 0, 9000)
+    np.testing.assert_allclose(sp.feature.lmfe(sig, 16000, fft_length=2048, num_filters=80),
+                               ref.lmfe(sig, 16000, fft_length=2048, num_filters=80), **FEAT_TOL)
+    f, e = sp.feature.mfe(sig, 16000, frame_length=0.025, fft_length=400)         # not a power of two
+    fr, er = ref.mfe(sig, 16000, frame_length=0.025, fft_length=400)
+    np.testing.assert_allclose(f, fr, rtol=1e-4)
+    np.testing.assert_allclose(e, er, rtol=1e-4)
+    np.testing.assert_allclose(sp.feature.mfcc(sig, 16000, fft_length=256, dc_elimination=False, num_cepstral=20),
+                               ref.mfcc(sig, 16000, fft_length=256, dc_elimination=False, num_cepstral=20), **FEAT_TOL)
+
+
 def test_error_paths(eng):
     """Unsupported configurations fail loudly with the library's message; nothing falls back."""
     from speaker_verification_amd._lib import SvkError
     from speaker_verification_amd.speechpy import feature, processing
     sig = synth.noise_clip(1, 4000)
     with pytest.raises(SvkError, match="fft_length 512 or 1024"):
-        feature.mfcc(sig, 16000, fft_length=256)
+        feature.features_batch(sig[None], 16000, fft_length=256)            # the batched entry point is the fused kernel
     with pytest.raises(SvkError, match="filters"):
-        feature.mfcc(sig, 16000, num_filters=80)
+        feature.features_batch(sig[None], 16000, num_filters=80)
     with pytest.raises(AssertionError):
         feature.mfcc(sig, 16000, high_frequency=9000)                     # feature.py:58
     with pytest.raises(AssertionError):
