@@ -192,6 +192,16 @@ int svk_cosine_scores(svk_ctx* ctx, const float* d_test, const float* d_enroll, 
 /* siamese.py:29-30: out[i] = || a[i] - b[i] ||_2 */
 int svk_l2_dist(svk_ctx* ctx, const float* d_a, const float* d_b, int32_t n, int32_t dim, float* d_out);
 
+/* ---- ROC / EER / AUC on the device ------------------------------------------------------------
+ * evaluation.py:47-52 (sklearn roc_curve + roc_auc_score + brentq on interp1d) for pair sets too
+ * large for the host: stable sort of the scores (descending), scan of the labels, one point per
+ * distinct score, trapezoid AUC and the linear root of 1 - fpr - tpr.  d_labels: uint8, 1 = positive.
+ * d_workspace: svk_roc_workspace_bytes(n) bytes.  h_out[4] (HOST) = {eer, auc, positives, ROC points};
+ * the call synchronises the stream (its result is a host scalar). */
+size_t svk_roc_workspace_bytes(int64_t n);
+int svk_roc_eer(svk_ctx* ctx, const float* d_scores, const uint8_t* d_labels, int64_t n, void* d_workspace,
+                size_t workspace_bytes, double* h_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -333,6 +333,22 @@ class Engine:
                                          self._ptr(out)), self.ctx)
         return out
 
+    def roc_eer(self, scores, labels):
+        """(eer, auc) of flat scores / 0-1 labels, computed on the device (svk_roc_eer)."""
+        torch = _torch()
+        sc = self.to_device(scores, torch.float32).reshape(-1)
+        lb = self.to_device(labels).reshape(-1)
+        lb = (lb != 0).to(torch.uint8) if lb.dtype != torch.uint8 else lb
+        n = sc.numel()
+        if lb.numel() != n:
+            raise ValueError("scores and labels differ in length")
+        work = torch.empty((int(self.lib.svk_roc_workspace_bytes(n)),), dtype=torch.uint8, device=self.device)
+        out = (C.c_double * 4)()
+        self._stream()
+        check(self.lib.svk_roc_eer(self.ctx, self._ptr(sc), self._ptr(lb), n, self._ptr(work), work.numel(), out),
+              self.ctx)
+        return float(out[0]), float(out[1])
+
     def l2_dist(self, a, b):
         torch = _torch()
         a = self.to_device(a, torch.float32)

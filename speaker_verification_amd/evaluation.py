@@ -28,6 +28,13 @@ def get_eer_auc(label, distance):
     return eer, auc, fpr, tpr
 
 
+def get_eer_auc_device(label, distance):
+    """(eer, auc) like `get_eer_auc`, computed on the GPU (sort + scan + one pass over the ROC
+    points): for score sets that should not travel to the host (dev-set scale, 1.8e8 pairs).
+    Accepts NumPy arrays or CUDA tensors of any shape; no fpr / tpr arrays are returned."""
+    return get_engine().roc_eer(distance, label)
+
+
 def get_and_plot_k_eer_auc(label, scores, k=1, plot_path='eer_auc.png'):
     """Mean EER / AUC over k consecutive equal slices, printed in percent, ROC
     curves saved to `plot_path` when matplotlib is importable (evaluation.py:11-44).

@@ -502,6 +502,25 @@ def test_enrolment_store_roundtrip(eng, tmp_path):
     assert out["scores"].shape == (6, 3) and 0.0 <= out["eer"] <= 1.0 and out["accuracy"] >= 50.0
 
 
+def test_device_roc_eer(eng, golden):
+    from speaker_verification_amd import evaluation
+    g = golden["scoring"]
+    eer, auc = evaluation.get_eer_auc_device(g["labels"], g["sims"])
+    assert eer == pytest.approx(float(g["eer"][0]), abs=1e-9) and auc == pytest.approx(float(g["auc"][0]), abs=1e-9)
+    eer, auc = evaluation.get_eer_auc_device(g["big_labels"], g["big_scores"].astype(np.float32))
+    want = scoring_ref.get_eer_auc(g["big_labels"], g["big_scores"].astype(np.float32))
+    assert eer == pytest.approx(want[0], abs=1e-9) and auc == pytest.approx(want[1], abs=1e-9)
+    rng = np.random.default_rng(10)
+    # heavy ties (quantised scores), unbalanced classes, 2e6 pairs
+    lab = (rng.random(2_000_000) < 0.03).astype(np.uint8)
+    sc = np.round(rng.standard_normal(2_000_000) + 0.8 * lab, 2).astype(np.float32)
+    eer, auc = evaluation.get_eer_auc_device(lab, sc)
+    want = scoring_ref.get_eer_auc(lab, sc)
+    assert eer == pytest.approx(want[0], abs=1e-9) and auc == pytest.approx(want[1], abs=1e-9)
+    with pytest.raises(Exception):
+        evaluation.get_eer_auc_device(np.ones(10, dtype=np.uint8), np.arange(10, dtype=np.float32))
+
+
 def test_siamese(eng, golden):
     from speaker_verification_amd.siamese import Siamese
     g = golden["scoring"]
