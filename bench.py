@@ -272,6 +272,7 @@ def main():
         labels = (spk_all[:n_test, None] == ids[None, :]).astype(np.float64)
         sc = scores.cpu().numpy().astype(np.float64)
         eer, auc, _, _ = evaluation.get_eer_auc(labels.flatten(), sc.flatten())
+        eer_dev, auc_dev = evaluation.get_eer_auc_device(labels, scores)       # svk_roc_eer on the same matrix
         result = {
             "metric": "utterances/sec (MFCC->embed->cosine)", "value": value, "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -290,7 +291,8 @@ def main():
                          "kernel": "frontend_kernel<int16,nfft1024>", "avg_launch_ms": avg_launch_s * 1e3,
                          "clips_per_launch": float(fe_clips.mean()), "bytes_per_utt": bytes_per_utt,
                          "frontend_share_of_step": float(fe_ms.sum()) / args.steps / ms_per_step},
-            "eer": {"eer": eer, "auc": auc, "pairs": int(labels.size), "short_clips": bad},
+            "eer": {"eer": eer, "auc": auc, "eer_device": eer_dev, "auc_device": auc_dev, "pairs": int(labels.size),
+                    "short_clips": bad},
         }
 
     if rank == 0 and world == 1:

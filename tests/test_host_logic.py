@@ -82,3 +82,22 @@ def test_enroll_last_utterance():
     from speaker_verification_amd.pipeline import enroll_last_utterance
     ids, last = enroll_last_utterance(None, np.array([5, 5, 2, 5, 2, 9]))
     assert list(ids) == [2, 5, 9] and list(last) == [4, 3, 5]                    # Q17: last one wins
+
+
+def test_fused_embedder_pool_order():
+    """BN folding + pool-before-PReLU (slope >= 0) and the plain order (negative slope) both equal
+    the module's own forward."""
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    x = torch.randn(2, 1, 20, 80, 40)
+    for negative in (False, True):
+        m = seeded_model(3, n_labels=4)
+        m.load_state_dict(perturb_inference_state(m.state_dict(), 4))
+        if negative:
+            with torch.no_grad():
+                m.PReLu1_2.weight.fill_(-0.3)
+                m.PReLu2_2.weight.fill_(-0.1)
+        fused = m.fused_inference()
+        assert [st[5] for st in fused.stages if st[4]] == [not negative, not negative]
+        with torch.no_grad():
+            want = m(x, development=False)
+        torch.testing.assert_close(fused(x), want, rtol=1e-4, atol=1e-5)

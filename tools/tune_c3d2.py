@@ -45,7 +45,7 @@ def main():
         fused_cl = model.fused_inference(channels_last=True)
         out["fused_channels_last_total_ms"] = timeit(torch, lambda: fused_cl(x))
         cur = x
-        for (tag, _, cout, kernel, stride, pool), (w, b, slope, _, _) in zip(_LAYERS, fused.stages):
+        for (tag, _, cout, kernel, stride, pool), (w, b, slope, _, _, _) in zip(_LAYERS, fused.stages):
             rec = {"in": list(cur.shape), "kernel": list(kernel), "stride": list(stride)}
             rec["conv3d_ms"] = timeit(torch, lambda: F.conv3d(cur, w, b, stride=stride))
             y = F.conv3d(cur, w, b, stride=stride)
