@@ -137,8 +137,12 @@ class VerificationPipeline:
         dev = self.eng.device
         spans = self.chunks(n)
         size = max(hi - lo for lo, hi in spans)
-        pinned = [torch.empty((size, L), dtype=torch.int16).pin_memory() for _ in range(2)]
-        staged = [torch.empty((size, L), dtype=torch.int16, device=dev) for _ in range(2)]
+        key = (size, L)
+        if getattr(self, "_host_key", None) != key:      # pinned allocations are slow: keep them across calls
+            self._host_key = key
+            self._pinned = [torch.empty((size, L), dtype=torch.int16).pin_memory() for _ in range(2)]
+            self._staged = [torch.empty((size, L), dtype=torch.int16, device=dev) for _ in range(2)]
+        pinned, staged = self._pinned, self._staged
         copied = [torch.cuda.Event() for _ in range(2)]
         consumed = [torch.cuda.Event() for _ in range(2)]
         copy_stream = torch.cuda.Stream(device=dev)
