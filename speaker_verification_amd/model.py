@@ -108,13 +108,31 @@ class FusedEmbedder:
                 self.stages.append((w, b, act.weight.detach().clone(), stride, pool, pool_first))
             self.fc_w = model.FC5.weight.detach().clone()
             self.fc_b = model.FC5.bias.detach().clone()
+            # First layer as patch-matrix x weight GEMM: MIOpen has no direct kernel for a 1-channel
+            # Conv3d and falls back to im2col + per-group GEMM + layout transposes (6.5 ms per 978
+            # cubes); gathering the 3x1x5 patches with ONE strided copy and calling addmm is 5.2 ms
+            # and lands directly in channels-last order.
+            w0 = self.stages[0][0]
+            self.first_as_gemm = bool(channels_last and w0.shape[1] == 1 and w0.shape[3] == 1 and
+                                      self.stages[0][3] == (1, 1, 1))
+            if self.first_as_gemm:
+                self.w0_mat = w0.reshape(w0.shape[0], -1).t().contiguous()      # (kd * kw, out_channels)
 
     @torch.no_grad()
     def __call__(self, x):
         if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last_3d)
-        for w, b, slope, stride, pool, pool_first in self.stages:
-            x = F.conv3d(x, w, b, stride=stride)
+        for li, (w, b, slope, stride, pool, pool_first) in enumerate(self.stages):
+            if li == 0 and self.first_as_gemm:
+                n, _, d, h, wd = x.shape
+                kd, kw = w.shape[2], w.shape[4]
+                od, ow = d - kd + 1, wd - kw + 1
+                xs = x.reshape(n, d, h, wd)
+                patches = xs.as_strided((n, od, h, ow, kd, kw), (d * h * wd, h * wd, wd, 1, h * wd, 1))
+                x = torch.addmm(b, patches.reshape(n * od * h * ow, kd * kw), self.w0_mat)
+                x = x.view(n, od, h, ow, w.shape[0]).permute(0, 4, 1, 2, 3)     # NDHWC memory = channels_last_3d
+            else:
+                x = F.conv3d(x, w, b, stride=stride)
             if pool_first:
                 # MaxPool3d((1,1,2)) as one element-wise max of the even and odd columns (an odd last
                 # column is dropped, as the pooling floor does): 2.3x faster than max_pool3d here
