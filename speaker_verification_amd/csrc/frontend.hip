@@ -235,6 +235,18 @@ struct FrameReader {
   }
 };
 
+// Natural log of a mel / frame energy.  With integer PCM an energy is either the eps that replaces
+// an exact zero or at least ~1e-3 (one LSB), never a float32 denormal, so the bare v_log_f32
+// (log2, 1 ulp) x ln 2 is safe: two instructions.  Float PCM can be arbitrarily quiet: keep the
+// denormal-safe library expansion there.
+template <bool INT_PCM>
+__device__ __forceinline__ float fast_log(float x) {
+  if constexpr (INT_PCM)
+    return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
+  else
+    return __logf(x);
+}
+
 template <typename PcmT, bool SPLIT1024, int TILE, bool RAW16>
 __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -255,6 +267,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
   cplx* scr = reinterpret_cast<cplx*>(ptile + TILE * prow);
   float* elds = reinterpret_cast<float*>(scr + SCR);
   const int lane_id = threadIdx.x & 63;
+  constexpr bool INT_PCM = sizeof(PcmT) == 2;
 
   cplx t1[8], t2[8], t3[5];
 #pragma unroll
@@ -423,13 +436,17 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
       float* orow = out_rows + (int64_t)jf * p.ncols;
 #pragma unroll
       for (int t = 0; t < MAX_FT; ++t) {
+        if (t < p.n_ft) {  // wave-uniform: an absent filter tile costs nothing
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float m = acc[t][r];
-          m = m == 0.f ? EPS64 : m;  // feature.py:217
-          const int filt = 16 * t + 4 * g + r;
-          if (p.out_kind != SVK_OUT_MFE) m = filt < p.nfilt ? __logf(m) : 0.f;
-          acc[t][r] = m;
+          for (int r = 0; r < 4; ++r) {
+            float m = acc[t][r];
+            m = m == 0.f ? EPS64 : m;  // feature.py:217
+            if (p.out_kind != SVK_OUT_MFE) {
+              m = fast_log<INT_PCM>(m);
+              if (16 * t + 12 + 3 >= p.nfilt) m = (16 * t + 4 * g + r) < p.nfilt ? m : 0.f;  // only the ragged last tile
+            }
+            acc[t][r] = m;
+          }
         }
       }
       if (p.out_kind != SVK_OUT_MFCC) {
@@ -448,7 +465,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         }
       } else {
         // ---- cepstra^T = DCT x log(mel)^T: acc[t][r] is already the B operand ------
-        const float le = __logf(elds[jf & (TILE - 1)]);
+        const float le = fast_log<INT_PCM>(elds[jf & (TILE - 1)]);
         for (int c = 0; c < ((p.ablate & 16) ? 0 : p.n_ct); ++c) {  // runtime loop: keeps the table loads of one cepstral tile in flight, not four
           f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
           const float* dfrag = dct_lds + c * p.n_ft * 4 * 64 + lane;
