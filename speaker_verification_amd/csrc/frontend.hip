@@ -410,22 +410,18 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
         if (t < p.n_ft && !(p.ablate & 8)) {
           const f32x4* frag = fb_lds + (p.slot_base[t] - p.chunk_lo[t]) * 64 + lane;
-          for (int u = p.chunk_lo[t]; u < p.chunk_hi[t]; u += 2) {
-            const bool two = u + 1 < p.chunk_hi[t];
-            const f32x4 a0 = frag[u * 64];
-            const f32x4 a1 = two ? frag[(u + 1) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int u = p.chunk_lo[t]; u < p.chunk_hi[t]; u += 2) {  // the plan makes every chunk range even
+            const f32x4 a0 = frag[u * 64], a1 = frag[(u + 1) * 64];
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(pb + 16 * u);
-            const f32x4 b1 = two ? *reinterpret_cast<const f32x4*>(pb + 16 * (u + 1)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(pb + 16 * (u + 1));
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], b0[0], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1], b0[1], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[2], b0[2], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[3], b0[3], acc1, 0, 0, 0);
-            if (two) {
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], b1[0], acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1], b1[1], acc1, 0, 0, 0);
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[2], b1[2], acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[3], b1[3], acc1, 0, 0, 0);
-            }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], b1[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1], b1[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[2], b1[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[3], b1[3], acc1, 0, 0, 0);
           }
         }
         acc[t] = acc0 + acc1;
@@ -597,8 +593,8 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
                     "filterbank reaches bin %d; the fused kernel keeps bins < 256 (the SpeechPy bank stops at "
                     "(nfft/2+2)/2, Q2)", kmax);
   }
-  plan->kp = ((kmax + 1 + 15) / 16) * 16;
-  if (plan->kp < 16) plan->kp = 16;
+  plan->kp = ((kmax + 1 + 31) / 32) * 32;  // a multiple of 32 bins: the mel loop consumes chunks of 16 in pairs
+  if (plan->kp < 32) plan->kp = 32;
   const int nchunks = plan->kp / 16;
   for (int t = 0; t < MAX_FT; ++t) {
     int lo = nchunks, hi = 0;
@@ -609,6 +605,9 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
           hi = std::max(hi, k / 16 + 1);
         }
     if (hi <= lo) lo = hi = 0;
+    if ((hi - lo) & 1) {  // pair up: take one more (all-zero) chunk on whichever side has room
+      if (hi < nchunks) ++hi; else --lo;
+    }
     plan->chunk_lo[t] = lo;
     plan->chunk_hi[t] = hi;
   }
