@@ -1,0 +1,66 @@
+"""`AudioDataset` with the constructor and item protocol of `/root/reference/load_data.py:9-87`
+(thin host plumbing on the path: file list -> WAV -> log-mel features -> transforms).
+
+The reference reads audio with `librosa.load(path, sr=16000, mono=True)` (`utils.py:170-173`), which is
+not installed here.  `load_wav` below reads 16-bit PCM WAV files with the standard library and returns
+the same thing librosa does for a file that is already mono at the target rate: float32 in [-1, 1)
+(`int16 / 32768`).  A file at another rate or with several channels raises -- librosa's resampler is
+third-party arithmetic that nothing in the reference pins, so it is not imitated ("parity unpinned").
+"""
+import contextlib
+import os
+import wave
+
+import numpy as np
+
+from . import constants as c
+from .speechpy import feature as speech
+from .utils import ToTensor
+
+
+def load_wav(path, sample_rate=c.SAMPLE_RATE):
+    """float32 mono signal in [-1, 1) of a 16-bit PCM WAV already at `sample_rate` (utils.py:170-173)."""
+    with contextlib.closing(wave.open(path, 'rb')) as wf:
+        if wf.getnchannels() != 1 or wf.getsampwidth() != 2:
+            raise ValueError(f"{path}: need mono 16-bit PCM, got {wf.getnchannels()} channel(s) x "
+                             f"{8 * wf.getsampwidth()} bit")
+        if wf.getframerate() != sample_rate:
+            raise ValueError(f"{path}: sample rate {wf.getframerate()} != {sample_rate}; resampling "
+                             "(librosa, absent) is not imitated")
+        pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16)
+    return (pcm.astype(np.float32) / np.float32(32768.0))
+
+
+class AudioDataset(object):
+    """files_path: text file with one relative WAV path per line; audio_dir: their root;
+    indexed_labels: {first 7 characters of the path (the speaker id): class index}; transform: callable
+    on `{'feature', 'label'}` (load_data.py:10-45).  Files that are missing or smaller than 1 000 bytes
+    are skipped like the reference does (load_data.py:28-39)."""
+
+    def __init__(self, files_path, audio_dir, indexed_labels, transform=None, derivative=c.DERIVATIVE):
+        self.audio_dir = audio_dir
+        self.transform = transform
+        self.indexed = indexed_labels
+        self.derivative = derivative
+        content = np.atleast_1d(np.genfromtxt(files_path, dtype='str'))
+        kept = []
+        for rel in content:
+            full = os.path.join(self.audio_dir, rel)
+            try:
+                assert os.path.getsize(full) > 1000, "Bad file!"
+                kept.append(str(rel))
+            except OSError as err:
+                print("OS error: {0}".format(err))
+        self.sound_files = kept
+
+    def __len__(self):
+        return len(self.sound_files)
+
+    def __getitem__(self, idx):
+        signal = load_wav(os.path.join(self.audio_dir, self.sound_files[idx]))
+        logenergy = speech.lmfe(signal, sampling_frequency=c.SAMPLE_RATE, frame_length=c.FRAME_LEN,
+                                frame_stride=c.FRAME_STEP, num_filters=c.NUM_COEF, fft_length=c.NUM_FFT)
+        sample = {'feature': logenergy, 'label': self.indexed[self.sound_files[idx][0:7]]}   # load_data.py:73
+        if self.transform:
+            return self.transform(sample)
+        return ToTensor()(sample)

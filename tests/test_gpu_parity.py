@@ -6,6 +6,8 @@ reference (the kernels compute in f32; element-wise RELATIVE error alone is not 
 for cepstra that cross zero -- SURVEY.md section 7); cosine |d| <= 1e-5; VAD masks bit-exact;
 EER equal.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -378,6 +380,44 @@ def test_general_fft_lengths(sp):
     np.testing.assert_allclose(e, er, rtol=1e-4)
     np.testing.assert_allclose(sp.feature.mfcc(sig, 16000, fft_length=256, dc_elimination=False, num_cepstral=20),
                                ref.mfcc(sig, 16000, fft_length=256, dc_elimination=False, num_cepstral=20), **FEAT_TOL)
+
+
+def test_audio_dataset(tmp_path):
+    """load_data.AudioDataset: WAV files -> lmfe(25 ms / 10 ms / 40 / 1024) -> transforms, like load_data.py:50-87."""
+    from speaker_verification_amd import load_data, utils, vad
+
+    class Compose:                                   # torchvision.transforms.Compose is absent here
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    names = ["id10001/a.wav", "id10002/b.wav", "id10001/missing.wav"]
+    clips = {names[0]: synth.speaker_clip(1, 0, 20000), names[1]: synth.speaker_clip(2, 0, 32000)}
+    for rel, pcm in clips.items():
+        os.makedirs(os.path.dirname(tmp_path / rel), exist_ok=True)
+        vad.write_wave(str(tmp_path / rel), pcm.tobytes(), 16000)
+    listing = tmp_path / "ids.txt"
+    listing.write_text("\n".join(names) + "\n")
+    ds = load_data.AudioDataset(str(listing), str(tmp_path), {"id10001": 0, "id10002": 1})
+    assert len(ds) == 2                                                       # the missing file is skipped
+    feat, label = ds[1]
+    want = ref.lmfe((clips[names[1]] / 32768.0).astype(np.float32), 16000, 0.025, 0.01, 40, 1024)
+    assert label == 1
+    np.testing.assert_allclose(feat, want, **FEAT_TOL)
+    np.random.seed(5)
+    ds2 = load_data.AudioDataset(str(listing), str(tmp_path), {"id10001": 0, "id10002": 1},
+                                 transform=Compose([utils.CMVN(), utils.FeatureCube((80, 40, 20)), utils.ToTensor()]))
+    cube, label = ds2[0]
+    assert cube.shape == (1, 20, 80, 40) and cube.dtype == np.float32 and label == 0
+    sig, sr = vad.read_wave(str(tmp_path / names[0]))
+    assert sr == 16000 and sig == clips[names[0]].tobytes()
+    vad.write_wave(str(tmp_path / "stereo.wav"), b"\0" * 4000, 8000)
+    with pytest.raises(ValueError, match="sample rate"):
+        load_data.load_wav(str(tmp_path / "stereo.wav"))
 
 
 def test_error_paths(eng):
