@@ -128,6 +128,49 @@ def frontend_B_bench(eng, torch, reps=20, n_clips=1024):
                          "kernel": "frontend_kernel<int16,nfft1024>", "bytes_per_utt": bytes_per_utt}}
 
 
+def stage_breakdown(pipe, eng, torch, chunk, first_utt):
+    """HIP-event time of every stage of ONE micro-batch (serialised, outside the timed region) and
+    the algorithmic HBM rate of each hand-written kernel (bytes as in DESIGN.md section 3)."""
+    from speaker_verification_amd import constants as c
+    n, L = chunk.shape
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts)), out
+
+    rows = {}
+    t, (voiced, vlen) = timed(lambda: pipe.voiced(chunk))
+    kept = float(vlen.float().sum().item()) if vlen is not None else float(n * L)
+    rows["vad+compact"] = (t, n * L * 2 + kept * 2)
+    t, (feat, nf, _) = timed(lambda: eng.features(voiced, pipe.spec, lengths=vlen))
+    frames = float(nf.float().sum().item())
+    rows["frontend (lmfe-40, nfft 1024)"] = (t, kept * 2 + frames * 40 * 4)
+    t, _ = timed(lambda: eng.cmvn_(feat, nf, variance=True))
+    rows["cmvn"] = (t, 2 * frames * 40 * 4)
+    t, idx = timed(lambda: eng.draw_crops(nf, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, first_utt, pipe.bad_clips))
+    rows["draw_crops"] = (t, n * (4 + 80))
+    t, cube = timed(lambda: pipe.cubes(feat, idx))
+    rows["cube_gather"] = (t, frames * 40 * 4 + n * 256000)
+    t, emb = timed(lambda: pipe.embed_cubes(cube))
+    rows["C3D2 forward (PyTorch-ROCm)"] = (t, None)
+    t, _ = timed(lambda: pipe.score(emb, emb[:40]))
+    rows["cosine %dx40" % n] = (t, (n + 40) * 128 * 4 + n * 40 * 4)
+    total = sum(v[0] for v in rows.values())
+    return {"clips": n, "total_ms": total,
+            "stages": {k: {"ms": v[0], "share": v[0] / total,
+                           "algorithmic_GBps": None if v[1] is None else v[1] / (v[0] * 1e-3) / 1e9}
+                       for k, v in rows.items()}}
+
+
 def cpu_baseline(pcm_host, crop_idx, state, preemph, cmvn, use_vad):
     """The oracle (kind 'port') doing exactly the reference's per-utterance sequence on the host:
     vad -> preemphasis -> lmfe -> cmvn -> cube -> C3D2 at batch 1 -> per-pair cosine."""
@@ -308,6 +351,8 @@ def main():
         result["host_fed"] = {"utt_per_s": n_host / t_h, "clips": n_host,
                               "max_abs_diff_vs_resident": float((emb_h - full[:n_host]).abs().max().item()),
                               "note": "int16 NumPy -> pinned double buffer -> copy stream -> same kernels"}
+        lo0, hi0 = pipe.chunks(n_local)[0]
+        result["micro_batch_breakdown"] = stage_breakdown(pipe, eng, torch, pcm[lo0:hi0], 0)
         result["frontend_A"] = frontend_A_bench(eng, torch)
         if args.cpu_sample > 0:
             ns = min(args.cpu_sample, n_local)
