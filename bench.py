@@ -200,6 +200,14 @@ def cpu_baseline(pcm_host, crop_idx, state, preemph, cmvn, use_vad):
 
 def main():
     args = parse()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # one MIOpen find-db / kernel cache per rank: N processes searching kernels at once would
+        # otherwise contend for the same sqlite files under ~/.config/miopen and ~/.cache/miopen
+        import tempfile
+        tag = os.path.join(tempfile.gettempdir(), "svk_miopen_rank%s" % os.environ.get("LOCAL_RANK", "0"))
+        os.makedirs(tag, exist_ok=True)
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", tag)
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", tag)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
