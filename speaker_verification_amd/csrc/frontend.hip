@@ -163,22 +163,34 @@ __device__ __forceinline__ void stage_raw16(const FrontendParams& p, const int16
   }
 }
 
-// Wave sum with DPP moves only (no LDS crossbar): an inclusive scan inside each 16-lane row
-// (row_shr 1, 2, 4, 8), then row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3
-// (row_bcast:31).  The total is in LANE 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-  return v + __int_as_float(moved);
-}
-__device__ __forceinline__ float wave_sum_lane63(float v) {
-  v = dpp_add<0x111, 0xf>(v);
-  v = dpp_add<0x112, 0xf>(v);
-  v = dpp_add<0x114, 0xf>(v);
-  v = dpp_add<0x118, 0xf>(v);
-  v = dpp_add<0x142, 0xa>(v);
-  v = dpp_add<0x143, 0xc>(v);
-  return v;
+// Sum of two values over the wave with DPP adds only (no LDS crossbar): an inclusive scan inside
+// each 16-lane row (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then row
+// 0 -> 1 and 2 -> 3 (row_bcast:15, rows 1 and 3 written), then rows 0-1 -> 2-3 (row_bcast:31).  The
+// totals are in LANE 63.  Written as v_add_f32_dpp (add and lane move in ONE instruction; the
+// update_dpp builtin costs a zero-init, a move and an add per step); a VALU result needs two wait
+// states before a DPP read, which the other value's step plus one s_nop provide.
+__device__ __forceinline__ void wave_sum2_lane63(float& a, float& b) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(a), "+v"(b));
 }
 
 // Frame samples -> the 8 complex registers of a lane.  NSTEPS = how many of the 8 register steps
@@ -378,21 +390,26 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
               const cplx O2 = mk(Ot.x, -Ot.y);
               cplx xp = E2 + cmul(t3[j], O2);
               xp *= xp;
-              if (64 * (j + 1) <= p.kp || k < p.kp) rowa[k] = (xp.x + xp.y) * (0.25f * inv_scale);
+              const float pk = (xp.x + xp.y) * (0.25f * inv_scale);
+              if (64 * (j + 1) <= p.kp) rowa[k] = pk;  // wave-uniform: no exec masking
+              else if (k < p.kp) rowa[k] = pk;         // ragged last step only
             } else {
               // 2 X1 = Zk + conj Zn,  2i X2 = Zk - conj Zn  (|.|^2 is what matters)
               cplx xa = add_conj(zk, zn), xb = swap_add_conj(zk, zn);
               xa *= xa;
               xb *= xb;
-              if (64 * (j + 1) <= p.kp || k < p.kp) {  // uniform for all but a ragged last step
-                rowa[k] = (xa.x + xa.y) * inv_scale;
-                rowb[k] = (xb.x + xb.y) * inv_scale;
+              const float pa = (xa.x + xa.y) * inv_scale, pb = (xb.x + xb.y) * inv_scale;
+              if (64 * (j + 1) <= p.kp) {  // wave-uniform: no exec masking
+                rowa[k] = pa;
+                rowb[k] = pb;
+              } else if (k < p.kp) {       // ragged last step only
+                rowa[k] = pa;
+                rowb[k] = pb;
               }
             }
           }
         }
-        ea = wave_sum_lane63(ea);
-        if (!SPLIT1024) eb = wave_sum_lane63(eb);
+        wave_sum2_lane63(ea, eb);  // (eb is idle for nfft 1024: its slot still hides ea's DPP wait states)
         if (lane63) {
           elds[fa] = ea == 0.f ? EPS64 : ea;  // feature.py:205
           if (!SPLIT1024) elds[fa + 1] = eb == 0.f ? EPS64 : eb;
