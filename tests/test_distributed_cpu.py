@@ -56,3 +56,57 @@ def test_single_process_passthrough():
     x = _fake_embed(torch.arange(5))
     assert torch.equal(svdist.all_gather_embeddings(x, 5), x)
     assert torch.equal(svdist.sharded_embed(_fake_embed, torch.arange(5)), x)
+
+
+def _train_worker(rank, world, port, out_dir):
+    """Two ranks, each with half of the pair batch; the averaged gradient must equal the gradient of
+    the mean of the two local losses (what one process would compute on the whole batch)."""
+    from speaker_verification_amd.model import seeded_model
+    from speaker_verification_amd.train_siamese import allreduce_gradients, make_criterion
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = seeded_model(9, n_labels=4)
+        crit = make_criterion(0.001, 2.0)
+        g = torch.Generator().manual_seed(100)
+        a = torch.randn(4, 1, 20, 80, 40, generator=g)
+        b = torch.randn(4, 1, 20, 80, 40, generator=g)
+        y = torch.tensor([1.0, 0.0, 0.0, 1.0])
+        lo, hi = rank * 2, rank * 2 + 2
+        model.eval()                                    # BN in eval mode: shard-independent statistics
+        loss = crit(model, y[lo:hi], model(a[lo:hi], development=False), model(b[lo:hi], development=False))
+        loss.backward()
+        allreduce_gradients(model)
+        flat = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+        np.save(os.path.join(out_dir, f"g{rank}.npy"), flat.numpy())
+        if rank == 0:
+            ref = seeded_model(9, n_labels=4).eval()
+            l0 = crit(ref, y[0:2], ref(a[0:2], development=False), ref(b[0:2], development=False))
+            l1 = crit(ref, y[2:4], ref(a[2:4], development=False), ref(b[2:4], development=False))
+            (0.5 * (l0 + l1)).backward()
+            want = torch.cat([p.grad.reshape(-1) for p in ref.parameters() if p.grad is not None])
+            np.save(os.path.join(out_dir, "want.npy"), want.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_siamese_gradient_allreduce(tmp_path):
+    port = _free_port()
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1, want = (np.load(tmp_path / f) for f in ("g0.npy", "g1.npy", "want.npy"))
+    np.testing.assert_array_equal(g0, g1)
+    np.testing.assert_allclose(g0, want, rtol=1e-4, atol=1e-6)
+
+
+def test_siamese_train_step_single_process():
+    from speaker_verification_amd.model import seeded_model
+    from speaker_verification_amd.train_siamese import make_criterion, siamese_train_step
+    model = seeded_model(2, n_labels=4)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01)
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(4, 1, 20, 80, 40, generator=g), torch.randn(4, 1, 20, 80, 40, generator=g)
+    y = torch.tensor([1.0, 0.0, 1.0, 0.0])
+    before = model.FC5.weight.detach().clone()
+    l1 = siamese_train_step(model, make_criterion(), opt, a, b, y)
+    assert np.isfinite(l1) and not torch.equal(before, model.FC5.weight)
