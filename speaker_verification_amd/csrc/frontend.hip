@@ -47,6 +47,15 @@ constexpr int MAX_FT = 4;    // 16-filter tiles  (<= 64 filters)
 constexpr int PT_PAD = 8;    // ptile row padding (floats): conflict-free ds_read_b128
 constexpr float EPS64 = 2.220446049250313e-16f;  // np.finfo(float).eps, functions.py:62
 
+// Phase-ablation switches for tuning: compiled in only with -DSVK_TUNING
+// (`make TUNING=1`), selected at run time by SVK_FE_ABLATE = 1 skip staging | 2 skip the FFT loop |
+// 4 skip mel..output | 8 skip the mel MFMAs | 16 skip the DCT | 32 skip log..output | 64 skip zero fill.
+#ifdef SVK_TUNING
+#define SVK_ABLATE(p, bit) (((p).ablate & (bit)) != 0)
+#else
+#define SVK_ABLATE(p, bit) false
+#endif
+
 struct FrontendParams {
   const void* pcm;
   const int64_t* offsets;
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
       const PcmT* x = reinterpret_cast<const PcmT*>(p.pcm) + off;
       const int need = (nvalid - 1) * p.stride + p.flen_eff;
       wave_sync();  // previous tile's readers of sig / ptile are done
-      if (p.ablate & 1) {
+      if (SVK_ABLATE(p, 1)) {
       } else if constexpr (RAW16)
         stage_raw16(p, reinterpret_cast<const int16_t*>(x), (int64_t)f0 * p.stride, need, len, sigh, lane);
       else
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
 
       // ---- spectra -----------------------------------------------------------
       constexpr int FR_PER_FFT = SPLIT1024 ? 1 : 2;
-      for (int fa = 0; fa < ((p.ablate & 2) ? 0 : nvalid); fa += FR_PER_FFT) {
+      for (int fa = 0; fa < (SVK_ABLATE(p, 2) ? 0 : nvalid); fa += FR_PER_FFT) {
         cplx v[8];
         const bool hasb = !SPLIT1024 && fa + 1 < nvalid;
         {
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
       }
       wave_sync();
 
-      if (p.ablate & 4) continue;
+      if (SVK_ABLATE(p, 4)) continue;
       // ---- mel^T = fb x P^T (f32 MFMA), block-sparse over 16-bin chunks ---------
       f32x4 acc[MAX_FT];
       const float* pb = ptile + (jf & (TILE - 1)) * prow + 4 * g;  // an 8-frame tile repeats its rows in N = 8..15
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
       for (int t = 0; t < MAX_FT; ++t) {
         // two accumulators per filter tile: back-to-back MFMAs never wait on their own result
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-        if (t < p.n_ft && !(p.ablate & 8)) {
+        if (t < p.n_ft && !SVK_ABLATE(p, 8)) {
           const f32x4* frag = fb_lds + (p.slot_base[t] - p.chunk_lo[t]) * 64 + lane;
           for (int u = p.chunk_lo[t]; u < p.chunk_hi[t]; u += 2) {  // the plan makes every chunk range even
             const f32x4 a0 = frag[u * 64], a1 = frag[(u + 1) * 64];
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         }
         acc[t] = acc0 + acc1;
       }
-      if (p.ablate & 32) continue;
+      if (SVK_ABLATE(p, 32)) continue;
       // lane (jf, g) now holds mel[filter 16 t + 4 g + reg][frame jf]
       const bool row_ok = jf < nvalid;
       float* orow = out_rows + (int64_t)jf * p.ncols;
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
       } else {
         // ---- cepstra^T = DCT x log(mel)^T: acc[t][r] is already the B operand ------
         const float le = fast_log<INT_PCM>(elds[jf & (TILE - 1)]);
-        for (int c = 0; c < ((p.ablate & 16) ? 0 : p.n_ct); ++c) {  // runtime loop: keeps the table loads of one cepstral tile in flight, not four
+        for (int c = 0; c < (SVK_ABLATE(p, 16) ? 0 : p.n_ct); ++c) {  // runtime loop: keeps the table loads of one cepstral tile in flight, not four
           f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
           const float* dfrag = dct_lds + c * p.n_ft * 4 * 64 + lane;
 #pragma unroll
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
     const int first_bad = nvalid > 0 ? nvalid : 0;
     int last = p.max_frames - f0;
     last = last > TILE ? TILE : last;
-    if (p.ablate & 64) continue;
+    if (SVK_ABLATE(p, 64)) continue;
     for (int i = first_bad * p.ncols + lane; i < last * p.ncols; i += 64) out_rows[i] = 0.f;
     if (p.energy)
       for (int i = first_bad + lane; i < last; i += 64) p.energy[(int64_t)utt * p.max_frames + f0 + i] = 0.f;
