@@ -79,6 +79,130 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float* __restrict__ t
   }
 }
 
+// Large problems (dev-set scale: 148 642 x 1 211): a register / LDS tiled version of the same product.
+// A workgroup owns 128 test rows (each of its 4 waves two 16-row tiles, whose fragments stay in
+// registers for the whole kernel when dim <= 128) and walks the enrolled matrix 32 rows at a time; the
+// 32 x 128 enrolled block is staged in LDS once per workgroup (rows padded to 136 floats: conflict-free
+// ds_read_b128) and double-buffered: the next block's global loads are issued before the 128 MFMAs of
+// the current one and written to the other buffer after them.  16 MFMAs per ds_read_b128 pair instead
+// of 4 per pair of 16-byte global loads.
+constexpr int CT_BM = 128, CT_BN = 32, CT_KB = 128, CT_LD = CT_KB + 8;
+
+template <bool HOIST>
+__global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restrict__ test, const float* __restrict__ enroll,
+                                                           int nt, int ns, int dim, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float bs[2][CT_BN * CT_LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int nkb = (dim + CT_KB - 1) / CT_KB;
+  const bool vec_ok = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(test) | reinterpret_cast<uintptr_t>(enroll)) & 15) == 0;
+  const int m0 = blockIdx.x * CT_BM + wave * 32;
+  const int n_stiles = (ns + CT_BN - 1) / CT_BN;
+
+  // staging assignment: thread t moves 4 float4 of the 32 x 128 block: row = (t >> 5) + 8 j, float4 column = t & 31
+  const int srow = threadIdx.x >> 5, scol = (threadIdx.x & 31) * 4;
+  auto fetch = [&](int st, int kb, f32x4 (&regs)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = st * CT_BN + srow + 8 * j;
+      regs[j] = load4(enroll + (int64_t)r * dim, kb * CT_KB + scol, dim, r < ns, vec_ok);
+    }
+  };
+  auto stash = [&](float* buf, const f32x4 (&regs)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(buf + (srow + 8 * j) * CT_LD + scol) = regs[j];
+  };
+
+  // test-row fragments and norms
+  f32x4 a[2][8];
+  float tn[2] = {0.f, 0.f};
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = m0 + 16 * rt + i;
+    const float* tp = test + (int64_t)row * dim;
+    for (int kb = 0; kb < nkb; ++kb) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const f32x4 v = load4(tp, kb * CT_KB + 16 * u + 4 * kk, dim, row < nt, vec_ok);
+        tn[rt] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        if (HOIST) a[rt][u] = v;
+      }
+    }
+    tn[rt] += __shfl_xor(tn[rt], 16, 64);
+    tn[rt] += __shfl_xor(tn[rt], 32, 64);
+    tn[rt] = sqrtf(tn[rt]);
+    tn[rt] = tn[rt] == 0.f ? 1.f : tn[rt];
+  }
+
+  f32x4 pre[4];
+  fetch(0, 0, pre);
+  stash(bs[0], pre);
+  __syncthreads();
+  int cur = 0;
+  for (int st = 0; st < n_stiles; ++st) {
+    f32x4 acc[2][2];
+    float sn[2] = {0.f, 0.f};
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < nkb; ++kb) {
+      // prefetch the next (enroll block, K block) while this one is multiplied
+      const bool last_kb = kb + 1 == nkb;
+      const int nst = last_kb ? st + 1 : st, nkb_i = last_kb ? 0 : kb + 1;
+      const bool more = nst < n_stiles;
+      if (more) fetch(nst, nkb_i, pre);
+      const float* b = bs[cur];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        f32x4 av[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          if (HOIST) {
+            av[rt] = a[rt][u];
+          } else {
+            const int row = m0 + 16 * rt + i;
+            av[rt] = load4(test + (int64_t)row * dim, kb * CT_KB + 16 * u + 4 * kk, dim, row < nt, vec_ok);
+          }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(b + (16 * ct + i) * CT_LD + 16 * u + 4 * kk);
+          sn[ct] += bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2] + bv[3] * bv[3];
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][0], bv[0], acc[rt][ct], 0, 0, 0);
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][1], bv[1], acc[rt][ct], 0, 0, 0);
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][2], bv[2], acc[rt][ct], 0, 0, 0);
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][3], bv[3], acc[rt][ct], 0, 0, 0);
+          }
+        }
+      }
+      if (more) stash(bs[cur ^ 1], pre);
+      __syncthreads();  // everyone is done with bs[cur]; bs[cur ^ 1] is complete
+      cur ^= 1;
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      float s2 = sn[ct];
+      s2 += __shfl_xor(s2, 16, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      float snorm = sqrtf(s2);
+      snorm = snorm == 0.f ? 1.f : snorm;
+      const int col = st * CT_BN + 16 * ct + i;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + 16 * rt + 4 * kk + r;
+          const float rn = __shfl(tn[rt], 4 * kk + r, 64);
+          if (row < nt && col < ns) out[(int64_t)row * ns + col] = acc[rt][ct][r] / (rn * snorm);
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void l2_dist_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
                                                       int dim, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -106,10 +230,21 @@ int svk_cosine_scores(svk_ctx* ctx, const float* d_test, const float* d_enroll, 
   if (dim > 4096) return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "embedding dim %d > 4096", dim);
   if (n_test == 0 || n_enroll == 0) return SVK_OK;
   SVK_REQUIRE(ctx, d_test && d_enroll && d_out, "NULL buffer");
-  const int tiles = (n_test + 15) / 16;
-  const unsigned grid = (unsigned)std::max(1, std::min((tiles + 3) / 4, ctx->num_cu * 8));
-  hipLaunchKernelGGL(cosine_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_test, d_enroll, n_test, n_enroll, dim,
-                     d_out);
+  if ((int64_t)n_test * n_enroll >= ((int64_t)1 << 22) && n_enroll >= 64) {
+    // enough work to fill the chip with 128-row workgroups: tiled kernel
+    const unsigned grid = (unsigned)((n_test + CT_BM - 1) / CT_BM);
+    if (dim <= CT_KB)
+      hipLaunchKernelGGL(cosine_tiled_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, d_test, d_enroll, n_test,
+                         n_enroll, dim, d_out);
+    else
+      hipLaunchKernelGGL(cosine_tiled_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, d_test, d_enroll, n_test,
+                         n_enroll, dim, d_out);
+  } else {
+    const int tiles = (n_test + 15) / 16;
+    const unsigned grid = (unsigned)std::max(1, std::min((tiles + 3) / 4, ctx->num_cu * 8));
+    hipLaunchKernelGGL(cosine_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_test, d_enroll, n_test, n_enroll, dim,
+                       d_out);
+  }
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }

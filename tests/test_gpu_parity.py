@@ -499,6 +499,20 @@ def test_cosine_scores(eng, golden):
         assert not got[0].any()
 
 
+def test_cosine_scores_tiled_kernel(eng):
+    """Problems with >= 2^22 pairs take the LDS-tiled kernel (dim <= 128: fragments hoisted; larger: streamed)."""
+    rng = np.random.default_rng(9)
+    for nt, ns, d in ((4100, 1030, 128), (2050, 2100, 200), (8200, 520, 100), (3000, 1500, 7)):
+        t = rng.standard_normal((nt, d)).astype(np.float32)
+        e = rng.standard_normal((ns, d)).astype(np.float32)
+        t[5] = 0
+        e[3] = 0
+        got = eng.cosine_scores(t, e).cpu().numpy()
+        want = scoring_ref.cosine_matrix(t, e)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
+        assert not got[5].any() and not got[:, 3].any()
+
+
 def test_evaluation_dropin(eng, golden):
     from speaker_verification_amd import evaluation
     g = golden["scoring"]
