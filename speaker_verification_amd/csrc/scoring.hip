@@ -97,7 +97,11 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
   const int nkb = (dim + CT_KB - 1) / CT_KB;
   const bool vec_ok = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(test) | reinterpret_cast<uintptr_t>(enroll)) & 15) == 0;
   const int m0 = blockIdx.x * CT_BM + wave * 32;
-  const int n_stiles = (ns + CT_BN - 1) / CT_BN;
+  // blockIdx.y splits the enrolled range so that a few tall row blocks still fill the chip
+  const int all_stiles = (ns + CT_BN - 1) / CT_BN;
+  const int per_y = (all_stiles + gridDim.y - 1) / gridDim.y;
+  const int st_begin = blockIdx.y * per_y;
+  const int n_stiles = min(all_stiles, st_begin + per_y);
 
   // staging assignment: thread t moves 4 float4 of the 32 x 128 block: row = (t >> 5) + 8 j, float4 column = t & 31
   const int srow = threadIdx.x >> 5, scol = (threadIdx.x & 31) * 4;
@@ -133,13 +137,20 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
     tn[rt] = sqrtf(tn[rt]);
     tn[rt] = tn[rt] == 0.f ? 1.f : tn[rt];
   }
+  // 1 / norm of the four output rows this lane writes per tile (row 4 kk + r lives in lane 4 kk + r)
+  float rinv[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rinv[rt][r] = 1.0f / __shfl(tn[rt], 4 * kk + r, 64);
 
   f32x4 pre[4];
-  fetch(0, 0, pre);
+  if (st_begin >= n_stiles) return;  // uniform per workgroup
+  fetch(st_begin, 0, pre);
   stash(bs[0], pre);
   __syncthreads();
   int cur = 0;
-  for (int st = 0; st < n_stiles; ++st) {
+  for (int st = st_begin; st < n_stiles; ++st) {
     f32x4 acc[2][2];
     float sn[2] = {0.f, 0.f};
 #pragma unroll
@@ -187,16 +198,16 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
       float s2 = sn[ct];
       s2 += __shfl_xor(s2, 16, 64);
       s2 += __shfl_xor(s2, 32, 64);
-      float snorm = sqrtf(s2);
-      snorm = snorm == 0.f ? 1.f : snorm;
+      const float sinv = s2 == 0.f ? 1.f : 1.0f / sqrtf(s2);
       const int col = st * CT_BN + 16 * ct + i;
+      if (col < ns) {
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = m0 + 16 * rt + 4 * kk + r;
-          const float rn = __shfl(tn[rt], 4 * kk + r, 64);
-          if (row < nt && col < ns) out[(int64_t)row * ns + col] = acc[rt][ct][r] / (rn * snorm);
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * rt + 4 * kk + r;
+            if (row < nt) out[(int64_t)row * ns + col] = acc[rt][ct][r] * rinv[rt][r] * sinv;
+          }
         }
       }
     }
@@ -232,12 +243,15 @@ int svk_cosine_scores(svk_ctx* ctx, const float* d_test, const float* d_enroll, 
   SVK_REQUIRE(ctx, d_test && d_enroll && d_out, "NULL buffer");
   if ((int64_t)n_test * n_enroll >= ((int64_t)1 << 22) && n_enroll >= 64) {
     // enough work to fill the chip with 128-row workgroups: tiled kernel
-    const unsigned grid = (unsigned)((n_test + CT_BM - 1) / CT_BM);
+    const unsigned gx = (unsigned)((n_test + CT_BM - 1) / CT_BM);
+    const unsigned stiles = (unsigned)((n_enroll + CT_BN - 1) / CT_BN);
+    const unsigned gy = std::max(1u, std::min(stiles, (unsigned)(2 * ctx->num_cu + gx - 1) / gx));
+    const dim3 grid(gx, gy);
     if (dim <= CT_KB)
-      hipLaunchKernelGGL(cosine_tiled_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, d_test, d_enroll, n_test,
+      hipLaunchKernelGGL(cosine_tiled_kernel<true>, grid, dim3(256), 0, ctx->stream, d_test, d_enroll, n_test,
                          n_enroll, dim, d_out);
     else
-      hipLaunchKernelGGL(cosine_tiled_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, d_test, d_enroll, n_test,
+      hipLaunchKernelGGL(cosine_tiled_kernel<false>, grid, dim3(256), 0, ctx->stream, d_test, d_enroll, n_test,
                          n_enroll, dim, d_out);
   } else {
     const int tiles = (n_test + 15) / 16;
