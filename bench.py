@@ -171,6 +171,32 @@ def stage_breakdown(pipe, eng, torch, chunk, first_utt):
                        for k, v in rows.items()}}
 
 
+def cosine_mfma_bench(eng, torch, reps=10):
+    """The all-pairs cosine kernel at dev-set scale (148 642 x 1 211 x 128, SURVEY 8d's stress shape):
+    its MFMA utilisation against the dense f32 matrix peak (157.3 TFLOP/s).  The verification shape
+    (4 874 x 40) is 50 MFLOP -- launch-latency-bound by construction -- and is timed inside every step."""
+    nt, ns, d = 148642, 1211, 128
+    t = torch.randn(nt, d, device=eng.device)
+    e = torch.randn(ns, d, device=eng.device)
+    for _ in range(3):
+        eng.cosine_scores(t, e)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        eng.cosine_scores(t, e)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = float(np.median(ts))
+    tf = 2.0 * nt * ns * d / ms / 1e9
+    return {"workload": "%d x %d x %d cosine score matrix" % (nt, ns, d), "ms": ms,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                         "traffic": None, "kernel": "cosine_tiled_kernel<true> (v_mfma_f32_16x16x4_f32)",
+                         "output_GBps": nt * ns * 4 / ms / 1e6}}
+
+
 def cpu_baseline(pcm_host, crop_idx, state, preemph, cmvn, use_vad):
     """The oracle (kind 'port') doing exactly the reference's per-utterance sequence on the host:
     vad -> preemphasis -> lmfe -> cmvn -> cube -> C3D2 at batch 1 -> per-pair cosine."""
@@ -362,6 +388,7 @@ def main():
         lo0, hi0 = pipe.chunks(n_local)[0]
         result["micro_batch_breakdown"] = stage_breakdown(pipe, eng, torch, pcm[lo0:hi0], 0)
         result["frontend_A"] = frontend_A_bench(eng, torch)
+        result["cosine_mfma"] = cosine_mfma_bench(eng, torch)
         if args.cpu_sample > 0:
             ns = min(args.cpu_sample, n_local)
             sample = pcm[:ns]
