@@ -175,14 +175,15 @@ int svk_cube_gather(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
 
 /* Crop starts drawn ON THE DEVICE (no host round trip for the per-clip frame count):
  * crop[u][c] = floor(uniform(seed, u, c) * (n_frames[u] - crop_frames)), a counter-based
- * generator (splitmix64 of seed, first_utt + u, c), so a draw depends only on the clip's global
- * index.  utils.py:372 draws `np.random.randint(T - 80, size=20)` from the process-global
+ * generator (splitmix64 of seed, g, c) with g = d_utt_index[u] when that array is given (clips of a
+ * ragged corpus land in batches in any order) and first_utt + u otherwise, so a draw depends only on
+ * the clip's global index.  utils.py:372 draws `np.random.randint(T - 80, size=20)` from the process-global
  * NumPy RNG instead; hosts that need that exact sequence pass their own d_crop_idx to
  * svk_cube_gather.  Clips with n_frames <= crop_frames get -1 (svk_cube_gather then emits zeros)
  * and are counted in *d_bad_count (int32, may be NULL; the caller zeroes it).               */
 int svk_cube_draw_crops(svk_ctx* ctx, const int32_t* d_n_frames, int32_t n_utt, int64_t first_utt,
-                        int32_t n_crops, int32_t crop_frames, uint64_t seed, int32_t* d_crop_idx,
-                        int32_t* d_bad_count);
+                        const int64_t* d_utt_index, int32_t n_crops, int32_t crop_frames, uint64_t seed,
+                        int32_t* d_crop_idx, int32_t* d_bad_count);
 
 /* ---- scoring ---------------------------------------------------------------
  * evaluation.py:67-84: cosine of every test row against every enrolled row,

@@ -66,12 +66,12 @@ RocLayout roc_layout(int64_t n) {
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   RocLayout l;
   size_t sort_b = 0, scan_b = 0, sel_b = 0;
-  hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sort_b, (const float*)nullptr, (float*)nullptr,
+  (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sort_b, (const float*)nullptr, (float*)nullptr,
                                                (const uint8_t*)nullptr, (uint8_t*)nullptr, n);
   hipcub::TransformInputIterator<unsigned, ToU32, const uint8_t*> it((const uint8_t*)nullptr, ToU32());
-  hipcub::DeviceScan::InclusiveSum(nullptr, scan_b, it, (unsigned*)nullptr, n);
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_b, it, (unsigned*)nullptr, n);
   hipcub::CountingInputIterator<unsigned> cnt(0);
-  hipcub::DeviceSelect::Flagged(nullptr, sel_b, cnt, (const uint8_t*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, n);
+  (void)hipcub::DeviceSelect::Flagged(nullptr, sel_b, cnt, (const uint8_t*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, n);
   l.cub_bytes = std::max(sort_b, std::max(scan_b, sel_b));
   size_t o = 0;
   l.keys = o;  o += up((size_t)n * 4);

@@ -358,7 +358,8 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 
 __global__ __launch_bounds__(256) void draw_crops_kernel(const int32_t* __restrict__ n_frames, int n_utt,
-                                                         int64_t first_utt, int n_crops, int crop_frames,
+                                                         int64_t first_utt, const int64_t* __restrict__ utt_index,
+                                                         int n_crops, int crop_frames,
                                                          uint64_t seed, int32_t* __restrict__ crop,
                                                          int32_t* __restrict__ bad) {
   const int64_t total = (int64_t)n_utt * n_crops;
@@ -367,7 +368,8 @@ __global__ __launch_bounds__(256) void draw_crops_kernel(const int32_t* __restri
     const int range = n_frames[u] - crop_frames;
     int v = -1;
     if (range > 0) {
-      const uint64_t r = splitmix64(splitmix64(seed ^ (uint64_t)(first_utt + u)) + (uint64_t)c);
+      const uint64_t gid = utt_index ? (uint64_t)utt_index[u] : (uint64_t)(first_utt + u);
+      const uint64_t r = splitmix64(splitmix64(seed ^ gid) + (uint64_t)c);
       v = (int)__umul64hi(r, (uint64_t)range);  // floor(r / 2^64 * range)
     } else if (c == 0 && bad) {
       atomicAdd(bad, 1);
@@ -551,15 +553,15 @@ int svk_log_power(svk_ctx* ctx, float* d_power, int64_t n, int32_t normalize) {
 }
 
 int svk_cube_draw_crops(svk_ctx* ctx, const int32_t* d_n_frames, int32_t n_utt, int64_t first_utt,
-                        int32_t n_crops, int32_t crop_frames, uint64_t seed, int32_t* d_crop_idx,
-                        int32_t* d_bad_count) {
+                        const int64_t* d_utt_index, int32_t n_crops, int32_t crop_frames, uint64_t seed,
+                        int32_t* d_crop_idx, int32_t* d_bad_count) {
   if (!ctx) return SVK_ERR_BAD_ARG;
   SVK_REQUIRE(ctx, n_utt >= 0 && n_crops >= 0 && crop_frames >= 0, "negative shape");
   const int64_t total = (int64_t)n_utt * n_crops;
   if (total == 0) return SVK_OK;
   SVK_REQUIRE(ctx, d_n_frames && d_crop_idx, "NULL buffer");
   hipLaunchKernelGGL(draw_crops_kernel, dim3(capped_grid(ctx, total, 256)), dim3(256), 0, ctx->stream, d_n_frames,
-                     n_utt, first_utt, n_crops, crop_frames, seed, d_crop_idx, d_bad_count);
+                     n_utt, first_utt, d_utt_index, n_crops, crop_frames, seed, d_crop_idx, d_bad_count);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }

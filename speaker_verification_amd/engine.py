@@ -269,40 +269,53 @@ class Engine:
         return power
 
     def vad_energy(self, pcm, threshold, fs=16000, frame_ms=30, padding_ms=300, lengths=None, compact=True,
-                   want_segments=False, frame_samples=None, ring_len=None):
-        """pcm [n_utt, L] int16 -> dict(keep [n, F] u8, n_vad_frames [n] i32, voiced [n, L] i16,
-        voiced_len [n] i32, seg [n, F] i32)."""
+                   want_segments=False, frame_samples=None, ring_len=None, offsets=None):
+        """pcm [n_utt, L] int16 (or, with `offsets` + `lengths`, a 1-D concatenation of ragged clips) ->
+        dict(keep [n, F] u8, n_vad_frames [n] i32, voiced (same layout as pcm) i16, voiced_len [n] i32,
+        seg [n, F] i32)."""
         torch = _torch()
         x = self.to_device(pcm)
         if x.dtype != torch.int16:
             raise TypeError("VAD works on int16 PCM (vad.py:16-17 asserts 16-bit mono)")
-        if x.dim() == 1:
-            x = x[None]
-        n_utt, L = x.shape
         fsamp = int(frame_samples) if frame_samples else int(fs * (frame_ms / 1000.0) * 2) // 2   # vad.py:50
         ring_len = int(ring_len) if ring_len else int(padding_ms / frame_ms)                       # vad.py:81
         ring_thresh = int(math.floor(0.9 * ring_len))                    # count > 0.9 * maxlen, vad.py:99,117
-        max_vf = max(1, (2 * L - 1) // (2 * fsamp)) if L > 0 else 1
         lens = self.to_device(lengths, torch.int32) if lengths is not None else None
+        if offsets is not None:
+            if lens is None:
+                raise ValueError("offsets need lengths")
+            offs = self.to_device(offsets, torch.int64)
+            n_utt, stride = offs.numel(), 0
+            longest = int(lens.max().item()) if n_utt else 0
+        else:
+            offs = None
+            if x.dim() == 1:
+                x = x[None]
+            n_utt, stride = x.shape
+            longest = stride
+        max_vf = max(1, (2 * longest - 1) // (2 * fsamp)) if longest > 0 else 1
         keep = torch.empty((n_utt, max_vf), dtype=torch.uint8, device=self.device)
         nvf = torch.empty((n_utt,), dtype=torch.int32, device=self.device)
         seg = torch.empty((n_utt, max_vf), dtype=torch.int32, device=self.device) if want_segments else None
         voiced = torch.zeros_like(x) if compact else None
         vlen = torch.empty((n_utt,), dtype=torch.int32, device=self.device) if compact else None
         self._stream()
-        check(self.lib.svk_vad_energy(self.ctx, self._ptr(x), None, self._ptr(lens), L, L, n_utt, fsamp, ring_len,
-                                      ring_thresh, int(threshold), max_vf, self._ptr(keep), self._ptr(seg),
-                                      self._ptr(nvf), self._ptr(voiced), self._ptr(vlen)), self.ctx)
+        check(self.lib.svk_vad_energy(self.ctx, self._ptr(x), self._ptr(offs), self._ptr(lens), stride, longest, n_utt,
+                                      fsamp, ring_len, ring_thresh, int(threshold), max_vf, self._ptr(keep),
+                                      self._ptr(seg), self._ptr(nvf), self._ptr(voiced), self._ptr(vlen)), self.ctx)
         return {"keep": keep, "n_vad_frames": nvf, "voiced": voiced, "voiced_len": vlen, "seg": seg,
                 "frame_samples": fsamp}
 
-    def draw_crops(self, n_frames, n_crops=20, crop_frames=80, seed=12345, first_utt=0, bad_count=None):
-        """[n] i32 frame counts (device) -> [n, n_crops] i32 crop starts drawn on the device."""
+    def draw_crops(self, n_frames, n_crops=20, crop_frames=80, seed=12345, first_utt=0, bad_count=None,
+                   utt_index=None):
+        """[n] i32 frame counts (device) -> [n, n_crops] i32 crop starts drawn on the device, keyed by
+        the clip's global index: `utt_index[u]` if given, else first_utt + u."""
         torch = _torch()
         nf = self.to_device(n_frames, torch.int32)
+        gi = self.to_device(utt_index, torch.int64) if utt_index is not None else None
         idx = torch.empty((nf.numel(), n_crops), dtype=torch.int32, device=self.device)
         self._stream()
-        check(self.lib.svk_cube_draw_crops(self.ctx, self._ptr(nf), nf.numel(), int(first_utt), n_crops,
+        check(self.lib.svk_cube_draw_crops(self.ctx, self._ptr(nf), nf.numel(), int(first_utt), self._ptr(gi), n_crops,
                                            crop_frames, int(seed) & 0xFFFFFFFFFFFFFFFF, self._ptr(idx),
                                            self._ptr(bad_count)), self.ctx)
         return idx

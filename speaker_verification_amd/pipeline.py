@@ -127,6 +127,54 @@ class VerificationPipeline:
                               "n_frames": n_frames, "crop_idx": idx, "cube": cube})
         return (emb, inter) if return_intermediates else emb
 
+    def embed_ragged(self, clips, max_batch_samples=64 * 1024 * 1024, first_utt=0):
+        """Clips of DIFFERENT lengths (VoxCeleb1 utterances run from 4 to 145 s): `clips` is a list of 1-D
+        int16 arrays.  They are sorted by length, packed back to back (16-byte aligned) into batches of
+        at most `max_batch_samples` samples and `micro_batch` clips, and addressed through the
+        offsets / lengths form of the C-ABI, so a batch costs its own samples, not n x the longest
+        clip.  Embeddings come back in the order of `clips`.  Needs crop_rng='device'."""
+        if self.crop_rng != "device":
+            raise ValueError("embed_ragged needs crop_rng='device'")
+        order = sorted(range(len(clips)), key=lambda k: len(clips[k]))
+        emb = torch.empty((len(clips), 128), dtype=torch.float32, device=self.eng.device)
+        pos = 0
+        while pos < len(order):
+            batch, total = [], 0
+            while pos < len(order) and len(batch) < self.micro_batch:
+                n = (len(clips[order[pos]]) + 7) // 8 * 8
+                if batch and total + n > max_batch_samples:
+                    break
+                batch.append(order[pos])
+                total += n
+                pos += 1
+            buf = np.zeros((total,), dtype=np.int16)
+            offs, lens, at = [], [], 0
+            for k in batch:
+                x = np.asarray(clips[k], dtype=np.int16)
+                buf[at:at + x.size] = x
+                offs.append(at)
+                lens.append(x.size)
+                at += (x.size + 7) // 8 * 8
+            offs = np.asarray(offs, dtype=np.int64)
+            lens = np.asarray(lens, dtype=np.int32)
+            dev_buf = self.eng.to_device(buf)
+            if self.use_vad:
+                res = self.eng.vad_energy(dev_buf, self.vad_threshold, fs=c.SAMPLE_RATE, frame_ms=c.VAD_FRAME_MS,
+                                          padding_ms=c.VAD_PADDING_MS, lengths=lens, offsets=offs, compact=True)
+                dev_buf, dev_lens = res["voiced"], res["voiced_len"]
+            else:
+                dev_lens = lens
+            feat, n_frames, _ = self.eng.features(dev_buf, self.spec, lengths=dev_lens, offsets=offs,
+                                                  max_frames=self.spec.num_frames(int(lens.max())))
+            if self.normalize:
+                self.eng.cmvn_(feat, n_frames, variance=True)
+            rows = torch.as_tensor(np.asarray(batch, dtype=np.int64), device=self.eng.device)
+            # the crop draw is keyed by the clip's index in `clips`, whatever batch it landed in
+            idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, 0, self.bad_clips,
+                                      utt_index=rows + first_utt)
+            emb[rows] = self.embed_cubes(self.cubes(feat, idx))
+        return emb
+
     def embed_host(self, pcm_host, first_utt=0):
         """Host-fed variant of `embed`: `pcm_host` is a [n, L] int16 NumPy array (e.g. decoded WAVs).
         Micro-batches go through two pinned staging buffers and a copy stream, so the H2D copy of

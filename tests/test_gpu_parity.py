@@ -336,6 +336,38 @@ def test_cube_gather(eng, golden):
         np.testing.assert_array_equal(cube[u], model_ref.feature_cube(feats[u], idx[u]))
 
 
+def test_ragged_pipeline_and_vad_offsets(eng):
+    """Clips of different lengths packed back to back (offsets / lengths form of the C-ABI): VAD masks
+    equal the oracle's per clip, and embed_ragged equals embedding every clip on its own."""
+    from speaker_verification_amd.model import seeded_model
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    lens = [48000, 20011, 70000, 33333, 25000, 48000, 61234]
+    clips = [synth.speaker_clip(s, 1, n) for s, n in enumerate(lens)]
+    # VAD through offsets
+    offs, at = [], 0
+    for x in clips:
+        offs.append(at)
+        at += (x.size + 7) // 8 * 8
+    buf = np.zeros(at, dtype=np.int16)
+    for o, x in zip(offs, clips):
+        buf[o:o + x.size] = x
+    res = eng.vad_energy(buf, c.VAD_ENERGY_THRESHOLD, lengths=np.array(lens, dtype=np.int32),
+                         offsets=np.array(offs, dtype=np.int64))
+    keep, vlen, voiced = res["keep"].cpu().numpy(), res["voiced_len"].cpu().numpy(), res["voiced"].cpu().numpy()
+    for i, x in enumerate(clips):
+        k, _, v = vad_ref.vad_energy(x, 16000, 30, 300, c.VAD_ENERGY_THRESHOLD)
+        np.testing.assert_array_equal(keep[i, :k.size].astype(bool), k)
+        assert vlen[i] == v.size
+        np.testing.assert_array_equal(voiced[offs[i]:offs[i] + v.size], v)
+    # pipeline
+    pipe = VerificationPipeline(seeded_model(21, n_labels=8), use_vad=True, crop_rng="device", micro_batch=4)
+    ragged = pipe.embed_ragged(clips, first_utt=1000).cpu().numpy()
+    assert int(pipe.bad_clips.item()) == 0
+    for k, x in enumerate(clips):
+        alone = pipe.embed(x[None], first_utt=1000 + k).cpu().numpy()[0]
+        np.testing.assert_allclose(ragged[k], alone, rtol=1e-3, atol=1e-4 * np.abs(alone).max())
+
+
 def test_utils_transforms(eng, golden, monkeypatch):
     """utils.FeatureCube / CMVN / ToTensor with the reference's sample-dict protocol and RNG."""
     from speaker_verification_amd import constants, utils
