@@ -616,7 +616,7 @@ def test_siamese(eng, golden):
     lin = torch.nn.Linear(4, 3).to(eng.device)
     y = torch.tensor([1, 0, 1, 0, 1, 0, 1, 0, 1], dtype=torch.float32, device=eng.device)
     loss = sia(lin, y, o1.requires_grad_(), o2)
-    norms = [float(torch.norm(p)) for p in lin.parameters()]
+    norms = [float(torch.norm(p.detach())) for p in lin.parameters()]
     want = scoring_ref.contrastive_loss(y.cpu().numpy(), g["l2_o1"], g["l2_o2"], norms, 0.001, 2.0)
     assert float(loss) == pytest.approx(want, rel=1e-5)
     loss.backward()
