@@ -336,6 +336,28 @@ def test_cube_gather(eng, golden):
         np.testing.assert_array_equal(cube[u], model_ref.feature_cube(feats[u], idx[u]))
 
 
+def test_pipeline_properties_at_batch_scale(eng):
+    """1 024 clips through VAD -> front end -> cube -> C3D2 (BASELINE config 3 shape): bitwise repeatable,
+    a clip's embedding does not depend on its neighbours, VAD bookkeeping adds up."""
+    from speaker_verification_amd.model import seeded_model
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    pcm, _ = synth.corpus_device(1024, eng.device, utts_per_speaker=8)
+    pipe = VerificationPipeline(seeded_model(31, n_labels=8), use_vad=True, normalize=True, preemph_cof=0.98,
+                                crop_rng="device", micro_batch=512)
+    a = pipe.embed(pcm)
+    b = pipe.embed(pcm)
+    assert a.shape == (1024, 128) and torch.equal(a, b) and bool(torch.isfinite(a).all())
+    assert int(pipe.bad_clips.item()) == 0
+    half = pipe.embed(pcm[:512])                                     # same micro-batch shape, other neighbours later
+    assert torch.equal(half, a[:512])
+    solo = pipe.embed(pcm[100:101], first_utt=100)                   # batch of one: other MIOpen kernels, same maths
+    torch.testing.assert_close(solo[0], a[100], rtol=1e-3, atol=1e-4 * float(a.abs().max()))
+    res = eng.vad_energy(pcm, c.VAD_ENERGY_THRESHOLD)
+    kept = res["keep"].sum(dim=1).to(torch.int32)
+    assert torch.equal(kept * res["frame_samples"], res["voiced_len"])
+    assert int(res["voiced_len"].min()) > 81 * 160 + 400             # every clip keeps enough for a cube
+
+
 def test_ragged_pipeline_and_vad_offsets(eng):
     """Clips of different lengths packed back to back (offsets / lengths form of the C-ABI): VAD masks
     equal the oracle's per clip, and embed_ragged equals embedding every clip on its own."""
