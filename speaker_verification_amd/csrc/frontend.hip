@@ -76,6 +76,7 @@ struct FrontendParams {
   const float* dctfrag; // [n_ct][n_ft][4][64]
   int32_t n_slots, slot_base[MAX_FT];  // block (t, u) lives in slot slot_base[t] + u - chunk_lo[t]
   int32_t table_bytes, wave_bytes;     // LDS: shared tables, then one slice per wave
+  int32_t need_energy; // frame energies are consumed (c0 := log E, or d_energy given)
   int32_t n_steps; // register steps a frame reaches: ceil(flen_eff / 64), or / 128 for nfft 1024
   int32_t ablate;  // tuning only (SVK_FE_ABLATE): 1 skip staging, 2 skip the FFT loop, 4 skip mel/DCT/output
   float* feat;
@@ -366,15 +367,19 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         // Frame energy = sum over ALL nfft/2+1 power bins (feature.py:202).  By Parseval that is
         // sum(x^2)/2 + (X[0]^2 + X[nfft/2]^2) / (2 nfft), so only the bins the mel filters read
         // (k < kp) have to be untangled.
-        cplx e2 = mk(0.f, 0.f);  // (sum re^2, sum im^2): one packed fma per register
+        // (skipped altogether when nobody reads the energy: log-mel output without d_energy)
+        float ea = 0.f, eb = 0.f;
+        if (p.need_energy) {
+          cplx e2 = mk(0.f, 0.f);  // (sum re^2, sum im^2): one packed fma per register
 #pragma unroll
-        for (int a = 0; a < 8; ++a) e2 = __builtin_elementwise_fma(v[a], v[a], e2);
-        float ea = SPLIT1024 ? 0.5f * (e2.x + e2.y) : 0.5f * e2.x;
-        float eb = 0.5f * e2.y;
+          for (int a = 0; a < 8; ++a) e2 = __builtin_elementwise_fma(v[a], v[a], e2);
+          ea = SPLIT1024 ? 0.5f * (e2.x + e2.y) : 0.5f * e2.x;
+          eb = 0.5f * e2.y;
+        }
 
         fft512_wave(v, scr, lane, t1, t2);
 
-        if (lane0) {
+        if (lane0 && p.need_energy) {
           if (SPLIT1024) {  // X[0] = Re + Im, X[512] = Re - Im of Z[0]
             ea += (v[0].x * v[0].x + v[0].y * v[0].y) * (1.0f / 1024.0f);
           } else {          // X1[0], X1[256] = Re Z[0], Re Z[256];  X2: the imaginary parts
@@ -418,10 +423,12 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
             }
           }
         }
-        wave_sum2_lane63(ea, eb);  // (eb is idle for nfft 1024: its slot still hides ea's DPP wait states)
-        if (lane63) {
-          elds[fa] = ea == 0.f ? EPS64 : ea;  // feature.py:205
-          if (!SPLIT1024) elds[fa + 1] = eb == 0.f ? EPS64 : eb;
+        if (p.need_energy) {
+          wave_sum2_lane63(ea, eb);  // (eb is idle for nfft 1024: its slot still hides ea's DPP wait states)
+          if (lane63) {
+            elds[fa] = ea == 0.f ? EPS64 : ea;  // feature.py:205
+            if (!SPLIT1024) elds[fa + 1] = eb == 0.f ? EPS64 : eb;
+          }
         }
       }
       wave_sync();
@@ -794,6 +801,7 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.feat = d_feat;
   p.energy = d_energy;
   p.n_frames = d_n_frames;
+  p.need_energy = (d_energy != nullptr) || (plan->cfg.out_kind == SVK_OUT_MFCC && plan->cfg.dc_elimination);
 
   const int64_t total = (int64_t)n_utt * p.tiles_per_utt;
   // one workgroup of lds.waves waves per CU (it owns the CU's LDS); fewer when there is little work
