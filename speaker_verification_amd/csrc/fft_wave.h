@@ -67,6 +67,14 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
   return r;
 }
 
+// a * conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y): the same two instructions with other modifiers
+__device__ __forceinline__ cplx cmul_conj(cplx a, cplx b) {
+  cplx t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (a.x b.x, -a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));  // + (a.y b.y, a.y b.x)
+  return r;
+}
+
 // Forward 8-point DFT in place, natural order out: 26 packed instructions.
 __device__ __forceinline__ void dft8(cplx (&v)[8]) {
   const cplx S = mk(0.70710678118654752440f, 0.70710678118654752440f);

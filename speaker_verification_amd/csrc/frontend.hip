@@ -400,9 +400,8 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
             if (SPLIT1024) {
               // X[k] = E + W^k O  with  E = (Zk + conj Zn)/2,  O = (Zk - conj Zn)/(2i)
               // 2 E = Zk + conj Zn,  2 O = -i (Zk - conj Zn) = (zk.y + zn.y, -(zk.x - zn.x)); the 1/2's go into inv_scale
-              const cplx E2 = add_conj(zk, zn), Ot = swap_add_conj(zk, zn);  // Ot = (O2.x, -O2.y)
-              const cplx O2 = mk(Ot.x, -Ot.y);
-              cplx xp = E2 + cmul(t3[j], O2);
+              const cplx E2 = add_conj(zk, zn), Ot = swap_add_conj(zk, zn);  // Ot = conj(2 O)
+              cplx xp = E2 + cmul_conj(t3[j], Ot);
               xp *= xp;
               const float pk = (xp.x + xp.y) * (0.25f * inv_scale);
               if (64 * (j + 1) <= p.kp) rowa[k] = pk;  // wave-uniform: no exec masking
