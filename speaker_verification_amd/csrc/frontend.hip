@@ -6,26 +6,31 @@
 //   processing.py:142-174 (|rfft|^2 / nfft)       feature.py:202-205 (frame energy, 0 -> eps)
 //   feature.py:216-217 (mel projection, 0 -> eps) feature.py:146-153 (log, DCT-II ortho, c0 := log E)
 //
-// Work decomposition: one workgroup per CU, as many waves as LDS allows (up to 16); the
+// Work decomposition: one workgroup per CU, as many waves as LDS allows (up to 12); the
 // workgroup copies the filterbank / DCT operand fragments into LDS once (they are re-read
 // for every tile: fetching them from L2 per tile cost 4x the PCM traffic and its latency),
-// then every wave works on its own: it owns a TILE of 8 or 16 consecutive frames of one
+// then every wave works on its own: it owns a TILE of 8 (or 16) consecutive frames of one
 // clip, a private LDS slice, and loops over tiles with no further workgroup barrier.
-//   1. the tile's sample span is read from HBM once with 16-byte loads, pre-emphasised
-//      in flight and parked in LDS as f32 (frames overlap, so each sample feeds 2+ frames);
+//   1. the tile's sample span is read from HBM once with 16-byte loads issued back to back and
+//      parked in LDS -- int16 clips as raw int16 (pre-emphasis x[n] - c x[n-1] is applied when a
+//      frame is read), float clips or an unusual pre-emphasis shift as pre-emphasised f32;
 //   2. a 512-point complex FFT runs across the wave: 8 points per lane, three radix-8
-//      passes in registers, two transposes through a padded (bank-conflict-free) LDS
-//      scratch.  nfft = 512 packs TWO real frames into one complex FFT; nfft = 1024 packs
-//      the even/odd samples of ONE frame.  The untangle step pairs bin k with bin N-k,
-//      which lives in lane 64-l: one wave shuffle per register, no LDS;
-//   3. the low power bins that the mel filters touch go to a [16 x KP] LDS tile, the
-//      frame energy is a wave reduction over all bins;
+//      passes in registers on packed-f32 instructions (fft_wave.h), two transposes through a
+//      padded (bank-conflict-free) LDS scratch.  nfft = 512 packs TWO real frames into one
+//      complex FFT; nfft = 1024 packs the even/odd samples of ONE frame.  The untangle step
+//      pairs bin k with bin N-k, which lives in lane 64-l: one wave shuffle per register, no
+//      LDS, and only for the bins the mel filters read;
+//   3. those power bins go to a [TILE x KP] LDS tile; the frame energy (all bins) comes from
+//      Parseval's identity and a DPP wave reduction, and only when something consumes it;
 //   4. mel energies^T = filterbank x P^T on v_mfma_f32_16x16x4_f32 (exact f32), skipping
 //      the 16-bin chunks where a 16-filter tile is identically zero (Q2: the bank is
 //      ~97 % zeros);  log;  the accumulator layout of that product is exactly the B
 //      operand layout of the next one, so cepstra^T = DCT x log(mel)^T follows with no
 //      data movement;
 //   5. results go straight to HBM.
+// (v_mfma_f32_4x4x1_16b_f32, which could follow the bank's sparsity filter group by filter
+// group, was measured at 15 cycles per instruction = half the MAC rate of 16x16x4:
+// tools/probes/mfma4x4_probe.hip -- not worth it.)
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
