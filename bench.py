@@ -401,8 +401,12 @@ def main():
         result["cosine_mfma"] = cosine_mfma_bench(eng, torch)
         if args.cpu_sample > 0:
             ns = min(args.cpu_sample, n_local)
-            # every (n_local // ns)-th clip of the shard, so that the sample spans several speakers
-            pick = np.arange(ns) * max(1, n_local // ns)
+            # three utterances each of ns/3 speakers spread over the shard (the last one enrols, Q17)
+            n_spk_s = max(1, ns // 3)
+            spk_step = max(1, (n_local // UTTS_PER_SPK) // n_spk_s)
+            pick = np.array([min(n_local - 1, (k * spk_step) * UTTS_PER_SPK + u) for k in range(n_spk_s)
+                             for u in range(3)], dtype=np.int64)
+            ns = pick.size
             sample = pcm[torch.from_numpy(pick).to(dev)]
             emb, inter = pipe.embed(sample, return_intermediates=True)
             crops = np.zeros((ns, c.CUBE_CROPS), dtype=np.int32)
