@@ -72,8 +72,9 @@ def main():
             rec["hbm_read_bytes_per_launch"] = 2.0 * rec["FETCH_SIZE"] * 1024.0
             rec["hbm_write_bytes_per_launch"] = rec["WRITE_SIZE"] * 1024.0
             rec["hbm_traffic_bytes_per_launch"] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in rec and "SQ_BUSY_CYCLES" in rec and rec["SQ_BUSY_CYCLES"]:
-            rec["mfma_busy_over_sq_busy"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] / rec["SQ_BUSY_CYCLES"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in rec and rec.get("duration_ns_pmc_sq"):
+            # the counter sums busy cycles over the chip's 1024 SIMDs; 2.4 GHz is the nominal engine clock
+            rec["mfma_busy_fraction"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * 2.4 * rec["duration_ns_pmc_sq"])
         if "SQ_LDS_BANK_CONFLICT" in rec and rec.get("SQ_LDS_IDX_ACTIVE"):
             rec["lds_conflict_fraction"] = rec["SQ_LDS_BANK_CONFLICT"] / rec["SQ_LDS_IDX_ACTIVE"]
         result[k] = rec
