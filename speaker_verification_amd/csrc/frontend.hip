@@ -213,51 +213,95 @@ __device__ __forceinline__ void wave_sum2_lane63(float& a, float& b) {
 // before the last are read unconditionally, the last one clamps its address and masks, the
 // rest are the zero padding up to nfft (Q6).  Straight-line code: per-lane `if (n < frame_len)`
 // around every read cost 28 exec-mask branches and as many serialised LDS round trips per FFT.
+typedef const volatile __attribute__((address_space(3))) int16_t* lds_i16p;  // volatile needs the LDS address space spelled out
+typedef const volatile __attribute__((address_space(3))) int* lds_i32p;
 template <bool SPLIT1024, bool RAW16>
 struct FrameReader {
   const float* sig;
   const int16_t* sigh;
   int off_a, off_b, flen;
-  bool pre;
   float cof;
   bool hasb;
   int lane;
 
+  // PRE is a template parameter, not a select: with the LDS read of x[n-1] inside a `pre ? :`
+  // arm the compiler emitted a branch per sample, each read followed by its own s_waitcnt
+  // (20 serialised LDS round trips per FFT); straight-line code batches the reads.  The raw
+  // samples are read through a volatile pointer so that x[n-1], x[n] are NOT merged into one
+  // 2-byte-misaligned ds_read_b32 (measured: the merged form made the nfft-1024 kernel 16 % slower).
+  template <bool PRE>
   __device__ __forceinline__ float sample(int off, int idx) const {
     if constexpr (RAW16) {
-      const int16_t* s = sigh + RAW_OFF + off + idx;
+      const lds_i16p s = (lds_i16p)(sigh + RAW_OFF + off + idx);
       const float x0 = (float)s[0];
-      return pre ? x0 - cof * (float)s[-1] : x0;  // x[n] - c x[n-1] (shift 1), Q5
+      if constexpr (PRE) return x0 - cof * (float)s[-1];  // x[n] - c x[n-1] (shift 1), Q5
+      return x0;
     } else {
       return sig[off + idx];
     }
   }
 
-  template <int NSTEPS>
+  // Samples idx, idx + 1 (idx even) of the even/odd packing.  ALIGNED: the pair sits on a 4-byte
+  // boundary (even hop), one ds_read_b32; the sample before it is one more 2-byte read.
+  template <bool PRE, bool ALIGNED>
+  __device__ __forceinline__ cplx pair(int off, int idx) const {
+    if constexpr (RAW16) {
+      const lds_i16p s = (lds_i16p)(sigh + RAW_OFF + off + idx);
+      float x0, x1;
+      if constexpr (ALIGNED) {
+        const int w = *(lds_i32p)s;
+        x0 = (float)(short)w;
+        x1 = (float)(w >> 16);
+      } else {
+        x0 = (float)s[0];
+        x1 = (float)s[1];
+      }
+      if constexpr (PRE) return mk(x0 - cof * (float)s[-1], x1 - cof * x0);
+      return mk(x0, x1);
+    } else {
+      return mk(sig[off + idx], sig[off + idx + 1]);
+    }
+  }
+
+  template <int NSTEPS, bool PRE, bool ALIGNED>
   __device__ __forceinline__ void read(cplx (&v)[8]) const {
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
       const int first = SPLIT1024 ? 2 * (lane + 64 * a) : lane + 64 * a;
       if (a + 1 < NSTEPS) {
         if (SPLIT1024) {
-          v[a] = mk(sample(off_a, first), sample(off_a, first + 1));
+          v[a] = pair<PRE, ALIGNED>(off_a, first);
         } else {
-          const float yb = sample(off_b, first);
-          v[a] = mk(sample(off_a, first), hasb ? yb : 0.f);
+          const float yb = sample<PRE>(off_b, first);
+          v[a] = mk(sample<PRE>(off_a, first), hasb ? yb : 0.f);
         }
       } else if (a + 1 == NSTEPS) {
         if (SPLIT1024) {
-          const bool in0 = first < flen, in1 = first + 1 < flen;
-          const float x0 = sample(off_a, in0 ? first : 0), x1 = sample(off_a, in1 ? first + 1 : 0);
-          v[a] = mk(in0 ? x0 : 0.f, in1 ? x1 : 0.f);
+          const bool in0 = first < flen, in1 = first + 1 < flen;  // the sample after the frame is staged or slack: finite, masked
+          const cplx y = pair<PRE, ALIGNED>(off_a, in0 ? first : 0);
+          v[a] = mk(in0 ? y.x : 0.f, in1 ? y.y : 0.f);
         } else {
           const bool in = first < flen;
-          const float xa = sample(off_a, in ? first : 0), xb = sample(off_b, in ? first : 0);
+          const float xa = sample<PRE>(off_a, in ? first : 0), xb = sample<PRE>(off_b, in ? first : 0);
           v[a] = mk(in ? xa : 0.f, (in && hasb) ? xb : 0.f);
         }
       } else {
         v[a] = mk(0.f, 0.f);
       }
+    }
+  }
+
+  template <bool PRE, bool ALIGNED>
+  __device__ __forceinline__ void read_steps(int n_steps, cplx (&v)[8]) const {
+    switch (n_steps) {  // wave-uniform; each case is straight-line code
+      case 1: read<1, PRE, ALIGNED>(v); break;
+      case 2: read<2, PRE, ALIGNED>(v); break;
+      case 3: read<3, PRE, ALIGNED>(v); break;
+      case 4: read<4, PRE, ALIGNED>(v); break;
+      case 5: read<5, PRE, ALIGNED>(v); break;
+      case 6: read<6, PRE, ALIGNED>(v); break;
+      case 7: read<7, PRE, ALIGNED>(v); break;
+      default: read<8, PRE, ALIGNED>(v); break;
     }
   }
 };
@@ -357,16 +401,14 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         const bool hasb = !SPLIT1024 && fa + 1 < nvalid;
         {
           const FrameReader<SPLIT1024, RAW16> rd{sig, sigh, fa * p.stride, (hasb ? fa + 1 : fa) * p.stride, p.flen_eff,
-                                                 RAW16 && p.preemph != 0, p.pre_cof, hasb, lane};
-          switch (p.n_steps) {  // wave-uniform; each case is straight-line code
-            case 1: rd.template read<1>(v); break;
-            case 2: rd.template read<2>(v); break;
-            case 3: rd.template read<3>(v); break;
-            case 4: rd.template read<4>(v); break;
-            case 5: rd.template read<5>(v); break;
-            case 6: rd.template read<6>(v); break;
-            case 7: rd.template read<7>(v); break;
-            default: rd.template read<8>(v); break;
+                                                 p.pre_cof, hasb, lane};
+          const bool pre = RAW16 && p.preemph != 0;
+          if (SPLIT1024 && RAW16 && ((fa * p.stride) & 1) == 0) {  // RAW_OFF is even: the pairs are 4-byte aligned
+            if (pre) rd.template read_steps<true, true>(p.n_steps, v);
+            else rd.template read_steps<false, true>(p.n_steps, v);
+          } else {
+            if (pre) rd.template read_steps<true, false>(p.n_steps, v);
+            else rd.template read_steps<false, false>(p.n_steps, v);
           }
         }
         // Frame energy = sum over ALL nfft/2+1 power bins (feature.py:202).  By Parseval that is
