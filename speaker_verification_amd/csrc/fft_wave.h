@@ -119,6 +119,54 @@ __device__ __forceinline__ void fft512_wave(cplx (&v)[8], cplx* scr, int lane, c
   dft8(v);
 }
 
+// Two independent transforms through ONE scratch, software-pipelined: while the LDS round trip
+// of one transform's transpose is in flight the other transform's radix-8 pass issues.  With 3
+// waves per SIMD the other waves alone do not cover those round trips.  Sharing the scratch is
+// safe because the LDS unit executes one wave's DS instructions in program order: b's transpose
+// writes are issued after a's transpose reads and therefore land after them.
+__device__ __forceinline__ void fft512_wave_x2(cplx (&a)[8], cplx (&b)[8], cplx* scr, int lane, const cplx (&t1)[8],
+                                               const cplx (&t2)[8]) {
+  const int r2 = lane >> 3, p = lane & 7;
+  dft8(a);
+#pragma unroll
+  for (int r = 1; r < 8; ++r) a[r] = cmul(a[r], t1[r]);
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) scr[r * 72 + lane] = a[r];
+  wave_sync();
+#pragma unroll
+  for (int c = 0; c < 8; ++c) a[c] = scr[r2 * 72 + 8 * c + p];
+  dft8(b);
+#pragma unroll
+  for (int r = 1; r < 8; ++r) b[r] = cmul(b[r], t1[r]);
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) scr[r * 72 + lane] = b[r];
+  wave_sync();
+#pragma unroll
+  for (int c = 0; c < 8; ++c) b[c] = scr[r2 * 72 + 8 * c + p];
+  dft8(a);
+#pragma unroll
+  for (int r = 1; r < 8; ++r) a[r] = cmul(a[r], t2[r]);
+  wave_sync();
+#pragma unroll
+  for (int r1 = 0; r1 < 8; ++r1) scr[(8 * r1 + r2) * 9 + p] = a[r1];
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) a[q] = scr[lane * 9 + q];
+  dft8(b);
+#pragma unroll
+  for (int r = 1; r < 8; ++r) b[r] = cmul(b[r], t2[r]);
+  wave_sync();
+#pragma unroll
+  for (int r1 = 0; r1 < 8; ++r1) scr[(8 * r1 + r2) * 9 + p] = b[r1];
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) b[q] = scr[lane * 9 + q];
+  dft8(a);
+  dft8(b);
+}
+
 // Partner of bin k = lane + 64 j is bin 512 - k: register 7 - j of lane 64 - lane; lane 0
 // pairs with itself one register later (bin 64 j <-> bin 64 (8 - j)).
 __device__ __forceinline__ cplx shfl2(cplx v, int src) { return mk(__shfl(v.x, src, 64), __shfl(v.y, src, 64)); }

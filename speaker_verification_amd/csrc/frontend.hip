@@ -138,34 +138,28 @@ __device__ __forceinline__ void stage_span(const FrontendParams& p, const PcmT* 
 // half the LDS of the f32 form) and pre-emphasise when a frame is read: x[n] - c * x[n-1] needs
 // one extra sample in front of the span (the clip's LAST sample when the span starts the clip:
 // np.roll wraps, Q5).
-__device__ __forceinline__ void stage_raw16(const FrontendParams& p, const int16_t* x, int64_t s0, int need, int len,
-                                            int16_t* sigh, int lane) {
+__device__ __forceinline__ void stage_raw16(bool pre, const int16_t* x, int64_t s0, int need, int len, int16_t* sigh,
+                                            int lane) {
   typedef short vec_t __attribute__((ext_vector_type(8)));
   constexpr int NV = 3;  // 16-byte loads in flight per lane: an 8-frame tile at a 160-sample hop is 3 x 512 samples
-  const bool fast = (reinterpret_cast<uintptr_t>(x + s0) & 15) == 0 && len - s0 >= 8;
-  if (lane == 0 && p.preemph) sigh[RAW_OFF - 1] = s0 == 0 ? x[len - 1] : x[s0 - 1];
-  if (fast) {
+  if (lane == 0 && pre) sigh[RAW_OFF - 1] = s0 == 0 ? x[len - 1] : x[s0 - 1];
+  // wave-uniform: the span starts on a 16-byte boundary and its last vector ends inside the clip
+  // (every tile of a clip but possibly the last one), so no load needs patching
+  const bool whole = (reinterpret_cast<uintptr_t>(x + s0) & 15) == 0 && s0 + ((need + 7) & ~7) <= len;
+  if (whole) {
     for (int base = 0; base < need; base += NV * 512) {
       vec_t raw[NV];
       // all loads first (a load per loop trip followed by its own wait cost one HBM round trip EACH) ...
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         const int i = base + k * 512 + lane * 8;
-        const bool full = i < need && s0 + i + 8 <= len;
-        raw[k] = *reinterpret_cast<const vec_t*>(x + (full ? s0 + i : s0));  // clamped: always a valid aligned address
+        raw[k] = *reinterpret_cast<const vec_t*>(x + s0 + (i < need ? i : 0));  // clamped: always a valid aligned address
       }
-      // ... then the LDS writes; a clip that ends inside a vector is patched sample by sample (rare)
+      // ... then the LDS writes
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         const int i = base + k * 512 + lane * 8;
-        if (i < need) {
-          vec_t v = raw[k];
-          if (s0 + i + 8 > len) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = s0 + i + e < len ? x[s0 + i + e] : (short)0;
-          }
-          *reinterpret_cast<vec_t*>(sigh + RAW_OFF + i) = v;
-        }
+        if (i < need) *reinterpret_cast<vec_t*>(sigh + RAW_OFF + i) = raw[k];
       }
     }
   } else {
@@ -318,14 +312,46 @@ __device__ __forceinline__ float fast_log(float x) {
     return __logf(x);
 }
 
-template <typename PcmT, bool SPLIT1024, int TILE, bool RAW16>
+// Spec: configuration values fixed at compile time (>= 0) or read from the launch parameters (-1).
+// The generic kernel (every field -1) serves any plan; the two standard front ends get an instance
+// with their framing and output shape folded in, which removes the per-frame dispatch branches,
+// most scalar bookkeeping and the scalar-register spills that came with it.
+struct SpecGeneric {
+  static constexpr int STRIDE = -1, FLEN = -1, N_STEPS = -1, PRE = -1, KP = -1, NEED_ENERGY = -1, N_FT = -1, N_CT = -1,
+                       OUT_KIND = -1, NFILT = -1, NCOLS = -1, DC_ELIM = -1;
+};
+// speechpy.feature.mfcc(fs 16 kHz, 20 ms / 10 ms, 40 filters, 13 cepstra, nfft 512) after pre-emphasis
+struct SpecMfcc13 {
+  static constexpr int STRIDE = 160, FLEN = 320, N_STEPS = 5, PRE = 1, KP = 128, NEED_ENERGY = 1, N_FT = 3, N_CT = 1,
+                       OUT_KIND = SVK_OUT_MFCC, NFILT = 40, NCOLS = 13, DC_ELIM = 1;
+};
+// the model's front end: lmfe(25 ms / 10 ms, 40 filters, nfft 1024) after pre-emphasis (load_data.py:64-70)
+struct SpecLmfe40 {
+  static constexpr int STRIDE = 160, FLEN = 400, N_STEPS = 4, PRE = 1, KP = 256, NEED_ENERGY = 0, N_FT = 3, N_CT = 0,
+                       OUT_KIND = SVK_OUT_LMFE, NFILT = 40, NCOLS = 40, DC_ELIM = 0;
+};
+
+template <typename PcmT, bool SPLIT1024, int TILE, bool RAW16, typename Spec>
 __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
+  const int c_stride = Spec::STRIDE >= 0 ? Spec::STRIDE : p.stride;
+  const int c_flen = Spec::FLEN >= 0 ? Spec::FLEN : p.flen;
+  const int c_flen_eff = Spec::FLEN >= 0 ? Spec::FLEN : p.flen_eff;
+  const int c_n_steps = Spec::N_STEPS >= 0 ? Spec::N_STEPS : p.n_steps;
+  const int c_preemph = Spec::PRE >= 0 ? Spec::PRE : p.preemph;
+  const int c_kp = Spec::KP >= 0 ? Spec::KP : p.kp;
+  const int c_need_energy = Spec::NEED_ENERGY >= 0 ? Spec::NEED_ENERGY : p.need_energy;
+  const int c_n_ft = Spec::N_FT >= 0 ? Spec::N_FT : p.n_ft;
+  const int c_n_ct = Spec::N_CT >= 0 ? Spec::N_CT : p.n_ct;
+  const int c_out_kind = Spec::OUT_KIND >= 0 ? Spec::OUT_KIND : p.out_kind;
+  const int c_nfilt = Spec::NFILT >= 0 ? Spec::NFILT : p.nfilt;
+  const int c_ncols = Spec::NCOLS >= 0 ? Spec::NCOLS : p.ncols;
+  const int c_dc_elim = Spec::DC_ELIM >= 0 ? Spec::DC_ELIM : p.dc_elim;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // shared by the workgroup: mel and DCT operand fragments
   f32x4* fb_lds = reinterpret_cast<f32x4*>(smem);
   float* dct_lds = reinterpret_cast<float*>(smem + (size_t)p.n_slots * 64 * sizeof(f32x4));
   for (int i = threadIdx.x; i < p.n_slots * 64; i += blockDim.x) fb_lds[i] = p.fbfrag[i];
-  for (int i = threadIdx.x; i < p.n_ct * p.n_ft * 4 * 64; i += blockDim.x) dct_lds[i] = p.dctfrag[i];
+  for (int i = threadIdx.x; i < c_n_ct * c_n_ft * 4 * 64; i += blockDim.x) dct_lds[i] = p.dctfrag[i];
   __syncthreads();  // the only workgroup-wide barrier; from here on waves never wait for each other
   // private to this wave
   // the wave index is uniform: say so, or every per-tile index computation lands on the VALU
@@ -334,7 +360,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
   float* sig = reinterpret_cast<float*>(mine);
   int16_t* sigh = reinterpret_cast<int16_t*>(mine);
   float* ptile = reinterpret_cast<float*>(mine + p.sig_bytes);
-  const int prow = p.kp + PT_PAD;
+  const int prow = c_kp + PT_PAD;
   cplx* scr = reinterpret_cast<cplx*>(ptile + TILE * prow);
   float* elds = reinterpret_cast<float*>(scr + SCR);
   const int lane_id = threadIdx.x & 63;
@@ -376,57 +402,56 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
     if (p.offsets) off = p.offsets[utt];
     int len = p.clip_len;
     if (p.lengths) len = p.lengths[utt];
-    const int T = len >= p.flen ? (len - p.flen) / p.stride : 0;  // processing.py:115-116 (Q3)
+    const int T = len >= c_flen ? (len - c_flen) / c_stride : 0;  // processing.py:115-116 (Q3)
     if (f0 == 0 && lane0 && p.n_frames) p.n_frames[utt] = T < p.max_frames ? T : p.max_frames;
     int nvalid = T - f0;
     nvalid = nvalid > TILE ? TILE : nvalid;
     if (f0 + nvalid > p.max_frames) nvalid = p.max_frames - f0;
-    float* out_rows = p.feat + ((int64_t)utt * p.max_frames + f0) * p.ncols;
+    float* out_rows = p.feat + ((int64_t)utt * p.max_frames + f0) * c_ncols;
 
     if (nvalid > 0) {
       const PcmT* x = reinterpret_cast<const PcmT*>(p.pcm) + off;
-      const int need = (nvalid - 1) * p.stride + p.flen_eff;
+      const int need = (nvalid - 1) * c_stride + c_flen_eff;
       wave_sync();  // previous tile's readers of sig / ptile are done
       if (SVK_ABLATE(p, 1)) {
       } else if constexpr (RAW16)
-        stage_raw16(p, reinterpret_cast<const int16_t*>(x), (int64_t)f0 * p.stride, need, len, sigh, lane);
+        stage_raw16(c_preemph != 0, reinterpret_cast<const int16_t*>(x), (int64_t)f0 * c_stride, need, len, sigh, lane);
       else
-        stage_span<PcmT>(p, x, (int64_t)f0 * p.stride, need, len, sig, lane);
+        stage_span<PcmT>(p, x, (int64_t)f0 * c_stride, need, len, sig, lane);
       wave_sync();
 
       // ---- spectra -----------------------------------------------------------
+      // Two transforms per trip (4 frames at nfft 512, 2 at nfft 1024), pipelined through the one
+      // scratch (fft512_wave_x2).  A missing second transform (ragged last tile of a clip) redoes
+      // the first and drops the result: one code path.
       constexpr int FR_PER_FFT = SPLIT1024 ? 1 : 2;
-      for (int fa = 0; fa < (SVK_ABLATE(p, 2) ? 0 : nvalid); fa += FR_PER_FFT) {
-        cplx v[8];
-        const bool hasb = !SPLIT1024 && fa + 1 < nvalid;
-        {
-          const FrameReader<SPLIT1024, RAW16> rd{sig, sigh, fa * p.stride, (hasb ? fa + 1 : fa) * p.stride, p.flen_eff,
-                                                 p.pre_cof, hasb, lane};
-          const bool pre = RAW16 && p.preemph != 0;
-          if (SPLIT1024 && RAW16 && ((fa * p.stride) & 1) == 0) {  // RAW_OFF is even: the pairs are 4-byte aligned
-            if (pre) rd.template read_steps<true, true>(p.n_steps, v);
-            else rd.template read_steps<false, true>(p.n_steps, v);
-          } else {
-            if (pre) rd.template read_steps<true, false>(p.n_steps, v);
-            else rd.template read_steps<false, false>(p.n_steps, v);
-          }
+      const bool pre = RAW16 && c_preemph != 0;
+      auto load = [&](int f, cplx (&v)[8], float& ea, float& eb) {
+        const bool hasb = !SPLIT1024 && f + 1 < nvalid;
+        const FrameReader<SPLIT1024, RAW16> rd{sig, sigh, f * c_stride, (hasb ? f + 1 : f) * c_stride, c_flen_eff,
+                                               p.pre_cof, hasb, lane};
+        if (SPLIT1024 && RAW16 && ((f * c_stride) & 1) == 0) {  // RAW_OFF is even: the pairs are 4-byte aligned
+          if (pre) rd.template read_steps<true, true>(c_n_steps, v);
+          else rd.template read_steps<false, true>(c_n_steps, v);
+        } else {
+          if (pre) rd.template read_steps<true, false>(c_n_steps, v);
+          else rd.template read_steps<false, false>(c_n_steps, v);
         }
         // Frame energy = sum over ALL nfft/2+1 power bins (feature.py:202).  By Parseval that is
         // sum(x^2)/2 + (X[0]^2 + X[nfft/2]^2) / (2 nfft), so only the bins the mel filters read
         // (k < kp) have to be untangled.
         // (skipped altogether when nobody reads the energy: log-mel output without d_energy)
-        float ea = 0.f, eb = 0.f;
-        if (p.need_energy) {
+        ea = 0.f, eb = 0.f;
+        if (c_need_energy) {
           cplx e2 = mk(0.f, 0.f);  // (sum re^2, sum im^2): one packed fma per register
 #pragma unroll
           for (int a = 0; a < 8; ++a) e2 = __builtin_elementwise_fma(v[a], v[a], e2);
           ea = SPLIT1024 ? 0.5f * (e2.x + e2.y) : 0.5f * e2.x;
           eb = 0.5f * e2.y;
         }
-
-        fft512_wave(v, scr, lane, t1, t2);
-
-        if (lane0 && p.need_energy) {
+      };
+      auto finish = [&](int f, cplx (&v)[8], float ea, float eb) {
+        if (lane0 && c_need_energy) {
           if (SPLIT1024) {  // X[0] = Re + Im, X[512] = Re - Im of Z[0]
             ea += (v[0].x * v[0].x + v[0].y * v[0].y) * (1.0f / 1024.0f);
           } else {          // X1[0], X1[256] = Re Z[0], Re Z[256];  X2: the imaginary parts
@@ -434,12 +459,12 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
             eb += (v[0].y * v[0].y + v[4].y * v[4].y) * (1.0f / 1024.0f);
           }
         }
-        float* rowa = ptile + fa * prow;
-        float* rowb = rowa + prow;
+        float* rowa = ptile + f * prow;
+        float* rowb = rowa + prow;  // (a lone last frame writes its zero partner into a row >= nvalid of the tile: masked at the output)
         cplx carry = v[0];  // lane 0 pairs bin 64 j with bin 64 (8 - j): one register later
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (64 * j < p.kp) {
+          if (64 * j < c_kp) {
             const cplx sm = shfl2(v[7 - j], mirror);
             const cplx zk = v[j], zn = lane0 ? carry : sm;
             carry = sm;
@@ -451,31 +476,42 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
               cplx xp = E2 + cmul_conj(t3[j], Ot);
               xp *= xp;
               const float pk = (xp.x + xp.y) * (0.25f * inv_scale);
-              if (64 * (j + 1) <= p.kp) rowa[k] = pk;  // wave-uniform: no exec masking
-              else if (k < p.kp) rowa[k] = pk;         // ragged last step only
+              if (64 * (j + 1) <= c_kp) rowa[k] = pk;  // wave-uniform: no exec masking
+              else if (k < c_kp) rowa[k] = pk;         // ragged last step only
             } else {
               // 2 X1 = Zk + conj Zn,  2i X2 = Zk - conj Zn  (|.|^2 is what matters)
               cplx xa = add_conj(zk, zn), xb = swap_add_conj(zk, zn);
               xa *= xa;
               xb *= xb;
               const float pa = (xa.x + xa.y) * inv_scale, pb = (xb.x + xb.y) * inv_scale;
-              if (64 * (j + 1) <= p.kp) {  // wave-uniform: no exec masking
+              if (64 * (j + 1) <= c_kp) {  // wave-uniform: no exec masking
                 rowa[k] = pa;
                 rowb[k] = pb;
-              } else if (k < p.kp) {       // ragged last step only
+              } else if (k < c_kp) {       // ragged last step only
                 rowa[k] = pa;
                 rowb[k] = pb;
               }
             }
           }
         }
-        if (p.need_energy) {
+        if (c_need_energy) {
           wave_sum2_lane63(ea, eb);  // (eb is idle for nfft 1024: its slot still hides ea's DPP wait states)
           if (lane63) {
-            elds[fa] = ea == 0.f ? EPS64 : ea;  // feature.py:205
-            if (!SPLIT1024) elds[fa + 1] = eb == 0.f ? EPS64 : eb;
+            elds[f] = ea == 0.f ? EPS64 : ea;  // feature.py:205
+            if (!SPLIT1024) elds[f + 1] = eb == 0.f ? EPS64 : eb;
           }
         }
+      };
+      for (int fa = 0; fa < (SVK_ABLATE(p, 2) ? 0 : nvalid); fa += 2 * FR_PER_FFT) {
+        const bool two = fa + FR_PER_FFT < nvalid;  // wave-uniform
+        const int fb = two ? fa + FR_PER_FFT : fa;
+        cplx va[8], vb[8];
+        float eaa, eba, eab, ebb;
+        load(fa, va, eaa, eba);
+        load(fb, vb, eab, ebb);
+        fft512_wave_x2(va, vb, scr, lane, t1, t2);
+        finish(fa, va, eaa, eba);
+        if (two) finish(fb, vb, eab, ebb);
       }
       wave_sync();
 
@@ -487,7 +523,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
       for (int t = 0; t < MAX_FT; ++t) {
         // two accumulators per filter tile: back-to-back MFMAs never wait on their own result
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-        if (t < p.n_ft && !SVK_ABLATE(p, 8)) {
+        if (t < c_n_ft && !SVK_ABLATE(p, 8)) {
           const f32x4* frag = fb_lds + (p.slot_base[t] - p.chunk_lo[t]) * 64 + lane;
           for (int u = p.chunk_lo[t]; u < p.chunk_hi[t]; u += 2) {  // the plan makes every chunk range even
             const f32x4 a0 = frag[u * 64], a1 = frag[(u + 1) * 64];
@@ -508,45 +544,45 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
       if (SVK_ABLATE(p, 32)) continue;
       // lane (jf, g) now holds mel[filter 16 t + 4 g + reg][frame jf]
       const bool row_ok = jf < nvalid;
-      float* orow = out_rows + (int64_t)jf * p.ncols;
+      float* orow = out_rows + (int64_t)jf * c_ncols;
 #pragma unroll
       for (int t = 0; t < MAX_FT; ++t) {
-        if (t < p.n_ft) {  // wave-uniform: an absent filter tile costs nothing
+        if (t < c_n_ft) {  // wave-uniform: an absent filter tile costs nothing
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float m = acc[t][r];
             m = m == 0.f ? EPS64 : m;  // feature.py:217
-            if (p.out_kind != SVK_OUT_MFE) {
+            if (c_out_kind != SVK_OUT_MFE) {
               m = fast_log<INT_PCM>(m);
-              if (16 * t + 12 + 3 >= p.nfilt) m = (16 * t + 4 * g + r) < p.nfilt ? m : 0.f;  // only the ragged last tile
+              if (16 * t + 12 + 3 >= c_nfilt) m = (16 * t + 4 * g + r) < c_nfilt ? m : 0.f;  // only the ragged last tile
             }
             acc[t][r] = m;
           }
         }
       }
-      if (p.out_kind != SVK_OUT_MFCC) {
+      if (c_out_kind != SVK_OUT_MFCC) {
 #pragma unroll
         for (int t = 0; t < MAX_FT; ++t) {
           const int filt = 16 * t + 4 * g;
-          if (row_ok && t < p.n_ft) {
-            if ((p.ncols & 3) == 0 && filt + 3 < p.nfilt) {
+          if (row_ok && t < c_n_ft) {
+            if ((c_ncols & 3) == 0 && filt + 3 < c_nfilt) {
               *reinterpret_cast<f32x4*>(orow + filt) = acc[t];
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                if (filt + r < p.nfilt) orow[filt + r] = acc[t][r];
+                if (filt + r < c_nfilt) orow[filt + r] = acc[t][r];
             }
           }
         }
       } else {
         // ---- cepstra^T = DCT x log(mel)^T: acc[t][r] is already the B operand ------
         const float le = fast_log<INT_PCM>(elds[jf & (TILE - 1)]);
-        for (int c = 0; c < (SVK_ABLATE(p, 16) ? 0 : p.n_ct); ++c) {  // runtime loop: keeps the table loads of one cepstral tile in flight, not four
+        for (int c = 0; c < (SVK_ABLATE(p, 16) ? 0 : c_n_ct); ++c) {  // runtime loop: keeps the table loads of one cepstral tile in flight, not four
           f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-          const float* dfrag = dct_lds + c * p.n_ft * 4 * 64 + lane;
+          const float* dfrag = dct_lds + c * c_n_ft * 4 * 64 + lane;
 #pragma unroll
           for (int t = 0; t < MAX_FT; ++t) {
-            if (t < p.n_ft) {
+            if (t < c_n_ft) {
 #pragma unroll
               for (int r = 0; r < 4; ++r)
                 o = __builtin_amdgcn_mfma_f32_16x16x4f32(dfrag[(t * 4 + r) * 64], acc[t][r], o, 0, 0, 0);
@@ -555,7 +591,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int cep = 16 * c + 4 * g + r;
-            if (row_ok && cep < p.ncols) orow[cep] = (cep == 0 && p.dc_elim) ? le : o[r];  // feature.py:151-152
+            if (row_ok && cep < c_ncols) orow[cep] = (cep == 0 && c_dc_elim) ? le : o[r];  // feature.py:151-152
           }
         }
       }
@@ -567,7 +603,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
     int last = p.max_frames - f0;
     last = last > TILE ? TILE : last;
     if (SVK_ABLATE(p, 64)) continue;
-    for (int i = first_bad * p.ncols + lane; i < last * p.ncols; i += 64) out_rows[i] = 0.f;
+    for (int i = first_bad * c_ncols + lane; i < last * c_ncols; i += 64) out_rows[i] = 0.f;
     if (p.energy)
       for (int i = first_bad + lane; i < last; i += 64) p.energy[(int64_t)utt * p.max_frames + f0 + i] = 0.f;
   }
@@ -616,8 +652,19 @@ LdsLayout lds_layout(const svk_frontend_plan* plan, int tile, bool raw16, int ld
 
 template <typename PcmT, bool RAW16>
 void (*pick_kernel(bool split, int tile))(const FrontendParams) {
-  if (split) return tile == 8 ? frontend_kernel<PcmT, true, 8, RAW16> : frontend_kernel<PcmT, true, 16, RAW16>;
-  return tile == 8 ? frontend_kernel<PcmT, false, 8, RAW16> : frontend_kernel<PcmT, false, 16, RAW16>;
+  if (split)
+    return tile == 8 ? frontend_kernel<PcmT, true, 8, RAW16, SpecGeneric> : frontend_kernel<PcmT, true, 16, RAW16, SpecGeneric>;
+  return tile == 8 ? frontend_kernel<PcmT, false, 8, RAW16, SpecGeneric> : frontend_kernel<PcmT, false, 16, RAW16, SpecGeneric>;
+}
+
+// Does the launch match every value a specialised instance has folded in?
+template <typename Spec>
+bool spec_matches(const FrontendParams& p) {
+  return p.stride == Spec::STRIDE && p.flen == Spec::FLEN && p.flen_eff == Spec::FLEN && p.n_steps == Spec::N_STEPS &&
+         (p.preemph != 0) == (Spec::PRE != 0) && (!p.preemph || p.pre_shift == 1) && p.kp == Spec::KP &&
+         (p.need_energy != 0) == (Spec::NEED_ENERGY != 0) && p.n_ft == Spec::N_FT && p.n_ct == Spec::N_CT &&
+         p.out_kind == Spec::OUT_KIND && p.nfilt == Spec::NFILT && p.ncols == Spec::NCOLS &&
+         (Spec::OUT_KIND != SVK_OUT_MFCC || (p.dc_elim != 0) == (Spec::DC_ELIM != 0));
 }
 
 }  // namespace
@@ -857,10 +904,21 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   const size_t lds_total = (size_t)plan->table_bytes + (size_t)waves * lds.wave_bytes;
   const bool split = plan->cfg.nfft == 1024;
   void (*kern)(const FrontendParams) = nullptr;
-  if (pcm_dtype == SVK_PCM_I16)
+  const bool generic_only = getenv("SVK_FE_GENERIC") != nullptr;  // tuning / tests: force the unspecialised instance
+  if (pcm_dtype == SVK_PCM_I16 && raw16 && plan->tile == 8 && !generic_only && !split && spec_matches<SpecMfcc13>(p))
+    kern = frontend_kernel<int16_t, false, 8, true, SpecMfcc13>;
+  else if (pcm_dtype == SVK_PCM_I16 && raw16 && plan->tile == 8 && !generic_only && split && spec_matches<SpecLmfe40>(p))
+    kern = frontend_kernel<int16_t, true, 8, true, SpecLmfe40>;
+  else if (pcm_dtype == SVK_PCM_I16)
     kern = raw16 ? pick_kernel<int16_t, true>(split, plan->tile) : pick_kernel<int16_t, false>(split, plan->tile);
   else
     kern = pick_kernel<float, false>(split, plan->tile);
+  if (getenv("SVK_FE_DEBUG"))
+    fprintf(stderr, "svk_frontend_run: %s instance, %d waves/CU, grid %lld\n",
+            kern == (void (*)(const FrontendParams))frontend_kernel<int16_t, false, 8, true, SpecMfcc13>   ? "mfcc13"
+            : kern == (void (*)(const FrontendParams))frontend_kernel<int16_t, true, 8, true, SpecLmfe40> ? "lmfe40"
+                                                                                                           : "generic",
+            waves, (long long)grid);
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_total));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * waves), lds_total, ctx->stream, p);
