@@ -75,11 +75,17 @@ __device__ __forceinline__ cplx cmul_conj(cplx a, cplx b) {
   return r;
 }
 
-// Forward 8-point DFT in place, natural order out: 26 packed instructions.
+// Forward 8-point DFT in place, natural order out: 26 packed instructions.  NZ < 8 says inputs
+// v[NZ..7] are exact zeros (the zero padding of a frame up to the FFT length, which the first
+// radix-8 pass of the wave FFT sees as whole registers): their butterflies of the first stage
+// drop out (x + 0 is not something the compiler may fold: -0 + 0 = +0).
+template <int NZ = 8>
 __device__ __forceinline__ void dft8(cplx (&v)[8]) {
   const cplx S = mk(0.70710678118654752440f, 0.70710678118654752440f);
-  const cplx a0 = v[0] + v[4], a1 = v[0] - v[4], a2 = v[2] + v[6], d26 = v[2] - v[6];
-  const cplx a4 = v[1] + v[5], a5 = v[1] - v[5], a6 = v[3] + v[7], d37 = v[3] - v[7];
+  const cplx a0 = NZ > 4 ? v[0] + v[4] : v[0], a1 = NZ > 4 ? v[0] - v[4] : v[0];
+  const cplx a2 = NZ > 6 ? v[2] + v[6] : v[2], d26 = NZ > 6 ? v[2] - v[6] : v[2];
+  const cplx a4 = NZ > 5 ? v[1] + v[5] : v[1], a5 = NZ > 5 ? v[1] - v[5] : v[1];
+  const cplx a6 = NZ > 7 ? v[3] + v[7] : v[3], d37 = NZ > 7 ? v[3] - v[7] : v[3];
   const cplx b0 = a0 + a2, b2 = a0 - a2, b1 = add_mi(a1, d26), b3 = sub_mi(a1, d26);
   const cplx c4 = a4 + a6, d46 = a4 - a6, t5 = add_mi(a5, d37), t7 = sub_mi(a5, d37);
   const cplx c5 = rot_w8(t5), c7 = rot_w8_3(t7);  // still to be scaled by 1/sqrt 2: folded into the fma below
@@ -124,10 +130,12 @@ __device__ __forceinline__ void fft512_wave(cplx (&v)[8], cplx* scr, int lane, c
 // waves per SIMD the other waves alone do not cover those round trips.  Sharing the scratch is
 // safe because the LDS unit executes one wave's DS instructions in program order: b's transpose
 // writes are issued after a's transpose reads and therefore land after them.
+// NZ: inputs a[NZ..7], b[NZ..7] are exact zeros (see dft8).
+template <int NZ = 8>
 __device__ __forceinline__ void fft512_wave_x2(cplx (&a)[8], cplx (&b)[8], cplx* scr, int lane, const cplx (&t1)[8],
                                                const cplx (&t2)[8]) {
   const int r2 = lane >> 3, p = lane & 7;
-  dft8(a);
+  dft8<NZ>(a);
 #pragma unroll
   for (int r = 1; r < 8; ++r) a[r] = cmul(a[r], t1[r]);
   wave_sync();
@@ -136,7 +144,7 @@ __device__ __forceinline__ void fft512_wave_x2(cplx (&a)[8], cplx (&b)[8], cplx*
   wave_sync();
 #pragma unroll
   for (int c = 0; c < 8; ++c) a[c] = scr[r2 * 72 + 8 * c + p];
-  dft8(b);
+  dft8<NZ>(b);
 #pragma unroll
   for (int r = 1; r < 8; ++r) b[r] = cmul(b[r], t1[r]);
   wave_sync();

@@ -46,10 +46,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int MAX_TILE = 16;  // frames per wave tile: 8 or 16 (MFMA N = 16; an 8-frame tile leaves half of N idle)
 constexpr int RAW_OFF = 8;    // int16 staging: samples start 16 bytes in, slot RAW_OFF-1 holds the sample before the span
 constexpr int MAX_FT = 4;    // 16-filter tiles  (<= 64 filters)
-constexpr int PT_PAD = 8;    // ptile row padding (floats): conflict-free ds_read_b128
+constexpr int PT_PAD = 8;    // ptile row padding (floats): conflict-free ds_read_b128; also holds the frame's 8 energy group sums
 constexpr float EPS64 = 2.220446049250313e-16f;  // np.finfo(float).eps, functions.py:62
 
 // Phase-ablation switches for tuning: compiled in only with -DSVK_TUNING
@@ -172,13 +171,13 @@ __device__ __forceinline__ void stage_raw16(bool pre, const int16_t* x, int64_t 
   }
 }
 
-// Sum of two values over the wave with DPP adds only (no LDS crossbar): an inclusive scan inside
-// each 16-lane row (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then row
-// 0 -> 1 and 2 -> 3 (row_bcast:15, rows 1 and 3 written), then rows 0-1 -> 2-3 (row_bcast:31).  The
-// totals are in LANE 63.  Written as v_add_f32_dpp (add and lane move in ONE instruction; the
-// update_dpp builtin costs a zero-init, a move and an add per step); a VALU result needs two wait
-// states before a DPP read, which the other value's step plus one s_nop provide.
-__device__ __forceinline__ void wave_sum2_lane63(float& a, float& b) {
+// Sums of two values over each group of 8 consecutive lanes, DPP adds only: an inclusive scan inside
+// the 16-lane rows (row_shr 1, 2, 4; lanes shifted in from outside the row read 0) leaves the sum of
+// lanes 8 m .. 8 m + 7 in lane 8 m + 7.  Written as v_add_f32_dpp (add and lane move in ONE
+// instruction; the update_dpp builtin costs a zero-init, a move and an add per step); a VALU result
+// needs two wait states before a DPP read, which the other value's step plus one s_nop provide.
+// The 8 group sums of a frame are finished by the matrix cores (see the energy MFMA below).
+__device__ __forceinline__ void group8_sum2(float& a, float& b) {
   asm volatile(
       "s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
@@ -189,15 +188,6 @@ __device__ __forceinline__ void wave_sum2_lane63(float& a, float& b) {
       "s_nop 0\n\t"
       "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
       "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-      "s_nop 0\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-      "s_nop 0\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
       "s_nop 1"
       : "+v"(a), "+v"(b));
 }
@@ -362,7 +352,6 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
   float* ptile = reinterpret_cast<float*>(mine + p.sig_bytes);
   const int prow = c_kp + PT_PAD;
   cplx* scr = reinterpret_cast<cplx*>(ptile + TILE * prow);
-  float* elds = reinterpret_cast<float*>(scr + SCR);
   const int lane_id = threadIdx.x & 63;
   constexpr bool INT_PCM = sizeof(PcmT) == 2;
 
@@ -376,7 +365,6 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) t3[q] = p.tw3[q * 64 + lane_id];
   }
-  const float inv_scale = SPLIT1024 ? (1.0f / 1024.0f) : (1.0f / (4.0f * 512.0f));
   // Consecutive tiles go to the waves of one workgroup (neighbours share the overlapping PCM in
   // L1).  (clip, tile-in-clip) advance incrementally: one division here instead of a 64-bit
   // divide + modulo per tile.
@@ -396,7 +384,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
     asm volatile("" : "+v"(lane));
     const int jf = lane & 15, g = lane >> 4;
     const int mirror = (64 - lane) & 63;
-    const bool lane0 = lane == 0, lane63 = lane == 63;
+    const bool lane0 = lane == 0;
     const int f0 = ft * TILE;
     int64_t off = (int64_t)utt * p.clip_stride;  // utt is wave-uniform: these are scalar loads
     if (p.offsets) off = p.offsets[utt];
@@ -471,11 +459,11 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
             const int k = lane + 64 * j;
             if (SPLIT1024) {
               // X[k] = E + W^k O  with  E = (Zk + conj Zn)/2,  O = (Zk - conj Zn)/(2i)
-              // 2 E = Zk + conj Zn,  2 O = -i (Zk - conj Zn) = (zk.y + zn.y, -(zk.x - zn.x)); the 1/2's go into inv_scale
+              // 2 E = Zk + conj Zn,  2 O = -i (Zk - conj Zn) = (zk.y + zn.y, -(zk.x - zn.x)); the 1/2's are folded into the filterbank weights
               const cplx E2 = add_conj(zk, zn), Ot = swap_add_conj(zk, zn);  // Ot = conj(2 O)
               cplx xp = E2 + cmul_conj(t3[j], Ot);
               xp *= xp;
-              const float pk = (xp.x + xp.y) * (0.25f * inv_scale);
+              const float pk = xp.x + xp.y;  // 4 nfft |X[k]|^2
               if (64 * (j + 1) <= c_kp) rowa[k] = pk;  // wave-uniform: no exec masking
               else if (k < c_kp) rowa[k] = pk;         // ragged last step only
             } else {
@@ -483,7 +471,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
               cplx xa = add_conj(zk, zn), xb = swap_add_conj(zk, zn);
               xa *= xa;
               xb *= xb;
-              const float pa = (xa.x + xa.y) * inv_scale, pb = (xb.x + xb.y) * inv_scale;
+              const float pa = xa.x + xa.y, pb = xb.x + xb.y;  // 4 nfft |X[k]|^2
               if (64 * (j + 1) <= c_kp) {  // wave-uniform: no exec masking
                 rowa[k] = pa;
                 rowb[k] = pb;
@@ -495,10 +483,12 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
           }
         }
         if (c_need_energy) {
-          wave_sum2_lane63(ea, eb);  // (eb is idle for nfft 1024: its slot still hides ea's DPP wait states)
-          if (lane63) {
-            elds[f] = ea == 0.f ? EPS64 : ea;  // feature.py:205
-            if (!SPLIT1024) elds[f + 1] = eb == 0.f ? EPS64 : eb;
+          // 64 per-lane partial sums -> 8 (one per 8 lanes), parked in the 8 padding floats behind the
+          // row's power bins; the mel stage adds them up with two more MFMAs against a matrix of ones.
+          group8_sum2(ea, eb);  // (eb is idle for nfft 1024: its slot still hides ea's DPP wait states)
+          if ((lane & 7) == 7) {
+            rowa[c_kp + (lane >> 3)] = ea;
+            if (!SPLIT1024) rowb[c_kp + (lane >> 3)] = eb;
           }
         }
       };
@@ -509,7 +499,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         float eaa, eba, eab, ebb;
         load(fa, va, eaa, eba);
         load(fb, vb, eab, ebb);
-        fft512_wave_x2(va, vb, scr, lane, t1, t2);
+        fft512_wave_x2<(Spec::N_STEPS > 0 ? Spec::N_STEPS : 8)>(va, vb, scr, lane, t1, t2);
         finish(fa, va, eaa, eba);
         if (two) finish(fb, vb, eab, ebb);
       }
@@ -540,6 +530,16 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
           }
         }
         acc[t] = acc0 + acc1;
+      }
+      // frame energy = ones x (the 8 group sums of the frame): every output row of the tile is that sum,
+      // so each lane ends up with the energy of ITS frame jf (feature.py:202-205)
+      float e_frame = 0.f;
+      if (c_need_energy) {
+        const float* pe = ptile + (jf & (TILE - 1)) * prow + c_kp + g;
+        f32x4 oe = (f32x4){0.f, 0.f, 0.f, 0.f};
+        oe = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, pe[0], oe, 0, 0, 0);
+        oe = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, pe[4], oe, 0, 0, 0);
+        e_frame = oe[0] == 0.f ? EPS64 : oe[0];
       }
       if (SVK_ABLATE(p, 32)) continue;
       // lane (jf, g) now holds mel[filter 16 t + 4 g + reg][frame jf]
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         }
       } else {
         // ---- cepstra^T = DCT x log(mel)^T: acc[t][r] is already the B operand ------
-        const float le = fast_log<INT_PCM>(elds[jf & (TILE - 1)]);
+        const float le = fast_log<INT_PCM>(e_frame);
         for (int c = 0; c < (SVK_ABLATE(p, 16) ? 0 : c_n_ct); ++c) {  // runtime loop: keeps the table loads of one cepstral tile in flight, not four
           f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
           const float* dfrag = dct_lds + c * c_n_ft * 4 * 64 + lane;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
           }
         }
       }
-      if (p.energy && row_ok && g == 0) p.energy[(int64_t)utt * p.max_frames + f0 + jf] = elds[jf & (TILE - 1)];
+      if (p.energy && row_ok && g == 0) p.energy[(int64_t)utt * p.max_frames + f0 + jf] = e_frame;
     }
 
     // rows of this tile past the clip's last frame: defined (zero) output
@@ -630,7 +630,7 @@ struct svk_frontend_plan {
 
 namespace {
 
-// LDS carve: [shared tables] then per wave [staged samples | power tile [tile][kp + PT_PAD] | FFT scratch | energies]
+// LDS carve: [shared tables] then per wave [staged samples | power tile [tile][kp + PT_PAD] | FFT scratch]
 struct LdsLayout {
   int sig_bytes, wave_bytes, waves;
   size_t total;
@@ -642,7 +642,7 @@ LdsLayout lds_layout(const svk_frontend_plan* plan, int tile, bool raw16, int ld
     l.sig_bytes = (((RAW_OFF + span + 8) * 2 + 15) / 16) * 16;  // whole 16-byte groups per lane
   else
     l.sig_bytes = (((span + 8) * 4 + 15) / 16) * 16;
-  l.wave_bytes = l.sig_bytes + (int)sizeof(float) * (tile * (plan->kp + PT_PAD) + 2 * SCR + MAX_TILE);
+  l.wave_bytes = l.sig_bytes + (int)sizeof(float) * (tile * (plan->kp + PT_PAD) + 2 * SCR);
   l.wave_bytes = ((l.wave_bytes + 15) / 16) * 16;
   const int room = lds_per_cu - plan->table_bytes;
   l.waves = room >= l.wave_bytes ? std::min(12, room / l.wave_bytes) : 0;  // 12 waves = 768 threads: up to 168 VGPRs each, no spills
@@ -787,6 +787,7 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
       h_tw3[2 * (q * 64 + l)] = (float)cos(a);
       h_tw3[2 * (q * 64 + l) + 1] = (float)sin(a);
     }
+  const double power_scale = cfg->nfft == 1024 ? 1.0 / 4096.0 : 1.0 / 2048.0;
   // A-operand fragments of the filterbank: lane l = (i = l & 15, kk = l >> 4), element e of
   // chunk u is fb[16 t + i][16 u + 4 kk + e]
   for (int t = 0; t < plan->n_ft; ++t)
@@ -795,7 +796,9 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
         for (int e = 0; e < 4; ++e) {
           const int filt = 16 * t + (l & 15), bin = 16 * u + 4 * (l >> 4) + e;
           double w = (filt < nf && bin < nbins) ? h_filterbank[(size_t)filt * nbins + bin] : 0.0;
-          h_fb[(((size_t)plan->slot_base[t] + (u - plan->chunk_lo[t])) * 64 + l) * 4 + e] = (float)w;
+          // the weights carry the spectrum's 1/nfft and the 1/4 of the untangling (powers of two: exact),
+          // so the kernel stores raw |.|^2 sums in the power tile
+          h_fb[(((size_t)plan->slot_base[t] + (u - plan->chunk_lo[t])) * 64 + l) * 4 + e] = (float)(w * power_scale);
         }
   // A-operand fragments of the DCT-II (ortho) matrix, k-step (t, r) <-> filter 16 t + 4 (l >> 4) + r
   // scipy.fftpack.dct(type=2, norm='ortho'): D[k][n] = sqrt(2/N) cos(pi k (2n+1) / 2N), D[0][n] = sqrt(1/N)

@@ -140,6 +140,32 @@ def test_fused_preemphasis_matches_reference_chain(eng):
         np.testing.assert_allclose(feat[i].cpu().numpy(), want, **FEAT_TOL)
 
 
+@pytest.mark.parametrize("kind,nfft,fl", [("mfcc", 512, 0.020), ("lmfe", 1024, 0.025)])
+def test_specialised_instances_match_generic_and_oracle(eng, kind, nfft, fl, monkeypatch):
+    """The two standard configurations run compile-time specialised kernel instances (frontend.hip,
+    SpecMfcc13 / SpecLmfe40); SVK_FE_GENERIC forces the generic instance on the same input."""
+    from speaker_verification_amd.speechpy import feature
+    lens = [48000, 47999, 16001, 9999, 2723, 1280 + 320, 400, 319, 33333, 48000]
+    pcm = np.zeros((len(lens), max(lens)), dtype=np.int16)
+    for i, n in enumerate(lens):
+        pcm[i, :n] = synth.speaker_clip(i, 1, n) if i % 2 else synth.noise_clip(200 + i, n)
+    kw = dict(kind=kind, frame_length=fl, fft_length=nfft, preemphasis_cof=0.98,
+              lengths=np.array(lens, dtype=np.int32))
+    spec, nf_spec, _ = feature.features_batch(pcm, 16000, **kw)
+    monkeypatch.setenv("SVK_FE_GENERIC", "1")
+    gen, nf_gen, _ = feature.features_batch(pcm, 16000, **kw)
+    monkeypatch.delenv("SVK_FE_GENERIC")
+    assert torch.equal(nf_spec, nf_gen)
+    np.testing.assert_allclose(spec.cpu().numpy(), gen.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    fn = ref.mfcc if kind == "mfcc" else ref.lmfe
+    for i, n in enumerate(lens):
+        want = fn(ref.preemphasis(pcm[i, :n], cof=0.98), 16000, frame_length=fl, frame_stride=0.01, num_filters=40,
+                  fft_length=nfft)
+        assert int(nf_spec[i]) == want.shape[0]
+        np.testing.assert_allclose(spec[i, :want.shape[0]].cpu().numpy(), want, **FEAT_TOL)
+        assert not spec[i, want.shape[0]:].any()
+
+
 def test_full_size_batch_properties(eng):
     """BASELINE config 2 shape (1 024 x 3 s): determinism, row independence, no NaN."""
     from speaker_verification_amd.speechpy import feature
