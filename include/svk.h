@@ -185,6 +185,23 @@ int svk_cube_draw_crops(svk_ctx* ctx, const int32_t* d_n_frames, int32_t n_utt, 
                         const int64_t* d_utt_index, int32_t n_crops, int32_t crop_frames, uint64_t seed,
                         int32_t* d_crop_idx, int32_t* d_bad_count);
 
+/* ---- audio ingest ----------------------------------------------------------
+ * utils.py:170-173  `librosa.load(path, sr=16000, mono=True)`: down-mix (mean over
+ * channels), scale int16 / 32768 and resample, for n_utt clips in one launch.
+ * librosa is absent and its resampler unpinned, so the arithmetic is the published
+ * polyphase windowed-sinc scheme of scipy.signal.resample_poly (zero-padded edges):
+ *     y[m] = sum_j x[j] * taps[m * down + half - j * up],   half = (n_taps - 1) / 2
+ * d_pcm    : [n_utt][in_stride][n_ch] interleaved int16 frames (vad.py:10-22 reads them)
+ * d_in_len : [n_utt] int32 frames per clip, or NULL = clip_in
+ * d_taps   : [n_taps] float32 (odd count; the host builds them, see ingest.py)
+ * d_out    : [n_utt][out_stride] float32 in [-1, 1) (SVK_PCM_F32) or int16 rounded back to the
+ *            16-bit grid, saturating (SVK_PCM_I16); samples past a clip's end are written as 0
+ * d_out_len: [n_utt] int32 = min(ceil(n_in * up / down), clip_out), or NULL          */
+int svk_ingest_resample(svk_ctx* ctx, const int16_t* d_pcm, int32_t n_ch, int64_t in_stride,
+                        const int32_t* d_in_len, int32_t clip_in, int32_t n_utt, const float* d_taps,
+                        int32_t n_taps, int32_t up, int32_t down, void* d_out, int32_t out_dtype,
+                        int64_t out_stride, int32_t clip_out, int32_t* d_out_len);
+
 /* ---- scoring ---------------------------------------------------------------
  * evaluation.py:67-84: cosine of every test row against every enrolled row,
  * float32, out [n_test][n_enroll]  (f32 MFMA).  dim <= 4096.                 */

@@ -72,6 +72,8 @@ SIGNATURES = {
     "svk_roc_workspace_bytes": (C.c_size_t, [_i64]),
     "svk_roc_eer": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_size_t, C.POINTER(C.c_double)]),
     "svk_l2_dist": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "svk_ingest_resample": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32,
+                                      _i64, _i32, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,121 @@
+// Audio ingest: interleaved 16-bit PCM at any rate -> mono samples at the model's rate, on device.
+//
+// Replaces the load step of /root/reference/utils.py:170-173
+//     audio, sr = librosa.load(filename, sr=16000, mono=True)
+// (down-mix = mean over channels, scale int16 / 32768 to [-1, 1), resample to 16 kHz).  librosa
+// is absent here and its resampler unpinned, so the resampler is the published polyphase
+// windowed-sinc scheme of scipy.signal.resample_poly (zero-padded edges): with
+//     h = up * firwin(2 * half + 1, 1 / max(up, down), window = ("kaiser", 5.0)),  half = 10 max(up, down)
+//     y[m] = sum_j x[j] * h[m * down + half - j * up]
+// The taps come from the host (float64 -> float32, speaker_verification_amd/ingest.py), like the
+// filterbank does.  One workgroup produces 256 consecutive output samples of one clip: the input
+// span they touch is down-mixed once into LDS, the taps sit in LDS too, every lane then runs its
+// dot product out of LDS.  HBM-bound: 2 n_ch bytes read per input frame, 4 (or 2) written per
+// output sample.
+#include "svk_internal.h"
+
+namespace {
+
+constexpr int OUT_PER_WG = 256;
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void resample_kernel(const int16_t* __restrict__ pcm, int n_ch, int64_t in_stride,
+                                                       const int32_t* __restrict__ in_len, int clip_in,
+                                                       const float* __restrict__ taps, int n_taps, int up, int down,
+                                                       OutT* __restrict__ out, int64_t out_stride, int clip_out,
+                                                       int32_t* __restrict__ out_len, int span_cap) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* h = smem;            // [n_taps]
+  float* xs = smem + n_taps;  // [span_cap] mono samples, already / 32768
+  const int utt = blockIdx.y;
+  const int n_in = in_len ? in_len[utt] : clip_in;
+  // resample_poly: ceil(n_in * up / down) output samples
+  const int64_t n_out64 = ((int64_t)n_in * up + down - 1) / down;
+  const int n_out = n_out64 < clip_out ? (int)n_out64 : clip_out;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && out_len) out_len[utt] = n_out;
+  const int m0 = blockIdx.x * OUT_PER_WG;
+  OutT* o = out + (int64_t)utt * out_stride;
+  if (m0 >= n_out) {  // past the clip: defined (zero) output
+    for (int m = m0 + threadIdx.x; m < m0 + OUT_PER_WG && m < clip_out; m += blockDim.x) o[m] = (OutT)0;
+    return;
+  }
+  const int half = (n_taps - 1) / 2;
+  for (int i = threadIdx.x; i < n_taps; i += blockDim.x) h[i] = taps[i];
+  // input frames touched by outputs m0 .. m0 + 255:  ceil((m down - half) / up) .. floor((m down + half) / up)
+  const int64_t t_lo = (int64_t)m0 * down - half, t_hi = (int64_t)(m0 + OUT_PER_WG - 1) * down + half;
+  const int64_t j_lo = t_lo >= 0 ? (t_lo + up - 1) / up : -((-t_lo) / up);
+  const int64_t j_hi = t_hi / up;
+  const int span = (int)(j_hi - j_lo + 1);  // <= span_cap by construction of the launch
+  const int16_t* x = pcm + (int64_t)utt * in_stride * n_ch;
+  const float scale = 1.0f / (32768.0f * (float)n_ch);
+  for (int i = threadIdx.x; i < span; i += blockDim.x) {
+    const int64_t j = j_lo + i;
+    float v = 0.f;
+    if (j >= 0 && j < n_in) {
+      int acc = 0;
+      for (int c = 0; c < n_ch; ++c) acc += x[j * n_ch + c];
+      v = (float)acc * scale;
+    }
+    xs[i] = v;
+  }
+  __syncthreads();
+  const int m = m0 + threadIdx.x;
+  if (m >= clip_out) return;
+  float y = 0.f;
+  if (m < n_out) {
+    const int64_t t = (int64_t)m * down;
+    const int64_t a = t - half, b = t + half;
+    const int64_t ja = a >= 0 ? (a + up - 1) / up : -((-a) / up);
+    const int64_t jb = b / up;
+    int k = (int)(t + half - ja * up);  // tap index of the first frame; steps down by `up`
+    for (int64_t j = ja; j <= jb; ++j, k -= up) y = fmaf(xs[j - j_lo], h[k], y);
+  }
+  if constexpr (sizeof(OutT) == 2) {
+    float r = rintf(y * 32768.0f);  // back to the int16 grid, round half to even, saturating
+    r = r > 32767.f ? 32767.f : (r < -32768.f ? -32768.f : r);
+    o[m] = (OutT)r;
+  } else {
+    o[m] = y;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int svk_ingest_resample(svk_ctx* ctx, const int16_t* d_pcm, int32_t n_ch, int64_t in_stride, const int32_t* d_in_len,
+                        int32_t clip_in, int32_t n_utt, const float* d_taps, int32_t n_taps, int32_t up, int32_t down,
+                        void* d_out, int32_t out_dtype, int64_t out_stride, int32_t clip_out, int32_t* d_out_len) {
+  SVK_REQUIRE(ctx, ctx != nullptr, "ctx");
+  if (n_utt == 0 || clip_out == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_pcm && d_taps && d_out, "null buffer");
+  SVK_REQUIRE(ctx, n_utt > 0 && n_ch >= 1 && n_ch <= 8 && clip_in >= 0 && clip_out > 0, "shape");
+  SVK_REQUIRE(ctx, in_stride >= clip_in && out_stride >= clip_out, "strides shorter than the clips");
+  SVK_REQUIRE(ctx, up >= 1 && down >= 1 && n_taps >= 1 && (n_taps & 1) == 1, "up, down >= 1 and an odd tap count");
+  SVK_REQUIRE(ctx, out_dtype == SVK_PCM_I16 || out_dtype == SVK_PCM_F32, "out_dtype");
+  const int half = (n_taps - 1) / 2;
+  // frames one workgroup can touch: ((256 - 1) down + 2 half) / up + 2
+  const int64_t span_cap = ((int64_t)(OUT_PER_WG - 1) * down + 2LL * half) / up + 2;
+  const size_t lds = sizeof(float) * ((size_t)n_taps + (size_t)span_cap);
+  if (lds > (size_t)ctx->lds_per_cu)
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "resampling %d/%d needs %zu bytes of LDS per workgroup (have %d)", up,
+                    down, lds, ctx->lds_per_cu);
+  const dim3 grid((unsigned)((clip_out + OUT_PER_WG - 1) / OUT_PER_WG), (unsigned)n_utt);
+  if (out_dtype == SVK_PCM_I16) {
+    auto kern = resample_kernel<int16_t>;
+    SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, d_pcm, n_ch, in_stride, d_in_len, clip_in, d_taps,
+                       n_taps, up, down, static_cast<int16_t*>(d_out), out_stride, clip_out, d_out_len, (int)span_cap);
+  } else {
+    auto kern = resample_kernel<float>;
+    SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, d_pcm, n_ch, in_stride, d_in_len, clip_in, d_taps,
+                       n_taps, up, down, static_cast<float*>(d_out), out_stride, clip_out, d_out_len, (int)span_cap);
+  }
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+}  // extern "C"

@@ -374,6 +374,28 @@ class Engine:
               self.ctx)
         return out
 
+    # ---- audio ingest ------------------------------------------------------------
+    def resample(self, pcm, up, down, taps, lengths=None, out_dtype="f32"):
+        """svk_ingest_resample: pcm int16 [n_utt, frames] or [n_utt, frames, channels] -> mono
+        [n_utt, ceil(frames * up / down)] float32 in [-1, 1) or int16, plus the per-clip lengths."""
+        torch = _torch()
+        x = self.to_device(pcm)
+        if x.dtype != torch.int16 or x.dim() not in (2, 3):
+            raise ValueError("resample wants int16 PCM shaped (n_utt, frames) or (n_utt, frames, channels)")
+        n_utt, n_in = int(x.shape[0]), int(x.shape[1])
+        n_ch = int(x.shape[2]) if x.dim() == 3 else 1
+        h = self.to_device(np.asarray(taps, dtype=np.float32))
+        lens = self.to_device(np.asarray(lengths, dtype=np.int32)) if lengths is not None else None
+        n_out = (n_in * up + down - 1) // down
+        dt = {"f32": (torch.float32, _lib.PCM_F32), "i16": (torch.int16, _lib.PCM_I16)}[out_dtype]
+        out = torch.empty((n_utt, max(n_out, 1)), dtype=dt[0], device=self.device)
+        out_len = torch.empty((n_utt,), dtype=torch.int32, device=self.device)
+        self._stream()
+        check(self.lib.svk_ingest_resample(self.ctx, self._ptr(x), n_ch, n_in, self._ptr(lens), n_in, n_utt,
+                                           self._ptr(h), int(h.numel()), int(up), int(down), self._ptr(out), dt[1],
+                                           int(out.shape[1]), n_out, self._ptr(out_len)), self.ctx)
+        return out[:, :n_out], out_len
+
 
 _engines = {}
 

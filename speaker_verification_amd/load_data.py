@@ -2,33 +2,25 @@
 (thin host plumbing on the path: file list -> WAV -> log-mel features -> transforms).
 
 The reference reads audio with `librosa.load(path, sr=16000, mono=True)` (`utils.py:170-173`), which is
-not installed here.  `load_wav` below reads 16-bit PCM WAV files with the standard library and returns
-the same thing librosa does for a file that is already mono at the target rate: float32 in [-1, 1)
-(`int16 / 32768`).  A file at another rate or with several channels raises -- librosa's resampler is
-third-party arithmetic that nothing in the reference pins, so it is not imitated ("parity unpinned").
+not installed here.  `load_wav` reads 16-bit PCM WAV files with the standard library and returns what
+librosa does: float32 mono in [-1, 1) at the target rate.  A mono file already at the rate is only
+rescaled (`int16 / 32768`); other rates / channel counts are down-mixed and resampled on the device
+(`ingest.py`, `svk_ingest_resample`) with SciPy's published polyphase design -- librosa's own resampler
+is third-party arithmetic that nothing in the reference pins ("parity unpinned" for that case).
 """
-import contextlib
 import os
-import wave
 
 import numpy as np
 
 from . import constants as c
+from .ingest import load_audio
 from .speechpy import feature as speech
 from .utils import ToTensor
 
 
 def load_wav(path, sample_rate=c.SAMPLE_RATE):
-    """float32 mono signal in [-1, 1) of a 16-bit PCM WAV already at `sample_rate` (utils.py:170-173)."""
-    with contextlib.closing(wave.open(path, 'rb')) as wf:
-        if wf.getnchannels() != 1 or wf.getsampwidth() != 2:
-            raise ValueError(f"{path}: need mono 16-bit PCM, got {wf.getnchannels()} channel(s) x "
-                             f"{8 * wf.getsampwidth()} bit")
-        if wf.getframerate() != sample_rate:
-            raise ValueError(f"{path}: sample rate {wf.getframerate()} != {sample_rate}; resampling "
-                             "(librosa, absent) is not imitated")
-        pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16)
-    return (pcm.astype(np.float32) / np.float32(32768.0))
+    """float32 mono signal in [-1, 1) at `sample_rate` of a 16-bit PCM WAV (utils.py:170-173)."""
+    return load_audio(path, sample_rate)
 
 
 class AudioDataset(object):

@@ -495,9 +495,62 @@ def test_audio_dataset(tmp_path):
     assert cube.shape == (1, 20, 80, 40) and cube.dtype == np.float32 and label == 0
     sig, sr = vad.read_wave(str(tmp_path / names[0]))
     assert sr == 16000 and sig == clips[names[0]].tobytes()
-    vad.write_wave(str(tmp_path / "stereo.wav"), b"\0" * 4000, 8000)
-    with pytest.raises(ValueError, match="sample rate"):
-        load_data.load_wav(str(tmp_path / "stereo.wav"))
+    vad.write_wave(str(tmp_path / "silence8k.wav"), b"\0" * 4000, 8000)
+    up = load_data.load_wav(str(tmp_path / "silence8k.wav"))           # 8 kHz file: resampled to 16 kHz on the device
+    assert up.shape == (4000,) and up.dtype == np.float32 and not up.any()
+
+
+def test_ingest_resample_parity(eng):
+    """svk_ingest_resample against the CPU restatement of scipy.signal.resample_poly: mono 48 kHz,
+    stereo 44.1 kHz, up-sampling from 8 kHz, ragged lengths; float32 and int16 outputs."""
+    from oracle import ingest_ref
+    from speaker_verification_amd import ingest
+    rng = np.random.default_rng(11)
+    for fs_in, n_ch, lens in [(48000, 1, [48000, 30011, 3, 1]), (44100, 2, [44100, 12345, 441]),
+                              (8000, 1, [8000, 4001]), (32000, 3, [9999])]:
+        n = max(lens)
+        shape = (len(lens), n) if n_ch == 1 else (len(lens), n, n_ch)
+        pcm = (rng.standard_normal(shape) * 6000).clip(-32768, 32767).astype(np.int16)
+        up, down = ingest.rational_ratio(fs_in, 16000)
+        out, out_len = ingest.resample_batch(pcm, fs_in, 16000, lengths=np.array(lens, dtype=np.int32))
+        o16, _ = ingest.resample_batch(pcm, fs_in, 16000, lengths=np.array(lens, dtype=np.int32), out_dtype="i16")
+        out, out_len, o16 = out.cpu().numpy(), out_len.cpu().numpy(), o16.cpu().numpy()
+        for i, L in enumerate(lens):
+            want = ingest_ref.resample_poly(ingest_ref.to_mono(pcm[i, :L]), up, down)
+            assert out_len[i] == len(want) == -(-L * up // down)
+            np.testing.assert_allclose(out[i, :len(want)], want, rtol=0, atol=2e-6)      # f32 sums of <= 61 terms in [-1, 1)
+            assert not out[i, len(want):].any() and not o16[i, len(want):].any()
+            d = o16[i, :len(want)].astype(np.int32) - ingest_ref.to_int16(want).astype(np.int32)
+            assert np.abs(d).max() <= 1 and np.mean(d != 0) < 0.01                        # ties at .5 LSB only
+    # size-independent properties at a full 3 s batch: unit DC gain away from the edges, linearity
+    const = np.full((64, 48000), 12000, dtype=np.int16)
+    y, _ = ingest.resample_batch(const, 48000, 16000)
+    np.testing.assert_allclose(y[:, 40:-40].cpu().numpy(), 12000 / 32768.0, rtol=0, atol=2e-6)
+    a = (rng.standard_normal((8, 44100)) * 3000).astype(np.int16)
+    ya, _ = ingest.resample_batch(a, 44100, 16000)
+    y2, _ = ingest.resample_batch((2 * a).astype(np.int16), 44100, 16000)
+    np.testing.assert_allclose(y2.cpu().numpy(), 2 * ya.cpu().numpy(), rtol=0, atol=4e-6)
+
+
+def test_load_wav_resamples_on_device(tmp_path):
+    """load_data.load_wav (utils.py:170-173 drop-in) on a stereo 44.1 kHz file and on a mono 16 kHz one."""
+    import wave
+    from oracle import ingest_ref
+    from speaker_verification_amd import load_data
+    rng = np.random.default_rng(3)
+    frames = (rng.standard_normal((22050, 2)) * 5000).astype(np.int16)
+    for path, rate, data in [(str(tmp_path / "a.wav"), 44100, frames), (str(tmp_path / "b.wav"), 16000, frames[:, :1])]:
+        with wave.open(path, "wb") as wf:
+            wf.setnchannels(data.shape[1])
+            wf.setsampwidth(2)
+            wf.setframerate(rate)
+            wf.writeframes(np.ascontiguousarray(data).tobytes())
+    got = load_data.load_wav(str(tmp_path / "a.wav"))
+    want = ingest_ref.resample_poly(ingest_ref.to_mono(frames), 160, 441)
+    assert got.dtype == np.float32 and got.shape == want.shape == (8000,)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    same = load_data.load_wav(str(tmp_path / "b.wav"))
+    assert np.array_equal(same, frames[:, 0].astype(np.float32) / np.float32(32768.0))
 
 
 def test_error_paths(eng):

@@ -101,3 +101,28 @@ def test_fused_embedder_pool_order():
         with torch.no_grad():
             want = m(x, development=False)
         torch.testing.assert_close(fused(x), want, rtol=1e-4, atol=1e-5)
+
+
+def test_ingest_host_tables_and_wav_reader(tmp_path):
+    """Host side of the audio ingest: rate ratio, FIR taps (= the oracle's), any-rate / any-channel WAV reader."""
+    import wave
+    from oracle import ingest_ref
+    from speaker_verification_amd import ingest
+    assert ingest.rational_ratio(44100, 16000) == (160, 441)
+    assert ingest.rational_ratio(48000, 16000) == (1, 3)
+    assert ingest.rational_ratio(8000, 16000) == (2, 1)
+    assert ingest.rational_ratio(16000, 16000) == (1, 1)
+    with pytest.raises(ValueError):
+        ingest.rational_ratio(0, 16000)
+    for up, down in [(1, 3), (160, 441), (2, 1)]:
+        np.testing.assert_allclose(ingest.resample_taps(up, down), ingest_ref.firwin_kaiser(up, down), rtol=0, atol=1e-15)
+        assert len(ingest.resample_taps(up, down)) == 20 * max(up, down) + 1
+    frames = (np.arange(2 * 500).reshape(500, 2) * 13 % 2000 - 1000).astype(np.int16)
+    path = str(tmp_path / "stereo44k.wav")
+    with wave.open(path, "wb") as wf:
+        wf.setnchannels(2)
+        wf.setsampwidth(2)
+        wf.setframerate(44100)
+        wf.writeframes(frames.tobytes())
+    got, rate = ingest.read_wave_any(path)
+    assert rate == 44100 and got.shape == (500, 2) and np.array_equal(got, frames)

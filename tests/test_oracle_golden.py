@@ -226,3 +226,21 @@ def test_contrastive_loss_formula():
     loss = scoring_ref.contrastive_loss(y, o1, o2, [2.0, 1.0], LAMBDA=0.1, M=2.0)
     expected = (0.5 * 25 + 0.5 * 1 + 0 + 0 + 4 * 0.1 * 3.0) / 4
     assert loss == pytest.approx(expected, rel=1e-6)
+
+
+def test_ingest_resampler_against_scipy():
+    """The ingest oracle restates scipy.signal.resample_poly (the published algorithm the build uses in
+    place of librosa's unpinned resampler, utils.py:170-173): held to SciPy's own output."""
+    import scipy.signal as ss
+    from oracle import ingest_ref
+    rng = np.random.default_rng(7)
+    for n, up, down in [(48000, 1, 3), (44100, 160, 441), (8000, 2, 1), (1000, 3, 7), (5, 1, 3), (1, 160, 441)]:
+        x = rng.standard_normal(n)
+        got, want = ingest_ref.resample_poly(x, up, down), ss.resample_poly(x, up, down)
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-13)
+        ref_taps = ss.firwin(2 * 10 * max(up, down) + 1, 1.0 / max(up, down), window=("kaiser", 5.0)) * up
+        np.testing.assert_allclose(ingest_ref.firwin_kaiser(up, down), ref_taps, rtol=0, atol=1e-15)
+    stereo = np.array([[100, 300], [-32768, 32767], [7, 8]], dtype=np.int16)
+    np.testing.assert_allclose(ingest_ref.to_mono(stereo), np.array([200.0, -0.5, 7.5]) / 32768.0)
+    assert ingest_ref.to_int16([0.5, -1.5, 1.0, 1.5 / 32768, 2.5 / 32768]).tolist() == [16384, -32768, 32767, 2, 2]
