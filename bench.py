@@ -197,6 +197,33 @@ def cosine_mfma_bench(eng, torch, reps=10):
                          "output_GBps": nt * ns * 4 / ms / 1e6}}
 
 
+def ingest_bench(eng, torch, reps=10, n_clips=1024):
+    """svk_ingest_resample: 1 024 x 3 s mono clips at 48 kHz -> 16 kHz float32.
+    Algorithmic bytes per clip: 144 000 x 2 read + 48 000 x 4 written = 480 000 B."""
+    from speaker_verification_amd import ingest
+    pcm = (torch.randn(n_clips, 144000, device=eng.device) * 3000).to(torch.int16)
+    up, down = ingest.rational_ratio(48000, 16000)
+    taps = ingest.resample_taps(up, down)
+    for _ in range(3):
+        eng.resample(pcm, up, down, taps)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        eng.resample(pcm, up, down, taps)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = float(np.median(ts))
+    gbs = n_clips * 480000 / ms / 1e6
+    return {"workload": "%d x 3 s clips, 48 kHz mono int16 -> 16 kHz float32" % n_clips, "ms": ms,
+            "utt_per_s": n_clips / ms * 1e3,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "decimate_kernel<3, float>",
+                         "bytes_per_utt": 480000}}
+
+
 def cpu_baseline(pcm_host, crop_idx, state, preemph, cmvn, use_vad):
     """The oracle (kind 'port') doing exactly the reference's per-utterance sequence on the host:
     vad -> preemphasis -> lmfe -> cmvn -> cube -> C3D2 at batch 1 -> per-pair cosine."""
@@ -269,7 +296,8 @@ def main():
 
     if args.frontend_only:
         res = {"A": frontend_A_bench(eng, torch, reps=max(args.steps, 5)),
-               "B": frontend_B_bench(eng, torch, reps=max(args.steps, 5))}
+               "B": frontend_B_bench(eng, torch, reps=max(args.steps, 5)),
+               "ingest_resample": ingest_bench(eng, torch)}
         print(json.dumps(res))
         return
 
@@ -399,6 +427,7 @@ def main():
         result["micro_batch_breakdown"] = stage_breakdown(pipe, eng, torch, pcm[lo0:hi0], 0)
         result["frontend_A"] = frontend_A_bench(eng, torch)
         result["cosine_mfma"] = cosine_mfma_bench(eng, torch)
+        result["ingest_resample"] = ingest_bench(eng, torch)
         if args.cpu_sample > 0:
             ns = min(args.cpu_sample, n_local)
             # three utterances each of ns/3 speakers spread over the shard (the last one enrols, Q17)

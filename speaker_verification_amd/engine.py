@@ -384,7 +384,12 @@ class Engine:
             raise ValueError("resample wants int16 PCM shaped (n_utt, frames) or (n_utt, frames, channels)")
         n_utt, n_in = int(x.shape[0]), int(x.shape[1])
         n_ch = int(x.shape[2]) if x.dim() == 3 else 1
-        h = self.to_device(np.asarray(taps, dtype=np.float32))
+        taps = np.asarray(taps, dtype=np.float32)
+        key = (int(up), int(down), taps.size, float(taps[taps.size // 2]))
+        cache = self.__dict__.setdefault("_resample_taps", {})
+        if key not in cache:                         # the FIR is a per-ratio table: upload it once
+            cache[key] = self.to_device(taps)
+        h = cache[key]
         lens = self.to_device(np.asarray(lengths, dtype=np.int32)) if lengths is not None else None
         n_out = (n_in * up + down - 1) // down
         dt = {"f32": (torch.float32, _lib.PCM_F32), "i16": (torch.int16, _lib.PCM_I16)}[out_dtype]
