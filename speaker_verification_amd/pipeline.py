@@ -67,6 +67,13 @@ class VerificationPipeline:
         return spans
 
     # ---- stages ----------------------------------------------------------------------
+    def ingest(self, pcm, fs_in, lengths=None):
+        """Recordings at another rate / with several channels -> what `embed` takes: int16 mono at
+        16 kHz on the device (+ lengths).  pcm: int16 [n, frames] or [n, frames, channels]
+        (utils.py:170-173's `librosa.load(..., sr=16000, mono=True)`, batched; ingest.py)."""
+        from . import ingest as _ingest
+        return _ingest.resample_batch(pcm, fs_in, c.SAMPLE_RATE, lengths=lengths, out_dtype="i16", engine=self.eng)
+
     def voiced(self, pcm):
         """[n, L] int16 -> (packed voiced samples [n, L] int16, voiced_len [n] i32)."""
         if not self.use_vad:

@@ -532,6 +532,28 @@ def test_ingest_resample_parity(eng):
     np.testing.assert_allclose(y2.cpu().numpy(), 2 * ya.cpu().numpy(), rtol=0, atol=4e-6)
 
 
+def test_pipeline_ingest_feeds_the_int16_path(eng):
+    """48 kHz stereo recordings -> pipeline.ingest -> embed: same embeddings as feeding the oracle's
+    16 kHz int16 rendering of the same audio (up to the <= 1 LSB rounding ties of the resampler)."""
+    from oracle import ingest_ref
+    from speaker_verification_amd.model import seeded_model
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    mono16 = np.stack([synth.speaker_clip(s, 0) for s in range(4)])
+    stereo48 = np.repeat(np.repeat(mono16, 3, axis=1)[:, :, None], 2, axis=2)       # crude 48 kHz stereo source
+    model = seeded_model(0, n_labels=8).to(eng.device).eval()
+    pipe = VerificationPipeline(model, use_vad=False, crop_rng="device", crop_seed=5)
+    pcm16, lens = pipe.ingest(stereo48, 48000)
+    assert pcm16.dtype == torch.int16 and pcm16.shape == (4, 48000) and bool((lens == 48000).all())
+    want = np.stack([ingest_ref.to_int16(ingest_ref.resample_poly(ingest_ref.to_mono(stereo48[i]), 1, 3))
+                     for i in range(4)])
+    d = pcm16.cpu().numpy().astype(np.int32) - want.astype(np.int32)
+    assert np.abs(d).max() <= 1 and np.mean(d != 0) < 0.01
+    emb_a = pipe.embed(pcm16)
+    emb_b = pipe.embed(want)
+    assert emb_a.shape == (4, 128) and bool(torch.isfinite(emb_a).all())
+    np.testing.assert_allclose(emb_a.cpu().numpy(), emb_b.cpu().numpy(), rtol=1e-3, atol=1e-3)
+
+
 def test_load_wav_resamples_on_device(tmp_path):
     """load_data.load_wav (utils.py:170-173 drop-in) on a stereo 44.1 kHz file and on a mono 16 kHz one."""
     import wave
@@ -719,7 +741,7 @@ def test_siamese(eng, golden):
     loss = sia(lin, y, o1.requires_grad_(), o2)
     norms = [float(torch.norm(p.detach())) for p in lin.parameters()]
     want = scoring_ref.contrastive_loss(y.cpu().numpy(), g["l2_o1"], g["l2_o2"], norms, 0.001, 2.0)
-    assert float(loss) == pytest.approx(want, rel=1e-5)
+    assert float(loss.detach()) == pytest.approx(want, rel=1e-5)
     loss.backward()
     assert o1.grad is not None and torch.isfinite(o1.grad).all()
 
