@@ -86,30 +86,69 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float* __restrict__ t
 // ds_read_b128) and double-buffered: the next block's global loads are issued before the 128 MFMAs of
 // the current one and written to the other buffer after them.  16 MFMAs per ds_read_b128 pair instead
 // of 4 per pair of 16-byte global loads.
+// The 1 / norm of the enrolled rows comes from a one-wave-per-row pre-pass (inv_norm_kernel): summing
+// squares inside the main loop cost 64 VALU instructions per 128 MFMAs, and on gfx950 VALU and MFMA
+// issue never overlap.  Blocks that lie wholly inside both matrices (all but the last row / column
+// block) take wave-uniform fast paths for the loads and the stores: no per-element predicates.
 constexpr int CT_BM = 128, CT_BN = 32, CT_KB = 128, CT_LD = CT_KB + 8;
+
+// out[row] = 1 / ||x[row]||, a zero norm divides by 1 (sklearn normalize()).  One wave per row.
+__global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__ x, int n, int dim,
+                                                       float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += gridDim.x * 4) {
+    const float* p = x + (int64_t)row * dim;
+    float s = 0.f;
+    for (int k = lane; k < dim; k += 64) s = fmaf(p[k], p[k], s);
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s == 0.f ? 1.f : 1.0f / sqrtf(s);
+  }
+}
 
 template <bool HOIST>
 __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restrict__ test, const float* __restrict__ enroll,
-                                                           int nt, int ns, int dim, float* __restrict__ out) {
+                                                           const float* __restrict__ einv, int nt, int ns, int dim,
+                                                           float* __restrict__ out, int gy, int n_full, int tail_split) {
   __shared__ __attribute__((aligned(16))) float bs[2][CT_BN * CT_LD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
   const int nkb = (dim + CT_KB - 1) / CT_KB;
   const bool vec_ok = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(test) | reinterpret_cast<uintptr_t>(enroll)) & 15) == 0;
-  const int m0 = blockIdx.x * CT_BM + wave * 32;
-  // blockIdx.y splits the enrolled range so that a few tall row blocks still fill the chip
+  // Work items = (128-row block, 1 / gy of the enrolled range): gy > 1 lets a few tall row blocks
+  // still fill the chip.  The items of the last, partly filled round of workgroups are cut into
+  // `tail_split` pieces each, so that round costs 1 / tail_split of a full one (at the dev-set
+  // shape 1 162 items on 768 resident workgroups: 2 rounds -> 1.5).
+  int item = blockIdx.x, part = 0, parts = 1;
+  if (item >= n_full) {
+    const int t = item - n_full;
+    item = n_full + t / tail_split;
+    part = t % tail_split;
+    parts = tail_split;
+  }
+  const int m0 = (item / gy) * CT_BM + wave * 32;
   const int all_stiles = (ns + CT_BN - 1) / CT_BN;
-  const int per_y = (all_stiles + gridDim.y - 1) / gridDim.y;
-  const int st_begin = blockIdx.y * per_y;
-  const int n_stiles = min(all_stiles, st_begin + per_y);
+  const int per_y = (all_stiles + gy - 1) / gy;
+  int st_begin = (item % gy) * per_y;
+  int n_stiles = min(all_stiles, st_begin + per_y);
+  if (parts > 1) {
+    const int sub = (max(n_stiles - st_begin, 0) + parts - 1) / parts;
+    st_begin += part * sub;
+    n_stiles = min(n_stiles, st_begin + sub);
+  }
 
   // staging assignment: thread t moves 4 float4 of the 32 x 128 block: row = (t >> 5) + 8 j, float4 column = t & 31
   const int srow = threadIdx.x >> 5, scol = (threadIdx.x & 31) * 4;
   auto fetch = [&](int st, int kb, f32x4 (&regs)[4]) {
+    if (vec_ok && (st + 1) * CT_BN <= ns && (kb + 1) * CT_KB <= dim) {  // workgroup-uniform: whole block inside
+      const float* base = enroll + ((int64_t)st * CT_BN + srow) * dim + kb * CT_KB + scol;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = st * CT_BN + srow + 8 * j;
-      regs[j] = load4(enroll + (int64_t)r * dim, kb * CT_KB + scol, dim, r < ns, vec_ok);
+      for (int j = 0; j < 4; ++j) regs[j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(8 * j) * dim);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = st * CT_BN + srow + 8 * j;
+        regs[j] = load4(enroll + (int64_t)r * dim, kb * CT_KB + scol, dim, r < ns, vec_ok);
+      }
     }
   };
   auto stash = [&](float* buf, const f32x4 (&regs)[4]) {
@@ -143,6 +182,9 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) rinv[rt][r] = 1.0f / __shfl(tn[rt], 4 * kk + r, 64);
+  const bool rows_in = m0 + 32 <= nt;  // wave-uniform
+  // element offsets of this lane's first output of each (row tile, r): row (m0 + 16 rt + 4 kk + r), column i
+  float* const orow = out + (int64_t)(m0 + 4 * kk) * ns + i;
 
   f32x4 pre[4];
   if (st_begin >= n_stiles) return;  // uniform per workgroup
@@ -152,11 +194,17 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
   int cur = 0;
   for (int st = st_begin; st < n_stiles; ++st) {
     f32x4 acc[2][2];
-    float sn[2] = {0.f, 0.f};
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // this lane's two output columns: their 1 / norm is needed only after the MFMAs, load it now
+    float sinv[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int col = st * CT_BN + 16 * ct + i;
+      sinv[ct] = einv[col < ns ? col : ns - 1];
+    }
     for (int kb = 0; kb < nkb; ++kb) {
       // prefetch the next (enroll block, K block) while this one is multiplied
       const bool last_kb = kb + 1 == nkb;
@@ -179,7 +227,6 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           const f32x4 bv = *reinterpret_cast<const f32x4*>(b + (16 * ct + i) * CT_LD + 16 * u + 4 * kk);
-          sn[ct] += bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2] + bv[3] * bv[3];
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt) {
             acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][0], bv[0], acc[rt][ct], 0, 0, 0);
@@ -193,20 +240,27 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
       __syncthreads();  // everyone is done with bs[cur]; bs[cur ^ 1] is complete
       cur ^= 1;
     }
+    float* const o = orow + st * CT_BN;
+    if (rows_in && (st + 1) * CT_BN <= ns) {  // wave-uniform: the whole 32 x 32 block is inside: 16 plain stores
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      float s2 = sn[ct];
-      s2 += __shfl_xor(s2, 16, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      const float sinv = s2 == 0.f ? 1.f : 1.0f / sqrtf(s2);
-      const int col = st * CT_BN + 16 * ct + i;
-      if (col < ns) {
+      for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = m0 + 16 * rt + 4 * kk + r;
-            if (row < nt) out[(int64_t)row * ns + col] = acc[rt][ct][r] * rinv[rt][r] * sinv;
+          for (int ct = 0; ct < 2; ++ct)
+            o[(int64_t)(16 * rt + r) * ns + 16 * ct] = acc[rt][ct][r] * rinv[rt][r] * sinv[ct];
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int col = st * CT_BN + 16 * ct + i;
+        if (col < ns) {
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = m0 + 16 * rt + 4 * kk + r;
+              if (row < nt) out[(int64_t)row * ns + col] = acc[rt][ct][r] * rinv[rt][r] * sinv[ct];
+            }
           }
         }
       }
@@ -246,13 +300,30 @@ int svk_cosine_scores(svk_ctx* ctx, const float* d_test, const float* d_enroll, 
     const unsigned gx = (unsigned)((n_test + CT_BM - 1) / CT_BM);
     const unsigned stiles = (unsigned)((n_enroll + CT_BN - 1) / CT_BN);
     const unsigned gy = std::max(1u, std::min(stiles, (unsigned)(2 * ctx->num_cu + gx - 1) / gx));
-    const dim3 grid(gx, gy);
-    if (dim <= CT_KB)
-      hipLaunchKernelGGL(cosine_tiled_kernel<true>, grid, dim3(256), 0, ctx->stream, d_test, d_enroll, n_test,
-                         n_enroll, dim, d_out);
-    else
-      hipLaunchKernelGGL(cosine_tiled_kernel<false>, grid, dim3(256), 0, ctx->stream, d_test, d_enroll, n_test,
-                         n_enroll, dim, d_out);
+    const int rc = svk_ensure_work(ctx, sizeof(float) * (size_t)n_enroll);
+    if (rc != SVK_OK) return rc;
+    float* einv = static_cast<float*>(ctx->work);
+    hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)std::min((n_enroll + 3) / 4, ctx->num_cu * 8)), dim3(256), 0,
+                       ctx->stream, d_enroll, n_enroll, dim, einv);
+    auto kern = dim <= CT_KB ? cosine_tiled_kernel<true> : cosine_tiled_kernel<false>;
+    // resident workgroups = one "round"; the items of the last partial round are split (see the kernel)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, 0) != hipSuccess ||
+        per_cu < 1)
+      per_cu = 2;
+    const long long slots = (long long)per_cu * ctx->num_cu, items = (long long)gx * gy;
+    const long long n_full = (items / slots) * slots, rem = items - n_full;
+    const unsigned per_item_tiles = (stiles + gy - 1) / gy;
+    // pieces per tail item: minimise (rounds of pieces) x (column blocks per piece + ~2 blocks' worth of
+    // per-piece set-up: the test-row fragments and norms are loaded again)
+    long long split = 1, best = -1;
+    for (long long f = 1; rem > 0 && f <= std::max<long long>(1, per_item_tiles / 2); ++f) {
+      const long long cost = ((rem * f + slots - 1) / slots) * ((per_item_tiles + f - 1) / f + 2);
+      if (best < 0 || cost < best) best = cost, split = f;
+    }
+    const long long blocks = n_full + rem * split;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_test, d_enroll, einv, n_test, n_enroll,
+                       dim, d_out, (int)gy, (int)n_full, (int)split);
   } else {
     const int tiles = (n_test + 15) / 16;
     const unsigned grid = (unsigned)std::max(1, std::min((tiles + 3) / 4, ctx->num_cu * 8));

@@ -15,6 +15,8 @@ struct svk_ctx {
   int clock_khz = 0;
   int lds_per_cu = 160 * 1024;
   void* scratch = nullptr;  // 256 bytes of device memory for tiny reductions (svk_log_power)
+  void* work = nullptr;     // grow-only device workspace owned by the handle (row norms of svk_cosine_scores)
+  size_t work_bytes = 0;
   char err[512] = {0};
 };
 
@@ -26,6 +28,22 @@ inline int svk_fail(svk_ctx* ctx, int code, const char* fmt, ...) {
     va_end(ap);
   }
   return code;
+}
+
+// Grow-only workspace.  Kernels using it are ordered on ctx->stream; growing frees the old block
+// only after the stream has drained.
+inline int svk_ensure_work(svk_ctx* ctx, size_t bytes) {
+  if (ctx->work_bytes >= bytes) return SVK_OK;
+  if (ctx->work) {
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return svk_fail(ctx, SVK_ERR_HIP, "stream sync before workspace growth failed");
+    (void)hipFree(ctx->work);
+    ctx->work = nullptr;
+    ctx->work_bytes = 0;
+  }
+  const size_t want = (bytes + 4095) & ~(size_t)4095;
+  if (hipMalloc(&ctx->work, want) != hipSuccess) return svk_fail(ctx, SVK_ERR_OOM, "workspace of %zu bytes", want);
+  ctx->work_bytes = want;
+  return SVK_OK;
 }
 
 #define SVK_HIP(ctx, call)                                                                      \

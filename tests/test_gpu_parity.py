@@ -666,6 +666,20 @@ def test_cosine_scores_tiled_kernel(eng):
         want = scoring_ref.cosine_matrix(t, e)
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
         assert not got[5].any() and not got[:, 3].any()
+    # more 128-row blocks than resident workgroups: the last round's blocks are split along the enrolled
+    # range (scoring.hip: tail_split); rows of the first round, of the split tail and the ragged last block
+    nt, ns, d = 128 * 1100 + 37, 203, 128
+    t = rng.standard_normal((nt, d)).astype(np.float32)
+    e = rng.standard_normal((ns, d)).astype(np.float32)
+    got = eng.cosine_scores(t, e)
+    rows = np.r_[0:130, 128 * 700:128 * 700 + 130, 128 * 1024 - 2:128 * 1024 + 130, nt - 140:nt]
+    want = scoring_ref.cosine_matrix(t[rows], e)
+    np.testing.assert_allclose(got[torch.from_numpy(rows).to(got.device)].cpu().numpy(), want, rtol=0, atol=1e-5)
+    # every row is a unit-vector product: |score| <= 1 and the self-product of a copied row is 1
+    assert float(got.abs().max()) <= 1.0 + 1e-5
+    e2 = e.copy()
+    e2[7] = t[128 * 1050 + 5]
+    assert abs(float(eng.cosine_scores(t, e2)[128 * 1050 + 5, 7]) - 1.0) <= 1e-5
 
 
 def test_evaluation_dropin(eng, golden):
