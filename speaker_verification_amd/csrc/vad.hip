@@ -34,7 +34,34 @@ __global__ __launch_bounds__(256) void vad_kernel(const int16_t* __restrict__ pc
   const int16_t* x = pcm + off;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-  for (int f = wave; f < nf; f += 4) {
+  // Usual geometry (30 ms at 16 kHz = 480 samples = 60 16-byte vectors, clip on a 16-byte boundary):
+  // a frame is ONE vector per lane, and a wave keeps eight frames' loads in flight (one load per
+  // trip followed by its own reduction paid a full memory round trip per frame).
+  const int nvec_f = fsamp >> 3;
+  const bool one_vec = (fsamp & 7) == 0 && nvec_f <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  constexpr int VU = 8;
+  for (int f0 = wave; one_vec && f0 < nf; f0 += 4 * VU) {
+    i16x8 v[VU];
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int f = f0 + 4 * u;
+      const bool on = f < nf && lane < nvec_f;
+      v[u] = *reinterpret_cast<const i16x8*>(x + (on ? (int64_t)f * fsamp + 8 * lane : 0));
+      if (!on) v[u] = (i16x8)(short)0;
+    }
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int f = f0 + 4 * u;
+      if (f >= nf) break;  // wave-uniform
+      long long acc = 0;   // squares of 16-bit values pair up in 32 bits: a^2 + b^2 <= 2^31
+#pragma unroll
+      for (int e = 0; e < 8; e += 2)
+        acc += (long long)((unsigned)((int)v[u][e] * (int)v[u][e]) + (unsigned)((int)v[u][e + 1] * (int)v[u][e + 1]));
+      acc = wave_sum(acc);
+      if (lane == 0) flag[f] = acc > threshold * (long long)fsamp ? 1 : 0;
+    }
+  }
+  for (int f = wave; !one_vec && f < nf; f += 4) {
     const int16_t* fr = x + (int64_t)f * fsamp;
     long long acc = 0;
     const bool aligned = (reinterpret_cast<uintptr_t>(fr) & 15) == 0;
@@ -99,7 +126,21 @@ __global__ __launch_bounds__(256) void vad_kernel(const int16_t* __restrict__ pc
   }
   if (voiced) {
     int16_t* dst = voiced + off;
-    for (int f = wave; f < nf; f += 4) {
+    const bool one_vec_copy = one_vec && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (int f0 = wave; one_vec_copy && f0 < nf; f0 += 4 * VU) {  // eight frames' loads first, then their stores
+      i16x8 v[VU];
+      int pf[VU];
+#pragma unroll
+      for (int u = 0; u < VU; ++u) {
+        const int f = f0 + 4 * u;
+        pf[u] = f < nf ? pos[f] : -1;
+        if (pf[u] >= 0 && lane < nvec_f) v[u] = *reinterpret_cast<const i16x8*>(x + (int64_t)f * fsamp + 8 * lane);
+      }
+#pragma unroll
+      for (int u = 0; u < VU; ++u)
+        if (pf[u] >= 0 && lane < nvec_f) *reinterpret_cast<i16x8*>(dst + (int64_t)pf[u] * fsamp + 8 * lane) = v[u];
+    }
+    for (int f = wave; !one_vec_copy && f < nf; f += 4) {
       const int pf = pos[f];
       if (pf < 0) continue;
       const int16_t* s = x + (int64_t)f * fsamp;
