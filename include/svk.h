@@ -158,7 +158,8 @@ int svk_log_power(svk_ctx* ctx, float* d_power, int64_t n, int32_t normalize);
  * d_keep       : [n_utt][max_vad_frames] uint8, 1 = frame is in some yielded segment
  * d_seg        : [n_utt][max_vad_frames] int32 segment ordinal or -1, or NULL
  * d_n_vad_frames: [n_utt] int32, or NULL
- * d_voiced     : int16, same offsets as d_pcm: kept frames packed to the front, or NULL
+ * d_voiced     : int16, same offsets as d_pcm: kept frames packed to the front (the rest of a
+ *                clip's slot is left untouched), or NULL
  * d_voiced_len : [n_utt] int32 samples kept (required when d_voiced != NULL)
  */
 int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t* d_offsets, const int32_t* d_lengths,

@@ -5,8 +5,9 @@
 // delegates to webrtcvad (vad.py:90) is this build's integer rule
 //     sum(x^2) > threshold * frame_samples                       (int64, bit-exact)
 // Phase 1 (all waves): per-frame sum of squares with 16-byte loads and a wave reduction.
-// Phase 2 (one lane): the hysteresis is inherently sequential over <= a few thousand
-//     frames; it runs out of LDS and records keep / segment / packed position per frame.
+// Phase 2 (wave 0, wave-uniform): the hysteresis is inherently sequential over <= a few thousand
+//     frames; the flags travel as 64-bit ballot masks and the walk is scalar arithmetic; it
+//     records keep / segment / packed position per frame.
 // Phase 3 (all waves): kept frames are copied to the front of the clip's output slot.
 // HBM-bound: 2 bytes read per sample (+2 written when compacting).
 #include "svk_internal.h"
@@ -14,10 +15,11 @@
 namespace {
 
 constexpr int MAX_VAD_FRAMES = 8192;  // LDS budget: 245 s of 30 ms frames per clip
+constexpr int VAD_THREADS = 256;
 
 typedef short i16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256) void vad_kernel(const int16_t* __restrict__ pcm, const int64_t* __restrict__ offsets,
+__global__ __launch_bounds__(VAD_THREADS) void vad_kernel(const int16_t* __restrict__ pcm, const int64_t* __restrict__ offsets,
                                                   const int32_t* __restrict__ lengths, int64_t clip_stride,
                                                   int clip_len, int fsamp, int ring_len, int ring_thresh,
                                                   long long threshold, int max_vf, uint8_t* __restrict__ keep_out,
@@ -33,6 +35,7 @@ __global__ __launch_bounds__(256) void vad_kernel(const int16_t* __restrict__ pc
   if (nf > max_vf) nf = max_vf;
   const int16_t* x = pcm + off;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = VAD_THREADS / 64;
 
   // Usual geometry (30 ms at 16 kHz = 480 samples = 60 16-byte vectors, clip on a 16-byte boundary):
   // a frame is ONE vector per lane, and a wave keeps eight frames' loads in flight (one load per
@@ -40,18 +43,18 @@ __global__ __launch_bounds__(256) void vad_kernel(const int16_t* __restrict__ pc
   const int nvec_f = fsamp >> 3;
   const bool one_vec = (fsamp & 7) == 0 && nvec_f <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
   constexpr int VU = 8;
-  for (int f0 = wave; one_vec && f0 < nf; f0 += 4 * VU) {
+  for (int f0 = wave; one_vec && f0 < nf; f0 += NW * VU) {
     i16x8 v[VU];
 #pragma unroll
     for (int u = 0; u < VU; ++u) {
-      const int f = f0 + 4 * u;
+      const int f = f0 + NW * u;
       const bool on = f < nf && lane < nvec_f;
       v[u] = *reinterpret_cast<const i16x8*>(x + (on ? (int64_t)f * fsamp + 8 * lane : 0));
       if (!on) v[u] = (i16x8)(short)0;
     }
 #pragma unroll
     for (int u = 0; u < VU; ++u) {
-      const int f = f0 + 4 * u;
+      const int f = f0 + NW * u;
       if (f >= nf) break;  // wave-uniform
       long long acc = 0;   // squares of 16-bit values pair up in 32 bits: a^2 + b^2 <= 2^31
 #pragma unroll
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void vad_kernel(const int16_t* __restrict__ pc
       if (lane == 0) flag[f] = acc > threshold * (long long)fsamp ? 1 : 0;
     }
   }
-  for (int f = wave; !one_vec && f < nf; f += 4) {
+  for (int f = wave; !one_vec && f < nf; f += NW) {
     const int16_t* fr = x + (int64_t)f * fsamp;
     long long acc = 0;
     const bool aligned = (reinterpret_cast<uintptr_t>(fr) & 15) == 0;
@@ -81,58 +84,92 @@ __global__ __launch_bounds__(256) void vad_kernel(const int16_t* __restrict__ pc
   }
   __syncthreads();
 
-  if (threadIdx.x == 0) {
+  if (wave == 0) {
+    // The hysteresis is sequential, but nothing in it is per-lane: the whole of wave 0 walks it with
+    // wave-uniform (scalar) state.  64 frame flags at a time become one ballot mask; lane b keeps
+    // the result of frame f0 + b in a register and the chunk is written back with one store per
+    // lane.  (A single lane reading flag[f] and flag[f - ring_len] out of LDS every step was one
+    // LDS round trip per frame.)
     // ring buffer = the last min(since_clear, ring_len) frames since it was last cleared
     bool triggered = false;
     int since = 0, voiced_in_ring = 0, kept = 0, seg = 0;
-    for (int f = 0; f < nf; ++f) {
-      const int s = flag[f];
-      if (since == ring_len) voiced_in_ring -= flag[f - ring_len];  // deque(maxlen) drops the oldest
-      else ++since;
-      voiced_in_ring += s;
-      int my_seg = -1, my_pos = -1;
-      if (!triggered) {
-        if (voiced_in_ring > ring_thresh) {  // vad.py:99  num_voiced > 0.9 * maxlen
-          triggered = true;
-          for (int g = f - since + 1; g <= f; ++g) {  // vad.py:105-106: the whole ring is emitted
-            pos[g] = kept++;
-            if (seg_out) seg_out[(int64_t)utt * max_vf + g] = seg;
-          }
-          since = 0;
-          voiced_in_ring = 0;
-          continue;
+    unsigned long long prev = 0;
+    for (int f0 = 0; f0 < nf; f0 += 64) {
+      const int fl = f0 + lane;
+      const unsigned long long m = __ballot(fl < nf && flag[fl] != 0);
+      int my_pos = -1, my_seg = -1;
+      const int cnt = nf - f0 < 64 ? nf - f0 : 64;
+      for (int b = 0; b < cnt; ++b) {
+        const int f = f0 + b;
+        const int sbit = (int)((m >> b) & 1ull);
+        if (since == ring_len) {  // deque(maxlen) drops the oldest: flag[f - ring_len]
+          const int o = b - ring_len;
+          voiced_in_ring -= o >= 0 ? (int)((m >> o) & 1ull) : (int)((prev >> (64 + o)) & 1ull);
+        } else {
+          ++since;
         }
-      } else {
-        my_seg = seg;
-        my_pos = kept++;
-        if (since - voiced_in_ring > ring_thresh) {  // vad.py:117  num_unvoiced > 0.9 * maxlen
-          triggered = false;
-          ++seg;
-          since = 0;
-          voiced_in_ring = 0;
+        voiced_in_ring += sbit;
+        int v_pos = -1, v_seg = -1;
+        if (!triggered) {
+          if (voiced_in_ring > ring_thresh) {  // vad.py:99  num_voiced > 0.9 * maxlen
+            triggered = true;
+            for (int g = f - since + 1; g <= f; ++g) {  // vad.py:105-106: the whole ring is emitted
+              if (lane == (g & 63)) {                   // the lane that owns frame g (f0 is a multiple of 64)
+                if (g >= f0) {
+                  my_pos = kept;
+                  my_seg = seg;
+                } else {  // frame of the previous chunk: already written back as -1
+                  pos[g] = kept;
+                  if (seg_out) seg_out[(int64_t)utt * max_vf + g] = seg;
+                }
+              }
+              ++kept;
+            }
+            since = 0;
+            voiced_in_ring = 0;
+            continue;
+          }
+        } else {
+          v_seg = seg;
+          v_pos = kept++;
+          if (since - voiced_in_ring > ring_thresh) {  // vad.py:117  num_unvoiced > 0.9 * maxlen
+            triggered = false;
+            ++seg;
+            since = 0;
+            voiced_in_ring = 0;
+          }
+        }
+        if (lane == b) {
+          my_pos = v_pos;
+          my_seg = v_seg;
         }
       }
-      pos[f] = my_pos;
-      if (seg_out) seg_out[(int64_t)utt * max_vf + f] = my_seg;
+      if (fl < nf) {
+        pos[fl] = my_pos;
+        if (seg_out) seg_out[(int64_t)utt * max_vf + fl] = my_seg;
+      }
+      prev = m;
     }
-    if (nvf_out) nvf_out[utt] = nf;
-    if (voiced_len) voiced_len[utt] = kept * fsamp;
+    if (lane == 0) {
+      if (nvf_out) nvf_out[utt] = nf;
+      if (voiced_len) voiced_len[utt] = kept * fsamp;
+    }
   }
   __syncthreads();
 
-  for (int f = threadIdx.x; f < max_vf; f += 256) {
+  for (int f = threadIdx.x; f < max_vf; f += VAD_THREADS) {
     keep_out[(int64_t)utt * max_vf + f] = (f < nf && pos[f] >= 0) ? 1 : 0;
     if (seg_out && f >= nf) seg_out[(int64_t)utt * max_vf + f] = -1;
   }
   if (voiced) {
     int16_t* dst = voiced + off;
     const bool one_vec_copy = one_vec && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
-    for (int f0 = wave; one_vec_copy && f0 < nf; f0 += 4 * VU) {  // eight frames' loads first, then their stores
+    for (int f0 = wave; one_vec_copy && f0 < nf; f0 += NW * VU) {  // eight frames' loads first, then their stores
       i16x8 v[VU];
       int pf[VU];
 #pragma unroll
       for (int u = 0; u < VU; ++u) {
-        const int f = f0 + 4 * u;
+        const int f = f0 + NW * u;
         pf[u] = f < nf ? pos[f] : -1;
         if (pf[u] >= 0 && lane < nvec_f) v[u] = *reinterpret_cast<const i16x8*>(x + (int64_t)f * fsamp + 8 * lane);
       }
@@ -140,7 +177,7 @@ __global__ __launch_bounds__(256) void vad_kernel(const int16_t* __restrict__ pc
       for (int u = 0; u < VU; ++u)
         if (pf[u] >= 0 && lane < nvec_f) *reinterpret_cast<i16x8*>(dst + (int64_t)pf[u] * fsamp + 8 * lane) = v[u];
     }
-    for (int f = wave; !one_vec_copy && f < nf; f += 4) {
+    for (int f = wave; !one_vec_copy && f < nf; f += NW) {
       const int pf = pos[f];
       if (pf < 0) continue;
       const int16_t* s = x + (int64_t)f * fsamp;
@@ -175,7 +212,7 @@ extern "C" int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t*
   if (max_vad_frames > MAX_VAD_FRAMES)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "at most %d VAD frames per clip, got %d", MAX_VAD_FRAMES,
                     max_vad_frames);
-  hipLaunchKernelGGL(vad_kernel, dim3(n_utt), dim3(256), 0, ctx->stream, d_pcm, d_offsets, d_lengths, clip_stride,
+  hipLaunchKernelGGL(vad_kernel, dim3(n_utt), dim3(VAD_THREADS), 0, ctx->stream, d_pcm, d_offsets, d_lengths, clip_stride,
                      clip_len, frame_samples, ring_len, ring_thresh, (long long)threshold, max_vad_frames, d_keep,
                      d_seg, d_n_vad_frames, d_voiced, d_voiced_len);
   SVK_LAUNCH_CHECK(ctx);
