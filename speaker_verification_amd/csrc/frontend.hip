@@ -310,14 +310,16 @@ struct SpecGeneric {
   static constexpr int STRIDE = -1, FLEN = -1, N_STEPS = -1, PRE = -1, KP = -1, NEED_ENERGY = -1, N_FT = -1, N_CT = -1,
                        OUT_KIND = -1, NFILT = -1, NCOLS = -1, DC_ELIM = -1;
 };
-// speechpy.feature.mfcc(fs 16 kHz, 20 ms / 10 ms, 40 filters, 13 cepstra, nfft 512) after pre-emphasis
+// speechpy.feature.mfcc(fs 16 kHz, 20 ms / 10 ms, 40 filters, 13 cepstra, nfft 512), with or without
+// the fused pre-emphasis (PRE stays a launch parameter: one wave-uniform branch per frame read)
 struct SpecMfcc13 {
-  static constexpr int STRIDE = 160, FLEN = 320, N_STEPS = 5, PRE = 1, KP = 128, NEED_ENERGY = 1, N_FT = 3, N_CT = 1,
+  static constexpr int STRIDE = 160, FLEN = 320, N_STEPS = 5, PRE = -1, KP = 128, NEED_ENERGY = 1, N_FT = 3, N_CT = 1,
                        OUT_KIND = SVK_OUT_MFCC, NFILT = 40, NCOLS = 13, DC_ELIM = 1;
 };
-// the model's front end: lmfe(25 ms / 10 ms, 40 filters, nfft 1024) after pre-emphasis (load_data.py:64-70)
+// the model's front end: lmfe(25 ms / 10 ms, 40 filters, nfft 1024) (load_data.py:64-70), with or without
+// the fused pre-emphasis
 struct SpecLmfe40 {
-  static constexpr int STRIDE = 160, FLEN = 400, N_STEPS = 4, PRE = 1, KP = 256, NEED_ENERGY = 0, N_FT = 3, N_CT = 0,
+  static constexpr int STRIDE = 160, FLEN = 400, N_STEPS = 4, PRE = -1, KP = 256, NEED_ENERGY = 0, N_FT = 3, N_CT = 0,
                        OUT_KIND = SVK_OUT_LMFE, NFILT = 40, NCOLS = 40, DC_ELIM = 0;
 };
 
@@ -661,7 +663,7 @@ void (*pick_kernel(bool split, int tile))(const FrontendParams) {
 template <typename Spec>
 bool spec_matches(const FrontendParams& p) {
   return p.stride == Spec::STRIDE && p.flen == Spec::FLEN && p.flen_eff == Spec::FLEN && p.n_steps == Spec::N_STEPS &&
-         (p.preemph != 0) == (Spec::PRE != 0) && (!p.preemph || p.pre_shift == 1) && p.kp == Spec::KP &&
+         (Spec::PRE < 0 || (p.preemph != 0) == (Spec::PRE != 0)) && (!p.preemph || p.pre_shift == 1) && p.kp == Spec::KP &&
          (p.need_energy != 0) == (Spec::NEED_ENERGY != 0) && p.n_ft == Spec::N_FT && p.n_ct == Spec::N_CT &&
          p.out_kind == Spec::OUT_KIND && p.nfilt == Spec::NFILT && p.ncols == Spec::NCOLS &&
          (Spec::OUT_KIND != SVK_OUT_MFCC || (p.dc_elim != 0) == (Spec::DC_ELIM != 0));
