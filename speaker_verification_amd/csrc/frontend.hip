@@ -344,6 +344,8 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
   float* dct_lds = reinterpret_cast<float*>(smem + (size_t)p.n_slots * 64 * sizeof(f32x4));
   for (int i = threadIdx.x; i < p.n_slots * 64; i += blockDim.x) fb_lds[i] = p.fbfrag[i];
   for (int i = threadIdx.x; i < c_n_ct * c_n_ft * 4 * 64; i += blockDim.x) dct_lds[i] = p.dctfrag[i];
+  int* tile_counter = reinterpret_cast<int*>(smem + p.table_bytes - 16);
+  if (threadIdx.x == 0) *tile_counter = 0;
   __syncthreads();  // the only workgroup-wide barrier; from here on waves never wait for each other
   // private to this wave
   // the wave index is uniform: say so, or every per-tile index computation lands on the VALU
@@ -367,18 +369,21 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) t3[q] = p.tw3[q * 64 + lane_id];
   }
-  // Consecutive tiles go to the waves of one workgroup (neighbours share the overlapping PCM in
-  // L1).  (clip, tile-in-clip) advance incrementally: one division here instead of a 64-bit
-  // divide + modulo per tile.
+  // The workgroup owns tiles {r * grid * n_waves + block * n_waves + w}: n_waves consecutive tiles per
+  // round r (neighbours share the overlapping PCM in L1).  Its waves take them in that order from a
+  // counter in LDS rather than by a fixed stride: tiles differ in cost (a clip's last tile, clips
+  // shortened by the VAD), and with fixed shares the waves of a CU finished up to 17 % apart.
   const int tpu = p.tiles_per_utt;
-  const int step = (int)gridDim.x * n_waves, step_utt = step / tpu, step_ft = step % tpu;
-  const int first = (int)blockIdx.x * n_waves + wave;
-  int utt = first / tpu, ft = first % tpu;
-  for (; utt < p.n_utt; utt += step_utt, ft += step_ft) {
-    if (ft >= tpu) {
-      ft -= tpu;
-      if (++utt >= p.n_utt) break;
-    }
+  const unsigned total_tiles = (unsigned)p.n_utt * (unsigned)tpu;  // < 2^31: checked by svk_frontend_run
+  const unsigned round_stride = gridDim.x * (unsigned)n_waves;
+  for (;;) {
+    int ticket = 0;
+    if (lane_id == 0) ticket = atomicAdd(tile_counter, 1);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    const unsigned round = (unsigned)ticket / (unsigned)n_waves;
+    const unsigned tile = round * round_stride + blockIdx.x * (unsigned)n_waves + ((unsigned)ticket - round * (unsigned)n_waves);
+    if (round > total_tiles / round_stride || tile >= total_tiles) break;  // the counter only grows: every wave gets here
+    const int utt = (int)(tile / (unsigned)tpu), ft = (int)(tile - (unsigned)utt * (unsigned)tpu);
     // An opaque per-tile copy of the lane id: without it the compiler hoists every lane-derived
     // address and predicate of the tile body out of this loop and pins ~40 VGPRs for the whole
     // kernel (172 -> 3 waves per SIMD become 2); recomputing them per tile is a few dozen VALU.
@@ -746,7 +751,7 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
   }
   plan->table_bytes = plan->n_slots * 64 * (int)sizeof(f32x4) +
                       std::max(plan->n_ct, 0) * plan->n_ft * 4 * 64 * (int)sizeof(float);
-  plan->table_bytes = ((plan->table_bytes + 15) / 16) * 16;
+  plan->table_bytes = ((plan->table_bytes + 15) / 16) * 16 + 16;  // + the workgroup's tile counter
   // Tile size: 8 frames leave half of the MFMA N dimension idle but halve the per-wave LDS slice,
   // i.e. double the waves a CU can hold.  SVK_FRONTEND_TILE=8|16 overrides (tuning).
   {
@@ -906,6 +911,9 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   int waves = (int)std::max<int64_t>(1, std::min<int64_t>(lds.waves, (total + ctx->num_cu - 1) / ctx->num_cu));
   if (const char* env = getenv("SVK_FE_WAVES")) waves = std::max(1, std::min(waves, atoi(env)));  // tuning only
   const int64_t grid = std::min<int64_t>((total + waves - 1) / waves, ctx->num_cu);
+  if ((int64_t)n_utt * p.tiles_per_utt >= ((int64_t)1 << 31))
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "%lld frame tiles in one launch (limit 2^31): split the batch",
+                    (long long)n_utt * p.tiles_per_utt);
   const size_t lds_total = (size_t)plan->table_bytes + (size_t)waves * lds.wave_bytes;
   const bool split = plan->cfg.nfft == 1024;
   void (*kern)(const FrontendParams) = nullptr;
