@@ -1,0 +1,23 @@
+#!/bin/bash
+# Everything profiles/ is built from, in one pass on the GPU box (from the repo root):
+#   bash tools/refresh_profiles.sh
+# then, back in the build container:  python tools/summarize_prof.py rNN
+# Separate rocprofv3 runs: kernel trace + stats on the end-to-end bench, one --pmc pass per counter
+# group on `bench.py --frontend-only` (never --pmc together with other trace domains).
+set -e
+root=${GRAFT_REPO_ROOT:-$PWD}
+out=$root/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+echo "[1/5] kernel trace + stats of the end-to-end bench"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bench -- python3 $root/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
+echo "[2/5] HBM read / write counters"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --frontend-only > $out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py --frontend-only > $out/pmc_write.log 2>&1
+echo "[3/5] SQ counters"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_sq -- python3 $root/bench.py --frontend-only > $out/pmc_sq.log 2>&1
+echo "[4/5] stall composition"
+bash $root/tools/pmc_stalls.sh final
+cd /tmp
+echo "[5/5] the bench itself"
+python3 $root/bench.py --steps 3 --warmup 1 > $out/bench_final.json 2> $out/bench_final.err
+echo done

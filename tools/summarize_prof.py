@@ -18,7 +18,8 @@ import sys
 from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OURS = ("frontend_kernel", "cmvn_kernel", "vad_kernel", "cube_gather_kernel", "cosine_kernel", "draw_crops_kernel")
+OURS = ("frontend_kernel", "cmvn_kernel", "vad_kernel", "cube_gather_kernel", "cosine_kernel", "cosine_tiled_kernel",
+        "inv_norm_kernel", "draw_crops_kernel", "decimate_kernel", "resample_kernel")
 
 
 def short(name):
@@ -85,6 +86,22 @@ def main():
         with open(os.path.join(out_dir, f"{tag}_frontend_pmc.json"), "w") as fh:
             json.dump(result, fh, indent=1, sort_keys=True)
         print(json.dumps(result, indent=1, sort_keys=True))
+    # the bench lines of the same pass and the stall-composition table (tools/refresh_profiles.sh)
+    import shutil
+    import subprocess
+    for src, dst in (("bench_final.json", f"{tag}_bench.json"), ("bench_under_rocprof.json", f"{tag}_bench_under_rocprof.json")):
+        path = os.path.join(REPO, "gpurun_out", src)
+        if os.path.exists(path) and os.path.getsize(path) > 0:
+            shutil.copyfile(path, os.path.join(out_dir, dst))
+            print("copied", dst)
+    if glob.glob(os.path.join(REPO, "gpurun_out", "final_1", "**", "*_counter_collection.csv"), recursive=True):
+        table = subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_table.py"), "final"],
+                               capture_output=True, text=True).stdout
+        with open(os.path.join(out_dir, f"{tag}_frontend_stalls.txt"), "w") as fh:
+            fh.write("# per-launch averages, bench.py --frontend-only (1 024 x 3 s clips per launch), three separate\n"
+                     "# rocprofv3 --pmc passes (tools/pmc_stalls.sh).  *_CYCLES of waves are in units of 4 clocks\n"
+                     "# (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*); SQ_VALU_MFMA_BUSY_CYCLES is in clocks.\n" + table)
+        print("wrote", f"{tag}_frontend_stalls.txt")
 
 
 if __name__ == "__main__":
