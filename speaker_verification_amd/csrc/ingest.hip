@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void decimate_kernel(const int16_t* __restrict
                                                        int64_t out_stride, int clip_out, int32_t* __restrict__ out_len) {
   constexpr int HALF = 10 * DOWN, NT = 2 * HALF + 1, R = 3, OUT_WG = 256 * R;
   constexpr int SPAN = (OUT_WG - 1) * DOWN + NT + 8;  // + 8: the staged span starts on a 16-byte boundary
-  __shared__ float xs[SPAN];
+  __shared__ __attribute__((aligned(16))) float xs[SPAN];
   typedef short i16x8 __attribute__((ext_vector_type(8)));
   const int utt = blockIdx.y;
   const int n_in = in_len ? in_len[utt] : clip_in;
@@ -128,9 +128,15 @@ __global__ __launch_bounds__(256) void decimate_kernel(const int16_t* __restrict
         f[e] = (float)acc * scale;
       }
     }
+    if (8 * v + 8 <= SPAN) {  // two 16-byte stores (eight scalar ones at a stride of 8 floats between lanes: 16-way bank conflicts)
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<f32x4*>(xs + 8 * v) = (f32x4){f[0], f[1], f[2], f[3]};
+      *reinterpret_cast<f32x4*>(xs + 8 * v + 4) = (f32x4){f[4], f[5], f[6], f[7]};
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (8 * v + e < SPAN) xs[8 * v + e] = f[e];
+      for (int e = 0; e < 8; ++e)
+        if (8 * v + e < SPAN) xs[8 * v + e] = f[e];
+    }
   }
   __syncthreads();
   const int m = m0 + R * threadIdx.x;
