@@ -119,6 +119,43 @@ class FusedEmbedder:
             self.first_as_gemm = bool(channels_last and w0.shape[1] == 1 and w0.shape[3] == 1 and
                                       self.stages[0][3] == (1, 1, 1))
             self._gemm_cache = {}
+            self.row_fold = self._row_fold_tables(fmt) if channels_last else None
+
+    def _row_fold_tables(self, fmt):
+        """Stages 1-3 (conv1_2, conv2_1, conv2_2 of C3D2) with the PARITY OF THE ROW folded into the
+        channels -- a pure re-indexing (same products, another summation order):
+          * conv1_2 (kernel (kd, kh, 1), row stride 2) becomes a Toeplitz-widened conv that emits two
+            output rows per position as 2 x co channels: kernel (kd, kh + 2, 1), row stride 4.  It has
+            1.22x the multiply-adds but a GEMM N of 32 instead of 16: 5.3 -> 4.2 ms per 978 cubes;
+          * conv2_1 (kernel (kd, 1, kw)) never mixes rows: a 2-group conv over the (parity, channel) pairs;
+          * conv2_2 (kernel (kd, 8, 1), row stride 2) over rows 2 hp + parity is a stride-1 conv with
+            kernel (kd, 4, 1) over row PAIRS whose input channels are (parity, ci): it un-folds the
+            layout for free.
+        The max-pool / PReLU between them act per channel along W and are unaffected (slopes tiled).
+        Returns None when the layer shapes do not have this structure."""
+        try:
+            (w1, b1, s1, st1, _, _), (w2, b2, s2, st2, _, _), (w3, b3, s3, st3, _, _) = self.stages[1:4]
+        except ValueError:
+            return None
+        ok = (tuple(st1) == (1, 2, 1) and w1.shape[4] == 1 and tuple(st2) == (1, 1, 1) and w2.shape[3] == 1 and
+              tuple(st3) == (1, 2, 1) and w3.shape[4] == 1 and w3.shape[3] % 2 == 0 and
+              w2.shape[1] == w1.shape[0] and w3.shape[1] == w2.shape[0])
+        if not ok:
+            return None
+        co1, ci1, kd1, kh1, _ = w1.shape
+        f1 = torch.zeros(2, co1, ci1, kd1, kh1 + 2, 1, dtype=w1.dtype, device=w1.device)
+        for parity in range(2):
+            f1[parity, :, :, :, 2 * parity:2 * parity + kh1, :] = w1
+        f1 = f1.reshape(2 * co1, ci1, kd1, kh1 + 2, 1).contiguous(memory_format=fmt)
+        f2 = w2.repeat(2, 1, 1, 1, 1).contiguous(memory_format=fmt)                  # groups = 2
+        co3, ci3, kd3, kh3, _ = w3.shape
+        # f3[co, parity * ci3 + ci, kd, khp] = w3[co, ci, kd, 2 khp + parity]
+        f3 = (w3.reshape(co3, ci3, kd3, kh3 // 2, 2, 1).permute(0, 4, 1, 2, 3, 5)
+              .reshape(co3, 2 * ci3, kd3, kh3 // 2, 1).contiguous(memory_format=fmt))
+        def tile(slope):                      # nn.PReLU() has ONE slope; a per-channel one follows its channels
+            return slope if slope.numel() == 1 else slope.repeat(2)
+        return {"kh1": kh1, 1: (f1, b1.repeat(2), tile(s1), (1, 4, 1), 1),
+                2: (f2, b2.repeat(2), tile(s2), (1, 1, 1), 2), 3: (f3, b3, s3, (1, 1, 1), 1)}
 
     def _first_layer_tables(self, ow):
         """(G, Toeplitz weight matrix, tiled bias) for an output width `ow`; G = largest divisor <= 12."""
@@ -140,7 +177,16 @@ class FusedEmbedder:
     def __call__(self, x):
         if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last_3d)
+        fold = None
         for li, (w, b, slope, stride, pool, pool_first) in enumerate(self.stages):
+            groups = 1
+            if li == 1 and self.row_fold is not None:
+                # rows fold only when conv1_2's output has an even number of rows that the stride-4 form reproduces
+                h_out = (x.shape[3] - self.row_fold["kh1"]) // 2 + 1
+                if h_out % 2 == 0 and (x.shape[3] - self.row_fold["kh1"] - 2) // 4 + 1 == h_out // 2:
+                    fold = self.row_fold
+            if fold is not None and li in (1, 2, 3):
+                w, b, slope, stride, groups = fold[li]
             if li == 0 and self.first_as_gemm:
                 n, _, d, h, wd = x.shape
                 kd, kw = w.shape[2], w.shape[4]
@@ -151,7 +197,7 @@ class FusedEmbedder:
                 x = torch.addmm(bt, windows.reshape(n * od * h * (ow // G), kd * (kw + G - 1)), wt)
                 x = x.view(n, od, h, ow, w.shape[0]).permute(0, 4, 1, 2, 3)     # NDHWC memory = channels_last_3d
             else:
-                x = F.conv3d(x, w, b, stride=stride)
+                x = F.conv3d(x, w, b, stride=stride, groups=groups)
             if pool_first:
                 # MaxPool3d((1,1,2)) as one element-wise max of the even and odd columns (an odd last
                 # column is dropped, as the pooling floor does): 2.3x faster than max_pool3d here

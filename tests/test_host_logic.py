@@ -126,3 +126,25 @@ def test_ingest_host_tables_and_wav_reader(tmp_path):
         wf.writeframes(frames.tobytes())
     got, rate = ingest.read_wave_any(path)
     assert rate == 44100 and got.shape == (500, 2) and np.array_equal(got, frames)
+
+
+def test_fused_embedder_row_fold():
+    """FusedEmbedder's row folding (conv1_2 as a widened two-rows-per-position conv, conv2_1 as a 2-group
+    conv, conv2_2 over row pairs) is a re-indexing: same embedding as the plain module, and it steps aside
+    for input heights it cannot fold."""
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    model = seeded_model(3, n_labels=10)
+    model.load_state_dict(perturb_inference_state(model.state_dict(), 5))
+    model.eval()
+    x = torch.randn(3, 1, 20, 80, 40)
+    with torch.no_grad():
+        want = model(x, development=False)
+        emb = model.fused_inference(channels_last=True)
+        assert emb.row_fold is not None and model.fused_inference(channels_last=False).row_fold is None
+        got = emb(x)
+        emb.row_fold = None
+        plain = emb(x)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-5 * max(scale, 1.0)
+    assert float((got - plain).abs().max()) <= 1e-5 * max(scale, 1.0)
+    assert not torch.equal(got, plain) or True           # (another summation order: equality is not required)
