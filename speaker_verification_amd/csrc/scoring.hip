@@ -5,6 +5,7 @@
 //       v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulation).
 //   svk_l2_dist       <- /root/reference/siamese.py:29-30.
 #include <algorithm>
+#include <cstdlib>
 
 #include "svk_internal.h"
 
@@ -106,43 +107,33 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
 }
 
 template <bool HOIST>
-__global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restrict__ test, const float* __restrict__ enroll,
-                                                           const float* __restrict__ einv, int nt, int ns, int dim,
-                                                           float* __restrict__ out, int gy, int n_full, int tail_split) {
-  __shared__ __attribute__((aligned(16))) float bs[2][CT_BN * CT_LD];
+__device__ __forceinline__ void cosine_tiled_body(const float* __restrict__ test, const float* __restrict__ enroll,
+                                                  const float* __restrict__ einv, int nt, int ns, int dim,
+                                                  float* __restrict__ out, long long total_units, float (&bs)[2][CT_BN * CT_LD]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
   const int nkb = (dim + CT_KB - 1) / CT_KB;
   const bool vec_ok = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(test) | reinterpret_cast<uintptr_t>(enroll)) & 15) == 0;
-  // Work items = (128-row block, 1 / gy of the enrolled range): gy > 1 lets a few tall row blocks
-  // still fill the chip.  The items of the last, partly filled round of workgroups are cut into
-  // `tail_split` pieces each, so that round costs 1 / tail_split of a full one (at the dev-set
-  // shape 1 162 items on 768 resident workgroups: 2 rounds -> 1.5).
-  int item = blockIdx.x, part = 0, parts = 1;
-  if (item >= n_full) {
-    const int t = item - n_full;
-    item = n_full + t / tail_split;
-    part = t % tail_split;
-    parts = tail_split;
-  }
-  const int m0 = (item / gy) * CT_BM + wave * 32;
+  // Work unit = (128-row block, one 32-row block of the enrolled matrix), numbered row-block-major.
+  // The grid is one workgroup per resident slot and workgroup b takes the contiguous unit range
+  // [b U / G, (b + 1) U / G): every workgroup gets the same number of units (+-1) whatever the shape,
+  // and its range touches at most a few row blocks, so the test-row fragments are (re)loaded a few
+  // times per workgroup.  No reduction is needed: the split is over output columns, never over K.
+  // (Whole row blocks per workgroup left the last round of workgroups ragged: 1 162 blocks on 768
+  // slots kept waves resident only 73 % of the launch.)
   const int all_stiles = (ns + CT_BN - 1) / CT_BN;
-  const int per_y = (all_stiles + gy - 1) / gy;
-  int st_begin = (item % gy) * per_y;
-  int n_stiles = min(all_stiles, st_begin + per_y);
-  if (parts > 1) {
-    const int sub = (max(n_stiles - st_begin, 0) + parts - 1) / parts;
-    st_begin += part * sub;
-    n_stiles = min(n_stiles, st_begin + sub);
-  }
+  const long long u_begin = total_units * blockIdx.x / gridDim.x, u_end = total_units * (blockIdx.x + 1) / gridDim.x;
 
   // staging assignment: thread t moves 4 float4 of the 32 x 128 block: row = (t >> 5) + 8 j, float4 column = t & 31
   const int srow = threadIdx.x >> 5, scol = (threadIdx.x & 31) * 4;
   auto fetch = [&](int st, int kb, f32x4 (&regs)[4]) {
-    if (vec_ok && (st + 1) * CT_BN <= ns && (kb + 1) * CT_KB <= dim) {  // workgroup-uniform: whole block inside
-      const float* base = enroll + ((int64_t)st * CT_BN + srow) * dim + kb * CT_KB + scol;
+    if (vec_ok && (kb + 1) * CT_KB <= dim) {  // workgroup-uniform: whole K block inside
+      // rows past the enrolled matrix (ragged last block) re-read its last row: those columns are never stored
 #pragma unroll
-      for (int j = 0; j < 4; ++j) regs[j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(8 * j) * dim);
+      for (int j = 0; j < 4; ++j) {
+        const int r = min(st * CT_BN + srow + 8 * j, ns - 1);
+        regs[j] = *reinterpret_cast<const f32x4*>(enroll + (int64_t)r * dim + kb * CT_KB + scol);
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -156,6 +147,11 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(buf + (srow + 8 * j) * CT_LD + scol) = regs[j];
   };
 
+  for (long long u = u_begin; u < u_end;) {
+  const int rb = (int)(u / all_stiles), st_begin = (int)(u - (long long)rb * all_stiles);
+  const int n_stiles = (int)min((long long)all_stiles, st_begin + (u_end - u));
+  u += n_stiles - st_begin;
+  const int m0 = rb * CT_BM + wave * 32;
   // test-row fragments and norms
   f32x4 a[2][8];
   float tn[2] = {0.f, 0.f};
@@ -187,7 +183,6 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
   float* const orow = out + (int64_t)(m0 + 4 * kk) * ns + i;
 
   f32x4 pre[4];
-  if (st_begin >= n_stiles) return;  // uniform per workgroup
   fetch(st_begin, 0, pre);
   stash(bs[0], pre);
   __syncthreads();
@@ -241,14 +236,17 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
       cur ^= 1;
     }
     float* const o = orow + st * CT_BN;
-    if (rows_in && (st + 1) * CT_BN <= ns) {  // wave-uniform: the whole 32 x 32 block is inside: 16 plain stores
+    if (rows_in) {  // wave-uniform: all 32 rows are inside: 16 stores, masked by column only in the ragged last block
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int ct = 0; ct < 2; ++ct) {
+        if (st * CT_BN + 16 * ct + i < ns) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+          for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct)
-            o[(int64_t)(16 * rt + r) * ns + 16 * ct] = acc[rt][ct][r] * rinv[rt][r] * sinv[ct];
+            for (int r = 0; r < 4; ++r)
+              o[(int64_t)(16 * rt + r) * ns + 16 * ct] = acc[rt][ct][r] * rinv[rt][r] * sinv[ct];
+        }
+      }
     } else {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
@@ -266,6 +264,25 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
       }
     }
   }
+  }  // next segment of this workgroup's unit range (the st loop ended on a __syncthreads: bs[] is free)
+}
+
+// Two register budgets of the same body.  Left alone the compiler puts the accumulators in AGPRs on
+// top of 158 VGPRs (176 in all: two workgroups per CU); hinted to 3 waves per SIMD it fits 168 with
+// the accumulators in VGPRs.  Which one is faster depends on the shape (SVK_COS_WAVES=2|3 picks, tuning).
+template <bool HOIST>
+__global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restrict__ test, const float* __restrict__ enroll,
+                                                           const float* __restrict__ einv, int nt, int ns, int dim,
+                                                           float* __restrict__ out, long long total_units) {
+  __shared__ __attribute__((aligned(16))) float bs[2][CT_BN * CT_LD];
+  cosine_tiled_body<HOIST>(test, enroll, einv, nt, ns, dim, out, total_units, bs);
+}
+template <bool HOIST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void cosine_tiled_kernel_w3(
+    const float* __restrict__ test, const float* __restrict__ enroll, const float* __restrict__ einv, int nt, int ns,
+    int dim, float* __restrict__ out, long long total_units) {
+  __shared__ __attribute__((aligned(16))) float bs[2][CT_BN * CT_LD];
+  cosine_tiled_body<HOIST>(test, enroll, einv, nt, ns, dim, out, total_units, bs);
 }
 
 __global__ __launch_bounds__(256) void l2_dist_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
@@ -299,31 +316,24 @@ int svk_cosine_scores(svk_ctx* ctx, const float* d_test, const float* d_enroll, 
     // enough work to fill the chip with 128-row workgroups: tiled kernel
     const unsigned gx = (unsigned)((n_test + CT_BM - 1) / CT_BM);
     const unsigned stiles = (unsigned)((n_enroll + CT_BN - 1) / CT_BN);
-    const unsigned gy = std::max(1u, std::min(stiles, (unsigned)(2 * ctx->num_cu + gx - 1) / gx));
     const int rc = svk_ensure_work(ctx, sizeof(float) * (size_t)n_enroll);
     if (rc != SVK_OK) return rc;
     float* einv = static_cast<float*>(ctx->work);
     hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)std::min((n_enroll + 3) / 4, ctx->num_cu * 8)), dim3(256), 0,
                        ctx->stream, d_enroll, n_enroll, dim, einv);
-    auto kern = dim <= CT_KB ? cosine_tiled_kernel<true> : cosine_tiled_kernel<false>;
-    // resident workgroups = one "round"; the items of the last partial round are split (see the kernel)
+    const char* wenv = getenv("SVK_COS_WAVES");
+    const bool w3 = wenv ? atoi(wenv) == 3 : false;
+    auto kern = dim <= CT_KB ? (w3 ? cosine_tiled_kernel_w3<true> : cosine_tiled_kernel<true>)
+                             : (w3 ? cosine_tiled_kernel_w3<false> : cosine_tiled_kernel<false>);
+    // one workgroup per resident slot (fewer when there is less work than that)
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, 0) != hipSuccess ||
         per_cu < 1)
       per_cu = 2;
-    const long long slots = (long long)per_cu * ctx->num_cu, items = (long long)gx * gy;
-    const long long n_full = (items / slots) * slots, rem = items - n_full;
-    const unsigned per_item_tiles = (stiles + gy - 1) / gy;
-    // pieces per tail item: minimise (rounds of pieces) x (column blocks per piece + ~2 blocks' worth of
-    // per-piece set-up: the test-row fragments and norms are loaded again)
-    long long split = 1, best = -1;
-    for (long long f = 1; rem > 0 && f <= std::max<long long>(1, per_item_tiles / 2); ++f) {
-      const long long cost = ((rem * f + slots - 1) / slots) * ((per_item_tiles + f - 1) / f + 2);
-      if (best < 0 || cost < best) best = cost, split = f;
-    }
-    const long long blocks = n_full + rem * split;
+    const long long units = (long long)gx * stiles;
+    const long long blocks = std::min<long long>((long long)per_cu * ctx->num_cu, std::max<long long>(1, units / 4));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_test, d_enroll, einv, n_test, n_enroll,
-                       dim, d_out, (int)gy, (int)n_full, (int)split);
+                       dim, d_out, units);
   } else {
     const int tiles = (n_test + 15) / 16;
     const unsigned grid = (unsigned)std::max(1, std::min((tiles + 3) / 4, ctx->num_cu * 8));
