@@ -10,18 +10,21 @@
 // workgroup copies the filterbank / DCT operand fragments into LDS once (they are re-read
 // for every tile: fetching them from L2 per tile cost 4x the PCM traffic and its latency),
 // then every wave works on its own: it owns a TILE of 8 (or 16) consecutive frames of one
-// clip, a private LDS slice, and loops over tiles with no further workgroup barrier.
+// clip, a private LDS slice, and loops over tiles with no further workgroup barrier (the waves
+// of a workgroup draw the workgroup's tiles from a counter in LDS).  The two standard
+// configurations run instances with their framing and output shape fixed at compile time (Spec).
 //   1. the tile's sample span is read from HBM once with 16-byte loads issued back to back and
 //      parked in LDS -- int16 clips as raw int16 (pre-emphasis x[n] - c x[n-1] is applied when a
 //      frame is read), float clips or an unusual pre-emphasis shift as pre-emphasised f32;
-//   2. a 512-point complex FFT runs across the wave: 8 points per lane, three radix-8
-//      passes in registers on packed-f32 instructions (fft_wave.h), two transposes through a
-//      padded (bank-conflict-free) LDS scratch.  nfft = 512 packs TWO real frames into one
+//   2. 512-point complex FFTs run across the wave, two per trip pipelined through one scratch:
+//      8 points per lane, three radix-8 passes in registers on packed-f32 instructions
+//      (fft_wave.h), two transposes through a padded (bank-conflict-free) LDS scratch.  nfft = 512 packs TWO real frames into one
 //      complex FFT; nfft = 1024 packs the even/odd samples of ONE frame.  The untangle step
 //      pairs bin k with bin N-k, which lives in lane 64-l: one wave shuffle per register, no
 //      LDS, and only for the bins the mel filters read;
 //   3. those power bins go to a [TILE x KP] LDS tile; the frame energy (all bins) comes from
-//      Parseval's identity and a DPP wave reduction, and only when something consumes it;
+//      Parseval's identity: per-lane partial sums, three DPP adds to 8 group sums parked behind the
+//      frame's power bins, finished by two MFMAs against ones -- and only when something consumes it;
 //   4. mel energies^T = filterbank x P^T on v_mfma_f32_16x16x4_f32 (exact f32), skipping
 //      the 16-bin chunks where a 16-filter tile is identically zero (Q2: the bank is
 //      ~97 % zeros);  log;  the accumulator layout of that product is exactly the B

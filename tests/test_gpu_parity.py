@@ -675,8 +675,9 @@ def test_cosine_scores_tiled_kernel(eng):
         want = scoring_ref.cosine_matrix(t, e)
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
         assert not got[5].any() and not got[:, 3].any()
-    # more 128-row blocks than resident workgroups: the last round's blocks are split along the enrolled
-    # range (scoring.hip: tail_split); rows of the first round, of the split tail and the ragged last block
+    # more 128-row blocks than resident workgroups: every workgroup takes an equal range of (row block,
+    # enrolled block) units (scoring.hip), so row blocks are shared between workgroups; rows early, in the
+    # middle, around block 1024 and in the ragged last block
     nt, ns, d = 128 * 1100 + 37, 203, 128
     t = rng.standard_normal((nt, d)).astype(np.float32)
     e = rng.standard_normal((ns, d)).astype(np.float32)
