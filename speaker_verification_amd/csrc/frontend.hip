@@ -927,12 +927,19 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
     kern = frontend_kernel<int16_t, true, 8, true, SpecLmfe40>;
   else if (pcm_dtype == SVK_PCM_I16)
     kern = raw16 ? pick_kernel<int16_t, true>(split, plan->tile) : pick_kernel<int16_t, false>(split, plan->tile);
+  // float32 signals (what librosa hands the reference's lmfe call, load_data.py:50-70): the same two configurations
+  else if (plan->tile == 8 && !generic_only && !split && spec_matches<SpecMfcc13>(p))
+    kern = frontend_kernel<float, false, 8, false, SpecMfcc13>;
+  else if (plan->tile == 8 && !generic_only && split && spec_matches<SpecLmfe40>(p))
+    kern = frontend_kernel<float, true, 8, false, SpecLmfe40>;
   else
     kern = pick_kernel<float, false>(split, plan->tile);
   if (getenv("SVK_FE_DEBUG"))
     fprintf(stderr, "svk_frontend_run: %s instance, %d waves/CU, grid %lld\n",
             kern == (void (*)(const FrontendParams))frontend_kernel<int16_t, false, 8, true, SpecMfcc13>   ? "mfcc13"
             : kern == (void (*)(const FrontendParams))frontend_kernel<int16_t, true, 8, true, SpecLmfe40> ? "lmfe40"
+            : kern == (void (*)(const FrontendParams))frontend_kernel<float, false, 8, false, SpecMfcc13> ? "mfcc13 (f32)"
+            : kern == (void (*)(const FrontendParams))frontend_kernel<float, true, 8, false, SpecLmfe40>  ? "lmfe40 (f32)"
                                                                                                            : "generic",
             waves, (long long)grid);
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

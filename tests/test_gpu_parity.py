@@ -140,6 +140,11 @@ def test_fused_preemphasis_matches_reference_chain(eng):
         np.testing.assert_allclose(feat[i].cpu().numpy(), want, **FEAT_TOL)
 
 
+def want_rows(n_samples, frame_length, fs=16000, stride=160):
+    flen = int(round(fs * frame_length))
+    return max(0, (n_samples - flen) // stride) if n_samples >= flen else 0
+
+
 @pytest.mark.parametrize("kind,nfft,fl", [("mfcc", 512, 0.020), ("lmfe", 1024, 0.025)])
 def test_specialised_instances_match_generic_and_oracle(eng, kind, nfft, fl, monkeypatch):
     """The two standard configurations run compile-time specialised kernel instances (frontend.hip,
@@ -160,6 +165,16 @@ def test_specialised_instances_match_generic_and_oracle(eng, kind, nfft, fl, mon
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(a[0].cpu().numpy(), (ref.mfcc if kind == "mfcc" else ref.lmfe)(
         pcm[0], 16000, frame_length=fl, frame_stride=0.01, num_filters=40, fft_length=nfft), **FEAT_TOL)
+    # float32 signals in [-1, 1) (what librosa hands the reference's lmfe call) have their own two instances
+    f32 = (pcm / 32768.0).astype(np.float32)
+    fa, _, _ = feature.features_batch(f32, 16000, **kw)
+    monkeypatch.setenv("SVK_FE_GENERIC", "1")
+    fb, _, _ = feature.features_batch(f32, 16000, **kw)
+    monkeypatch.delenv("SVK_FE_GENERIC")
+    np.testing.assert_allclose(fa.cpu().numpy(), fb.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(fa[1, :want_rows(lens[1], fl)].cpu().numpy(), (ref.mfcc if kind == "mfcc" else ref.lmfe)(
+        ref.preemphasis(f32[1, :lens[1]], cof=0.98), 16000, frame_length=fl, frame_stride=0.01, num_filters=40,
+        fft_length=nfft), **FEAT_TOL)
     spec, nf_spec, _ = feature.features_batch(pcm, 16000, **kw)
     monkeypatch.setenv("SVK_FE_GENERIC", "1")
     gen, nf_gen, _ = feature.features_batch(pcm, 16000, **kw)
