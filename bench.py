@@ -307,7 +307,8 @@ def main():
     model = seeded_model(2024, n_labels=1211)
     pipe = VerificationPipeline(model, use_vad=not args.no_vad, normalize=not args.no_cmvn,
                                 preemph_cof=None if args.no_preemph else 0.98, crop_rng="device",
-                                micro_batch=args.micro_batch, channels_last=not args.no_channels_last)
+                                micro_batch=args.micro_batch, channels_last=not args.no_channels_last,
+                                overlap_front=os.environ.get("SVK_BENCH_OVERLAP", "0") == "1")
     # random-init weights (no checkpoint ships) with BatchNorm statistics calibrated on 256 clips of
     # rank 0's shard, identically on every rank (model.calibrate_batchnorm explains why)
     cal_pcm, _ = synth.corpus_device(256, dev, first_clip=0, utts_per_speaker=UTTS_PER_SPK)

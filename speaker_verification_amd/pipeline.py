@@ -19,11 +19,13 @@ from .engine import get_engine, spec_from_seconds
 class VerificationPipeline:
     def __init__(self, model, use_vad=True, vad_threshold=c.VAD_ENERGY_THRESHOLD, normalize=c.NORMALIZE,
                  fused_model=True, crop_seed=12345, micro_batch=1024, channels_last=True, preemph_cof=None,
-                 crop_rng="reference", miopen_find=True):
+                 crop_rng="reference", miopen_find=True, overlap_front=False):
         """crop_rng: "reference" draws crop starts on the host exactly like utils.py:372 (needs the
         per-clip frame counts on the host: one small D2H per micro-batch); "device" draws them
         in a kernel keyed by (crop_seed, global clip index) -- no host round trip.
-        preemph_cof: fuse processing.preemphasis(clip, cof=...) in front of the log-mel stage."""
+        preemph_cof: fuse processing.preemphasis(clip, cof=...) in front of the log-mel stage.
+        overlap_front: build the cube of micro-batch k+1 (VAD, front end, CMVN, crops, gather) on a
+        second HIP stream while the network runs on micro-batch k (device-drawn crops only)."""
         self.eng = get_engine()
         if miopen_find:
             # MIOpen's exhaustive find picks 1.7x faster f32 Conv3d kernels for these odd filter
@@ -46,6 +48,8 @@ class VerificationPipeline:
         # the crop starts from it (utils.py:372); a private RandomState keeps that sequence
         self.rng = np.random.RandomState(crop_seed)
         self.last_stats = {}
+        self.overlap_front = bool(overlap_front)
+        self._side_stream = None
 
     def refresh_model(self):
         """Re-snapshot the (BN-folded) inference weights after the model's state changed."""
@@ -116,7 +120,11 @@ class VerificationPipeline:
         pcm = self.eng.to_device(pcm)
         emb = torch.empty((pcm.shape[0], 128), dtype=torch.float32, device=self.eng.device)
         inter = []
-        for lo, hi in self.chunks(pcm.shape[0]):
+        spans = self.chunks(pcm.shape[0])
+        if (self.overlap_front and crop_idx is None and self.crop_rng == "device" and not return_intermediates
+                and len(spans) > 1):
+            return self._embed_overlapped(pcm, spans, emb, first_utt)
+        for lo, hi in spans:
             chunk = pcm[lo:hi]
             voiced, vlen = self.voiced(chunk)
             feat, n_frames = self.features(voiced, vlen)
@@ -133,6 +141,39 @@ class VerificationPipeline:
                 inter.append({"lo": lo, "hi": hi, "voiced": voiced, "voiced_len": vlen, "feat": feat,
                               "n_frames": n_frames, "crop_idx": idx, "cube": cube})
         return (emb, inter) if return_intermediates else emb
+
+    def _embed_overlapped(self, pcm, spans, emb, first_utt):
+        """Two HIP streams: the side stream turns micro-batch k+1 into its cube (all libsvk kernels: they
+        are HBM / VALU work) while the main stream runs the MFMA-bound network on micro-batch k."""
+        dev = self.eng.device
+        main = torch.cuda.current_stream(dev)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        side = self._side_stream
+        side.wait_stream(main)                     # whatever produced `pcm` is ordered before the side stream
+
+        def stage(k):
+            lo, hi = spans[k]
+            with torch.cuda.stream(side):
+                voiced, vlen = self.voiced(pcm[lo:hi])
+                feat, n_frames = self.features(voiced, vlen)
+                idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo,
+                                          self.bad_clips)
+                cube = self.cubes(feat, idx)
+                done = torch.cuda.Event()
+                done.record(side)
+            return cube, done
+
+        nxt = stage(0)
+        for k, (lo, hi) in enumerate(spans):
+            cube, done = nxt
+            if k + 1 < len(spans):
+                nxt = stage(k + 1)
+            main.wait_event(done)
+            cube.record_stream(main)               # allocated on the side stream, consumed on the main one
+            emb[lo:hi] = self.embed_cubes(cube)
+        side.wait_stream(main)
+        return emb
 
     def embed_ragged(self, clips, max_batch_samples=64 * 1024 * 1024, first_utt=0):
         """Clips of DIFFERENT lengths (VoxCeleb1 utterances run from 4 to 145 s): `clips` is a list of 1-D

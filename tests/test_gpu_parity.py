@@ -578,6 +578,23 @@ def test_pipeline_ingest_feeds_the_int16_path(eng):
     np.testing.assert_allclose(emb_a.cpu().numpy(), emb_b.cpu().numpy(), rtol=1e-3, atol=1e-3)
 
 
+def test_overlapped_front_end_gives_the_same_embeddings(eng):
+    """pipeline(overlap_front=True): cube building on a side stream, network on the main one -- same
+    kernels, same inputs, same results as the serial schedule."""
+    from speaker_verification_amd.model import seeded_model
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    pcm, _ = synth.corpus_device(96, eng.device)
+    model = seeded_model(2, n_labels=8).to(eng.device).eval()
+    serial = VerificationPipeline(model, crop_rng="device", crop_seed=7, micro_batch=24, preemph_cof=0.98)
+    both = VerificationPipeline(model, crop_rng="device", crop_seed=7, micro_batch=24, preemph_cof=0.98,
+                                overlap_front=True)
+    want = serial.embed(pcm)
+    for _ in range(3):                                  # repeated: a missing cross-stream dependency shows as a diff
+        got = both.embed(pcm)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+
+
 def test_load_wav_resamples_on_device(tmp_path):
     """load_data.load_wav (utils.py:170-173 drop-in) on a stereo 44.1 kHz file and on a mono 16 kHz one."""
     import wave
