@@ -190,6 +190,25 @@ def test_specialised_instances_match_generic_and_oracle(eng, kind, nfft, fl, mon
         assert not spec[i, want.shape[0]:].any()
 
 
+def test_long_clips_front_end(eng):
+    """VoxCeleb clips run to 145 s: one 60 s and one 7 s clip in a batch (thousands of frame tiles per clip,
+    more tiles than waves in flight), both configurations, against the oracle."""
+    from speaker_verification_amd.speechpy import feature
+    lens = [60 * 16000 + 123, 7 * 16000]
+    pcm = np.zeros((2, lens[0]), dtype=np.int16)
+    pcm[0] = synth.noise_clip(31, lens[0])
+    pcm[1, :lens[1]] = synth.speaker_clip(3, 2, lens[1])
+    for kind, nfft, fl, fn in (("mfcc", 512, 0.020, ref.mfcc), ("lmfe", 1024, 0.025, ref.lmfe)):
+        feat, nf, _ = feature.features_batch(pcm, 16000, kind=kind, frame_length=fl, fft_length=nfft,
+                                             preemphasis_cof=0.98, lengths=np.array(lens, dtype=np.int32))
+        for i, n in enumerate(lens):
+            want = fn(ref.preemphasis(pcm[i, :n], cof=0.98), 16000, frame_length=fl, frame_stride=0.01,
+                      num_filters=40, fft_length=nfft)
+            assert int(nf[i]) == want.shape[0]
+            np.testing.assert_allclose(feat[i, :want.shape[0]].cpu().numpy(), want, **FEAT_TOL)
+            assert not feat[i, want.shape[0]:].any()
+
+
 def test_full_size_batch_properties(eng):
     """BASELINE config 2 shape (1 024 x 3 s): determinism, row independence, no NaN."""
     from speaker_verification_amd.speechpy import feature
