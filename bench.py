@@ -158,9 +158,16 @@ def stage_breakdown(pipe, eng, torch, chunk, first_utt):
     rows["cmvn"] = (t, 2 * frames * 40 * 4)
     t, idx = timed(lambda: eng.draw_crops(nf, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, first_utt, pipe.bad_clips))
     rows["draw_crops"] = (t, n * (4 + 80))
-    t, cube = timed(lambda: pipe.cubes(feat, idx))
-    rows["cube_gather"] = (t, frames * 40 * 4 + n * 256000)
-    t, emb = timed(lambda: pipe.embed_cubes(cube))
+    geo = pipe.embedder.first_layer_windows(c.CUBE_CROPS, 40) if pipe.embedder is not None else None
+    if geo is not None:
+        kd, kw, G = geo
+        t, win = timed(lambda: eng.cube_windows(feat, idx, c.CUBE_FRAMES, kd, kw, G))
+        rows["cube as first-layer patch matrix"] = (t, frames * 40 * 4 + float(win.numel()) * 4)
+        t, emb = timed(lambda: pipe.embedder.from_windows(win, n, c.CUBE_CROPS, c.CUBE_FRAMES, 40))
+    else:
+        t, cube = timed(lambda: pipe.cubes(feat, idx))
+        rows["cube_gather"] = (t, frames * 40 * 4 + n * 256000)
+        t, emb = timed(lambda: pipe.embed_cubes(cube))
     rows["C3D2 forward (PyTorch-ROCm)"] = (t, None)
     t, _ = timed(lambda: pipe.score(emb, emb[:40]))
     rows["cosine %dx40" % n] = (t, (n + 40) * 128 * 4 + n * 40 * 4)
@@ -340,7 +347,7 @@ def main():
                 eng.cmvn_(feat, n_frames, variance=True)
             idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, rank * n_local + lo,
                                  pipe.bad_clips)
-            local[lo:hi] = pipe.embed_cubes(pipe.cubes(feat, idx))
+            local[lo:hi] = pipe.embed_features(feat, idx)      # cube (as the first layer's patch matrix) -> C3D2
         full = svdist.all_gather_embeddings(local, n_total)
         scores = pipe.score(full[:n_test], full[:n_test][last_dev])
         return full, scores

@@ -174,6 +174,17 @@ int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t* d_offsets,
 int svk_cube_gather(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, float* d_out);
 
+/* The same cube, already unfolded for the first C3D2 layer (model.py:110, Conv3d(1, 16, (kd, 1, kw))) run
+ * as one GEMM: row (u, d, h, wg) of d_out holds, for the kd consecutive crops d .. d + kd - 1, the
+ * kw + group - 1 coefficients shared by the `group` adjacent output columns wg * group ..:
+ *     d_out[((u * od + d) * crop_frames + h) * (ow / group) + wg][kdi * (kw + group - 1) + j]
+ *         = feat[u][crop[u][d + kdi] + h][wg * group + j],     od = n_crops - kd + 1, ow = n_cols - kw + 1.
+ * group must divide ow; group, kw + group - 1 and n_cols must be multiples of 4 (16-byte copies), else
+ * SVK_ERR_UNSUPPORTED (build the cube with svk_cube_gather instead).                                        */
+int svk_cube_gather_windows(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                            const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, int32_t kd,
+                            int32_t kw, int32_t group, float* d_out);
+
 /* Crop starts drawn ON THE DEVICE (no host round trip for the per-clip frame count):
  * crop[u][c] = floor(uniform(seed, u, c) * (n_frames[u] - crop_frames)), a counter-based
  * generator (splitmix64 of seed, g, c) with g = d_utt_index[u] when that array is given (clips of a

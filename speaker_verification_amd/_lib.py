@@ -68,6 +68,7 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _vp]),
     "svk_cube_draw_crops": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _i32, _i32, C.c_uint64, _vp, _vp]),
     "svk_cube_gather": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "svk_cube_gather_windows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "svk_cosine_scores": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "svk_roc_workspace_bytes": (C.c_size_t, [_i64]),
     "svk_roc_eer": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_size_t, C.POINTER(C.c_double)]),

@@ -334,6 +334,21 @@ class Engine:
                                        self._ptr(out)), self.ctx)
         return out
 
+    def cube_windows(self, feat, crop_idx, crop_frames, kd, kw, group):
+        """svk_cube_gather_windows: the feature cube already unfolded into the patch matrix of the network's
+        first layer (see FusedEmbedder): [n * od * crop_frames * (ow / group), kd * (kw + group - 1)]."""
+        torch = _torch()
+        feat = self.to_device(feat, torch.float32)
+        idx = self.to_device(crop_idx, torch.int32)
+        n, T, Cc = feat.shape
+        n_crops = idx.shape[1]
+        od, ow, win = n_crops - kd + 1, Cc - kw + 1, kw + group - 1
+        out = torch.empty((n * od * crop_frames * (ow // group), kd * win), dtype=torch.float32, device=self.device)
+        self._stream()
+        check(self.lib.svk_cube_gather_windows(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), n_crops,
+                                               crop_frames, kd, kw, group, self._ptr(out)), self.ctx)
+        return out
+
     def cosine_scores(self, test, enroll):
         torch = _torch()
         t = self.to_device(test, torch.float32)

@@ -173,10 +173,34 @@ class FusedEmbedder:
             self._gemm_cache[ow] = hit
         return hit
 
+    def first_layer_windows(self, n_crops, n_cols):
+        """(kd, kw, G) of the patch matrix the first layer's GEMM consumes for cubes of `n_crops` x `n_cols`
+        (svk_cube_gather_windows can write it directly), or None when the first layer is a plain conv."""
+        if not self.first_as_gemm:
+            return None
+        w = self.stages[0][0]
+        kd, kw = int(w.shape[2]), int(w.shape[4])
+        G = self._first_layer_tables(n_cols - kw + 1)[0]
+        return kd, kw, G
+
+    @torch.no_grad()
+    def from_windows(self, windows, n, n_crops, crop_frames, n_cols):
+        """Embeddings from the first layer's patch matrix (see first_layer_windows) instead of the cube."""
+        w = self.stages[0][0]
+        kd, kw = int(w.shape[2]), int(w.shape[4])
+        od, ow = n_crops - kd + 1, n_cols - kw + 1
+        _, wt, bt = self._first_layer_tables(ow)
+        x = torch.addmm(bt, windows, wt)
+        x = x.view(n, od, crop_frames, ow, w.shape[0]).permute(0, 4, 1, 2, 3)     # NDHWC memory = channels_last_3d
+        return self._run(x, first_done=True)
+
     @torch.no_grad()
     def __call__(self, x):
         if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last_3d)
+        return self._run(x, first_done=False)
+
+    def _run(self, x, first_done):
         fold = None
         for li, (w, b, slope, stride, pool, pool_first) in enumerate(self.stages):
             groups = 1
@@ -187,7 +211,9 @@ class FusedEmbedder:
                     fold = self.row_fold
             if fold is not None and li in (1, 2, 3):
                 w, b, slope, stride, groups = fold[li]
-            if li == 0 and self.first_as_gemm:
+            if li == 0 and first_done:
+                pass
+            elif li == 0 and self.first_as_gemm:
                 n, _, d, h, wd = x.shape
                 kd, kw = w.shape[2], w.shape[4]
                 od, ow = d - kd + 1, wd - kw + 1

@@ -112,6 +112,18 @@ class VerificationPipeline:
                 return self.embedder(cubes)
             return self.model(cubes, development=False)
 
+    def embed_features(self, feat, crop_idx):
+        """features + crop starts -> embeddings.  With the fused embedder the cube is never materialised:
+        svk_cube_gather_windows writes the first layer's patch matrix straight from the feature rows
+        (FusedEmbedder.from_windows); otherwise cube -> network."""
+        geo = self.embedder.first_layer_windows(c.CUBE_CROPS, feat.shape[2]) if self.embedder is not None else None
+        if geo is not None:
+            kd, kw, G = geo
+            if G % 4 == 0 and (kw + G - 1) % 4 == 0 and feat.shape[2] % 4 == 0:
+                windows = self.eng.cube_windows(feat, crop_idx, c.CUBE_FRAMES, kd, kw, G)
+                return self.embedder.from_windows(windows, feat.shape[0], c.CUBE_CROPS, c.CUBE_FRAMES, feat.shape[2])
+        return self.embed_cubes(self.cubes(feat, crop_idx))
+
     # ---- whole path ---------------------------------------------------------------------
     def embed(self, pcm, crop_idx=None, return_intermediates=False, first_utt=0):
         """[n, L] int16 PCM (NumPy or CUDA tensor) -> [n, 128] float32 embeddings (device).
@@ -135,11 +147,13 @@ class VerificationPipeline:
                 idx = self.draw_crops(n_frames.to("cpu").numpy())      # tiny D2H: T per utterance
             else:
                 idx = np.asarray(crop_idx[lo:hi], dtype=np.int32)
-            cube = self.cubes(feat, idx)
-            emb[lo:hi] = self.embed_cubes(cube)
             if return_intermediates:
+                cube = self.cubes(feat, idx)
+                emb[lo:hi] = self.embed_cubes(cube)
                 inter.append({"lo": lo, "hi": hi, "voiced": voiced, "voiced_len": vlen, "feat": feat,
                               "n_frames": n_frames, "crop_idx": idx, "cube": cube})
+            else:
+                emb[lo:hi] = self.embed_features(feat, idx)
         return (emb, inter) if return_intermediates else emb
 
     def _embed_overlapped(self, pcm, spans, emb, first_utt):
@@ -159,7 +173,11 @@ class VerificationPipeline:
                 feat, n_frames = self.features(voiced, vlen)
                 idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo,
                                           self.bad_clips)
-                cube = self.cubes(feat, idx)
+                geo = self.embedder.first_layer_windows(c.CUBE_CROPS, feat.shape[2]) if self.embedder is not None else None
+                if geo is not None and geo[2] % 4 == 0 and (geo[1] + geo[2] - 1) % 4 == 0 and feat.shape[2] % 4 == 0:
+                    cube = ("windows", self.eng.cube_windows(feat, idx, c.CUBE_FRAMES, *geo), feat.shape[0], feat.shape[2])
+                else:
+                    cube = ("cube", self.cubes(feat, idx), 0, 0)
                 done = torch.cuda.Event()
                 done.record(side)
             return cube, done
@@ -170,8 +188,12 @@ class VerificationPipeline:
             if k + 1 < len(spans):
                 nxt = stage(k + 1)
             main.wait_event(done)
-            cube.record_stream(main)               # allocated on the side stream, consumed on the main one
-            emb[lo:hi] = self.embed_cubes(cube)
+            kind, data, n_rows, n_cols = cube
+            data.record_stream(main)               # allocated on the side stream, consumed on the main one
+            if kind == "windows":
+                emb[lo:hi] = self.embedder.from_windows(data, n_rows, c.CUBE_CROPS, c.CUBE_FRAMES, n_cols)
+            else:
+                emb[lo:hi] = self.embed_cubes(data)
         side.wait_stream(main)
         return emb
 
@@ -220,7 +242,7 @@ class VerificationPipeline:
             # the crop draw is keyed by the clip's index in `clips`, whatever batch it landed in
             idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, 0, self.bad_clips,
                                       utt_index=rows + first_utt)
-            emb[rows] = self.embed_cubes(self.cubes(feat, idx))
+            emb[rows] = self.embed_features(feat, idx)
         return emb
 
     def embed_host(self, pcm_host, first_utt=0):
@@ -289,7 +311,7 @@ class VerificationPipeline:
             feat, n_frames = self.features(voiced, vlen)
             idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo,
                                       self.bad_clips)
-            emb[lo:hi] = self.embed_cubes(self.cubes(feat, idx))
+            emb[lo:hi] = self.embed_features(feat, idx)
             consumed[slot].record(main)
             if k + 1 < len(spans):
                 launch_copy(k + 1)      # the host-side staging copy runs while the GPU works on batch k

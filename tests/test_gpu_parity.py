@@ -597,6 +597,32 @@ def test_pipeline_ingest_feeds_the_int16_path(eng):
     np.testing.assert_allclose(emb_a.cpu().numpy(), emb_b.cpu().numpy(), rtol=1e-3, atol=1e-3)
 
 
+def test_cube_windows_equals_cube_path(eng, golden):
+    """svk_cube_gather_windows writes the first layer's patch matrix straight from the feature rows: the same
+    numbers the PyTorch-side strided gather of the cube produces, hence bit-identical embeddings; too-short
+    clips (crop start -1) give zero rows like svk_cube_gather."""
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    rng = np.random.default_rng(21)
+    n, T, C = 5, 297, 40
+    feat = rng.standard_normal((n, T, C)).astype(np.float32)
+    idx = rng.integers(0, T - 80, size=(n, 20)).astype(np.int32)
+    idx[3] = -1
+    model = seeded_model(4, n_labels=6)
+    model.load_state_dict(perturb_inference_state(model.state_dict(), 9))
+    emb = model.to(eng.device).eval().fused_inference(channels_last=True)
+    kd, kw, G = emb.first_layer_windows(20, C)
+    win = eng.cube_windows(feat, idx, 80, kd, kw, G)
+    cube = eng.cube_gather(feat, idx, 80)
+    od, ow, wn = 20 - kd + 1, C - kw + 1, kw + G - 1
+    xs = cube.reshape(n, 20, 80, C)
+    want = xs.as_strided((n, od, 80, ow // G, kd, wn), (20 * 80 * C, 80 * C, C, G, 80 * C, 1)).reshape(-1, kd * wn)
+    assert win.shape == want.shape and torch.equal(win, want)
+    assert not win.view(n, -1)[3].any()
+    assert torch.equal(emb.from_windows(win, n, 20, 80, C), emb(cube))
+    with pytest.raises(Exception, match="multiples of 4"):
+        eng.cube_windows(feat, idx, 80, kd, kw, 9)
+
+
 def test_overlapped_front_end_gives_the_same_embeddings(eng):
     """pipeline(overlap_front=True): cube building on a side stream, network on the main one -- same
     kernels, same inputs, same results as the serial schedule."""
