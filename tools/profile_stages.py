@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--no-channels-last", action="store_true")
     args = ap.parse_args()
     import torch
-    from speaker_verification_amd import constants as c, synth
+    from speaker_verification_amd import synth
     from speaker_verification_amd.engine import get_engine
     from speaker_verification_amd.model import seeded_model
     from speaker_verification_amd.pipeline import VerificationPipeline

@@ -1,6 +1,6 @@
 """conv1_2 (16 -> 16, k(3,9,1), s(1,2,1)) against a Toeplitz-widened equivalent that produces two
 output rows per position as 32 channels (k(3,11,1), s(1,4,1)): more MACs (x1.22) but a wider GEMM N."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F

@@ -1,6 +1,6 @@
 """First-layer GEMM (patch matrix [4.2 M, 48] x Toeplitz weights [48, 192] + bias) with PyTorch's default
 hipBLASLt heuristic against TunableOp's pick."""
-import os, sys, time
+import time
 import torch
 dev = torch.device("cuda:0")
 M, K, N = 978 * 18 * 80 * 3, 48, 192
