@@ -231,13 +231,22 @@ def ingest_bench(eng, torch, reps=10, n_clips=1024):
                          "bytes_per_utt": 480000}}
 
 
-def cpu_baseline(pcm_host, crop_idx, state, preemph, cmvn, use_vad):
+def cpu_baseline(pcm_host, crop_idx, state, preemph, cmvn, use_vad, passes=3):
     """The oracle (kind 'port') doing exactly the reference's per-utterance sequence on the host:
-    vad -> preemphasis -> lmfe -> cmvn -> cube -> C3D2 at batch 1 -> per-pair cosine."""
+    vad -> preemphasis -> lmfe -> cmvn -> cube -> C3D2 at batch 1 -> per-pair cosine.  The sample is
+    walked `passes` times (about 10 s of host work); the embeddings of the last pass are returned."""
     import torch
     from oracle import model_ref, scoring_ref, speechpy_ref, vad_ref
     from speaker_verification_amd import constants as c
     t0 = time.perf_counter()
+    for _ in range(max(1, passes)):
+        embs = _cpu_pass(pcm_host, crop_idx, state, preemph, cmvn, use_vad, model_ref, scoring_ref, speechpy_ref,
+                         vad_ref, c)
+    dt = (time.perf_counter() - t0) / max(1, passes)
+    return embs, dt, torch.get_num_threads()
+
+
+def _cpu_pass(pcm_host, crop_idx, state, preemph, cmvn, use_vad, model_ref, scoring_ref, speechpy_ref, vad_ref, c):
     embs = []
     for i in range(pcm_host.shape[0]):
         clip = pcm_host[i]
@@ -254,8 +263,7 @@ def cpu_baseline(pcm_host, crop_idx, state, preemph, cmvn, use_vad):
     enroll = embs[::max(1, len(embs) // 8)]
     for i in range(len(embs)):
         scoring_ref.compute_similarity(embs[i], enroll)
-    dt = time.perf_counter() - t0
-    return embs, dt, torch.get_num_threads()
+    return embs
 
 
 def main():
@@ -473,7 +481,7 @@ def main():
             result["parity"] = par
             result["cpu_baseline"] = {"value": ns / cpu_dt, "unit": "utterances/s", "cores": threads, "kind": "port",
                                       "sample": "%d clips spread over the same shard through oracle/ (vad -> preemph -> lmfe "
-                                                "-> cmvn -> cube -> C3D2 batch 1 -> per-pair cosine), %.1f s" %
+                                                "-> cmvn -> cube -> C3D2 batch 1 -> per-pair cosine), 3 passes of %.1f s" %
                                                 (ns, cpu_dt)}
     if rank == 0:
         print(json.dumps(result))
