@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     import torch
+    if os.environ.get("SVK_TOOL_LIB"):      # tuning only: time another build of the library (A/B in one GPU call)
+        from speaker_verification_amd import _lib
+        _lib.LIB_PATH = os.environ["SVK_TOOL_LIB"]
     from speaker_verification_amd.engine import get_engine
     eng = get_engine(0)
     res = {}
