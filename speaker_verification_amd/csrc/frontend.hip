@@ -38,6 +38,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "fft_wave.h"
@@ -358,7 +359,12 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
   int16_t* sigh = reinterpret_cast<int16_t*>(mine);
   float* ptile = reinterpret_cast<float*>(mine + p.sig_bytes);
   const int prow = c_kp + PT_PAD;
-  cplx* scr = reinterpret_cast<cplx*>(ptile + TILE * prow);
+  // nfft 1024 with 8-frame tiles: the FFT scratch lies over rows 4..7 of the power tile (and a little
+  // beyond); the spectra of frames 4..7 wait in registers until the tile's last FFT is done.  One frame
+  // per FFT makes this cheap (4 floats per frame) and the tile rows are wide (KP = 256): 4.2 KB less LDS
+  // per wave, 8 -> 11 waves per CU for the model's front end.
+  constexpr bool ALIAS_SCR = SPLIT1024 && TILE == 8;
+  cplx* scr = reinterpret_cast<cplx*>(ptile + (ALIAS_SCR ? 4 : TILE) * prow);
   const int lane_id = threadIdx.x & 63;
   constexpr bool INT_PCM = sizeof(PcmT) == 2;
 
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
       // the first and drops the result: one code path.
       constexpr int FR_PER_FFT = SPLIT1024 ? 1 : 2;
       const bool pre = RAW16 && c_preemph != 0;
-      auto load = [&](int f, cplx (&v)[8], float& ea, float& eb) {
+      auto load = [&](int f, cplx (&v)[8], float& ea, float& eb) __attribute__((always_inline)) {
         const bool hasb = !SPLIT1024 && f + 1 < nvalid;
         const FrameReader<SPLIT1024, RAW16> rd{sig, sigh, f * c_stride, (hasb ? f + 1 : f) * c_stride, c_flen_eff,
                                                p.pre_cof, hasb, lane};
@@ -448,7 +454,10 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
           eb = 0.5f * e2.y;
         }
       };
-      auto finish = [&](int f, cplx (&v)[8], float ea, float eb) {
+      // defer = false_type: power bins (and energy group sums) go to the frame's tile row; true_type: into
+      // hold[0..3] (one float per 64-bin step) and hold[4] (energy partial): see ALIAS_SCR
+      auto finish = [&](int f, cplx (&v)[8], float ea, float eb, float (&hold)[5], auto defer) __attribute__((always_inline)) {
+        constexpr bool DEFER = decltype(defer)::value;
         if (lane0 && c_need_energy) {
           if (SPLIT1024) {  // X[0] = Re + Im, X[512] = Re - Im of Z[0]
             ea += (v[0].x * v[0].x + v[0].y * v[0].y) * (1.0f / 1024.0f);
@@ -474,8 +483,9 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
               cplx xp = E2 + cmul_conj(t3[j], Ot);
               xp *= xp;
               const float pk = xp.x + xp.y;  // 4 nfft |X[k]|^2
-              if (64 * (j + 1) <= c_kp) rowa[k] = pk;  // wave-uniform: no exec masking
-              else if (k < c_kp) rowa[k] = pk;         // ragged last step only
+              if constexpr (DEFER) hold[j] = pk;
+              else if (64 * (j + 1) <= c_kp) rowa[k] = pk;  // wave-uniform: no exec masking
+              else if (k < c_kp) rowa[k] = pk;              // ragged last step only
             } else {
               // 2 X1 = Zk + conj Zn,  2i X2 = Zk - conj Zn  (|.|^2 is what matters)
               cplx xa = add_conj(zk, zn), xb = swap_add_conj(zk, zn);
@@ -496,22 +506,64 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
           // 64 per-lane partial sums -> 8 (one per 8 lanes), parked in the 8 padding floats behind the
           // row's power bins; the mel stage adds them up with two more MFMAs against a matrix of ones.
           group8_sum2(ea, eb);  // (eb is idle for nfft 1024: its slot still hides ea's DPP wait states)
-          if ((lane & 7) == 7) {
+          if constexpr (DEFER) {
+            hold[4] = ea;
+          } else if ((lane & 7) == 7) {
             rowa[c_kp + (lane >> 3)] = ea;
             if (!SPLIT1024) rowb[c_kp + (lane >> 3)] = eb;
           }
         }
       };
-      for (int fa = 0; fa < (SVK_ABLATE(p, 2) ? 0 : nvalid); fa += 2 * FR_PER_FFT) {
-        const bool two = fa + FR_PER_FFT < nvalid;  // wave-uniform
-        const int fb = two ? fa + FR_PER_FFT : fa;
-        cplx va[8], vb[8];
-        float eaa, eba, eab, ebb;
-        load(fa, va, eaa, eba);
-        load(fb, vb, eab, ebb);
-        fft512_wave_x2<(Spec::N_STEPS > 0 ? Spec::N_STEPS : 8)>(va, vb, scr, lane, t1, t2);
-        finish(fa, va, eaa, eba);
-        if (two) finish(fb, vb, eab, ebb);
+      if constexpr (ALIAS_SCR) {
+        float held[4][5] = {};  // frames 4..7: four power values + the energy partial per lane
+        float unused[5];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // unrolled: the frames of trips 2 and 3 index `held` statically
+          const int fa = 2 * t;
+          if (fa < (SVK_ABLATE(p, 2) ? 0 : nvalid)) {  // wave-uniform
+            const bool two = fa + 1 < nvalid;
+            const int fb = two ? fa + 1 : fa;
+            cplx va[8], vb[8];
+            float eaa, eba, eab, ebb;
+            load(fa, va, eaa, eba);
+            load(fb, vb, eab, ebb);
+            fft512_wave_x2<(Spec::N_STEPS > 0 ? Spec::N_STEPS : 8)>(va, vb, scr, lane, t1, t2);
+            if (t < 2) {
+              finish(fa, va, eaa, eba, unused, std::false_type{});
+              if (two) finish(fb, vb, eab, ebb, unused, std::false_type{});
+            } else {
+              finish(fa, va, eaa, eba, held[2 * (t & 1)], std::true_type{});
+              if (two) finish(fb, vb, eab, ebb, held[2 * (t & 1) + 1], std::true_type{});
+            }
+          }
+        }
+        wave_sync();  // the scratch is dead: rows 4..7 may be written
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (4 + q < (SVK_ABLATE(p, 2) ? 0 : nvalid)) {  // wave-uniform
+            float* row = ptile + (4 + q) * prow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int k = lane + 64 * j;
+              if (64 * (j + 1) <= c_kp) row[k] = held[q][j];
+              else if (64 * j < c_kp && k < c_kp) row[k] = held[q][j];
+            }
+            if (c_need_energy && (lane & 7) == 7) row[c_kp + (lane >> 3)] = held[q][4];
+          }
+        }
+      } else {
+        for (int fa = 0; fa < (SVK_ABLATE(p, 2) ? 0 : nvalid); fa += 2 * FR_PER_FFT) {
+          const bool two = fa + FR_PER_FFT < nvalid;  // wave-uniform
+          const int fb = two ? fa + FR_PER_FFT : fa;
+          cplx va[8], vb[8];
+          float eaa, eba, eab, ebb;
+          load(fa, va, eaa, eba);
+          load(fb, vb, eab, ebb);
+          fft512_wave_x2<(Spec::N_STEPS > 0 ? Spec::N_STEPS : 8)>(va, vb, scr, lane, t1, t2);
+          float unused[5];
+          finish(fa, va, eaa, eba, unused, std::false_type{});
+          if (two) finish(fb, vb, eab, ebb, unused, std::false_type{});
+        }
       }
       wave_sync();
 
@@ -646,13 +698,18 @@ struct LdsLayout {
   size_t total;
 };
 LdsLayout lds_layout(const svk_frontend_plan* plan, int tile, bool raw16, int lds_per_cu) {
+  const bool alias_scr = plan->cfg.nfft == 1024 && tile == 8;  // frontend_kernel: ALIAS_SCR
   const int span = (tile - 1) * plan->cfg.frame_stride + plan->flen_eff;
   LdsLayout l;
   if (raw16)
     l.sig_bytes = (((RAW_OFF + span + 8) * 2 + 15) / 16) * 16;  // whole 16-byte groups per lane
   else
     l.sig_bytes = (((span + 8) * 4 + 15) / 16) * 16;
-  l.wave_bytes = l.sig_bytes + (int)sizeof(float) * (tile * (plan->kp + PT_PAD) + 2 * SCR);
+  const int prow = plan->kp + PT_PAD;
+  if (alias_scr)  // scratch starts at row 4 of the power tile
+    l.wave_bytes = l.sig_bytes + (int)sizeof(float) * std::max(tile * prow, 4 * prow + 2 * SCR);
+  else
+    l.wave_bytes = l.sig_bytes + (int)sizeof(float) * (tile * prow + 2 * SCR);
   l.wave_bytes = ((l.wave_bytes + 15) / 16) * 16;
   const int room = lds_per_cu - plan->table_bytes;
   l.waves = room >= l.wave_bytes ? std::min(12, room / l.wave_bytes) : 0;  // 12 waves = 768 threads: up to 168 VGPRs each, no spills

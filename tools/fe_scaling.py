@@ -5,6 +5,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from speaker_verification_amd import _lib, synth
+if os.environ.get("SVK_TOOL_LIB"):      # tuning only: time another build of the library (A/B in one GPU call)
+    _lib.LIB_PATH = os.environ["SVK_TOOL_LIB"]
 from speaker_verification_amd.engine import get_engine, spec_from_seconds
 
 eng = get_engine(0)
@@ -12,7 +14,7 @@ specs = {"A": spec_from_seconds(16000, 0.020, 0.01, 512, 40, 13, _lib.OUT_MFCC, 
          "B": spec_from_seconds(16000, 0.025, 0.01, 1024, 40, 40, _lib.OUT_LMFE, preemph=True, preemph_cof=0.98)}
 base = np.stack([synth.noise_clip(s) for s in range(16)])
 for name, spec in specs.items():
-    for n in (64, 256, 768, 1024, 2048, 4096, 8192):
+    for n in [int(v) for v in os.environ.get("SVK_TOOL_SIZES", "64,256,768,1024,2048,4096,8192").split(",")]:
         pcm = eng.to_device(np.tile(base, (n // 16, 1)))
         for _ in range(3):
             eng.features(pcm, spec)
