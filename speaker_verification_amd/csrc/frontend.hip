@@ -311,24 +311,27 @@ __device__ __forceinline__ float fast_log(float x) {
 // with their framing and output shape folded in, which removes the per-frame dispatch branches,
 // most scalar bookkeeping and the scalar-register spills that came with it.
 struct SpecGeneric {
+  static constexpr int MAX_THREADS = 768;  // 12 waves: up to 168 VGPRs each
   static constexpr int STRIDE = -1, FLEN = -1, N_STEPS = -1, PRE = -1, KP = -1, NEED_ENERGY = -1, N_FT = -1, N_CT = -1,
                        OUT_KIND = -1, NFILT = -1, NCOLS = -1, DC_ELIM = -1;
 };
 // speechpy.feature.mfcc(fs 16 kHz, 20 ms / 10 ms, 40 filters, 13 cepstra, nfft 512), with or without
 // the fused pre-emphasis (PRE stays a launch parameter: one wave-uniform branch per frame read)
 struct SpecMfcc13 {
+  static constexpr int MAX_THREADS = 1024;  // 16 waves of <= 128 VGPRs: this instance fits, and its LDS slice allows 15
   static constexpr int STRIDE = 160, FLEN = 320, N_STEPS = 5, PRE = -1, KP = 128, NEED_ENERGY = 1, N_FT = 3, N_CT = 1,
                        OUT_KIND = SVK_OUT_MFCC, NFILT = 40, NCOLS = 13, DC_ELIM = 1;
 };
 // the model's front end: lmfe(25 ms / 10 ms, 40 filters, nfft 1024) (load_data.py:64-70), with or without
 // the fused pre-emphasis
 struct SpecLmfe40 {
+  static constexpr int MAX_THREADS = 768;
   static constexpr int STRIDE = 160, FLEN = 400, N_STEPS = 4, PRE = -1, KP = 256, NEED_ENERGY = 0, N_FT = 3, N_CT = 0,
                        OUT_KIND = SVK_OUT_LMFE, NFILT = 40, NCOLS = 40, DC_ELIM = 0;
 };
 
 template <typename PcmT, bool SPLIT1024, int TILE, bool RAW16, typename Spec>
-__global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
+__global__ __launch_bounds__(Spec::MAX_THREADS) void frontend_kernel(const FrontendParams p) {
   const int c_stride = Spec::STRIDE >= 0 ? Spec::STRIDE : p.stride;
   const int c_flen = Spec::FLEN >= 0 ? Spec::FLEN : p.flen;
   const int c_flen_eff = Spec::FLEN >= 0 ? Spec::FLEN : p.flen_eff;
@@ -359,11 +362,11 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
   int16_t* sigh = reinterpret_cast<int16_t*>(mine);
   float* ptile = reinterpret_cast<float*>(mine + p.sig_bytes);
   const int prow = c_kp + PT_PAD;
-  // nfft 1024 with 8-frame tiles: the FFT scratch lies over rows 4..7 of the power tile (and a little
-  // beyond); the spectra of frames 4..7 wait in registers until the tile's last FFT is done.  One frame
-  // per FFT makes this cheap (4 floats per frame) and the tile rows are wide (KP = 256): 4.2 KB less LDS
-  // per wave, 8 -> 11 waves per CU for the model's front end.
-  constexpr bool ALIAS_SCR = SPLIT1024 && TILE == 8;
+  // 8-frame tiles: the FFT scratch lies over rows 4..7 of the power tile (and a little beyond); the
+  // spectra of frames 4..7 wait in registers (2-4 floats per lane and frame) until the tile's last FFT
+  // is done.  nfft 1024 (wide rows, KP = 256): 4.2 KB less LDS per wave, 8 -> 12 waves per CU for the
+  // model's front end; nfft 512: 2.2 KB less, 12 -> 15 waves for the MFCC instance.
+  constexpr bool ALIAS_SCR = TILE == 8;
   cplx* scr = reinterpret_cast<cplx*>(ptile + (ALIAS_SCR ? 4 : TILE) * prow);
   const int lane_id = threadIdx.x & 63;
   constexpr bool INT_PCM = sizeof(PcmT) == 2;
@@ -454,9 +457,10 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
           eb = 0.5f * e2.y;
         }
       };
-      // defer = false_type: power bins (and energy group sums) go to the frame's tile row; true_type: into
-      // hold[0..3] (one float per 64-bin step) and hold[4] (energy partial): see ALIAS_SCR
-      auto finish = [&](int f, cplx (&v)[8], float ea, float eb, float (&hold)[5], auto defer) __attribute__((always_inline)) {
+      // defer = false_type: power bins (and energy group sums) go to the frame's tile row(s); true_type: into
+      // hold[0..3] / hold[4..7] (first / second frame of the FFT, one float per 64-bin step) and hold[8], hold[9]
+      // (their energy partials): see ALIAS_SCR
+      auto finish = [&](int f, cplx (&v)[8], float ea, float eb, float (&hold)[10], auto defer) __attribute__((always_inline)) {
         constexpr bool DEFER = decltype(defer)::value;
         if (lane0 && c_need_energy) {
           if (SPLIT1024) {  // X[0] = Re + Im, X[512] = Re - Im of Z[0]
@@ -492,7 +496,10 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
               xa *= xa;
               xb *= xb;
               const float pa = xa.x + xa.y, pb = xb.x + xb.y;  // 4 nfft |X[k]|^2
-              if (64 * (j + 1) <= c_kp) {  // wave-uniform: no exec masking
+              if constexpr (DEFER) {
+                hold[j] = pa;
+                hold[4 + j] = pb;
+              } else if (64 * (j + 1) <= c_kp) {  // wave-uniform: no exec masking
                 rowa[k] = pa;
                 rowb[k] = pb;
               } else if (k < c_kp) {       // ragged last step only
@@ -507,7 +514,8 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
           // row's power bins; the mel stage adds them up with two more MFMAs against a matrix of ones.
           group8_sum2(ea, eb);  // (eb is idle for nfft 1024: its slot still hides ea's DPP wait states)
           if constexpr (DEFER) {
-            hold[4] = ea;
+            hold[8] = ea;
+            hold[9] = eb;
           } else if ((lane & 7) == 7) {
             rowa[c_kp + (lane >> 3)] = ea;
             if (!SPLIT1024) rowb[c_kp + (lane >> 3)] = eb;
@@ -515,40 +523,50 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
         }
       };
       if constexpr (ALIAS_SCR) {
-        float held[4][5] = {};  // frames 4..7: four power values + the energy partial per lane
-        float unused[5];
+        // two FFTs per trip: trips that fill rows 0..3 store directly, the later ones (rows 4..7, under the
+        // scratch) keep their results in `held` -- unrolled so that `held` is indexed statically
+        constexpr int TRIPS = 8 / (2 * FR_PER_FFT), DIRECT = TRIPS / 2, NHELD = 2 * (TRIPS - DIRECT);
+        float held[NHELD][10] = {};
+        float unused[10];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {  // unrolled: the frames of trips 2 and 3 index `held` statically
-          const int fa = 2 * t;
+        for (int t = 0; t < TRIPS; ++t) {
+          const int fa = 2 * FR_PER_FFT * t;
           if (fa < (SVK_ABLATE(p, 2) ? 0 : nvalid)) {  // wave-uniform
-            const bool two = fa + 1 < nvalid;
-            const int fb = two ? fa + 1 : fa;
+            const bool two = fa + FR_PER_FFT < nvalid;
+            const int fb = two ? fa + FR_PER_FFT : fa;
             cplx va[8], vb[8];
             float eaa, eba, eab, ebb;
             load(fa, va, eaa, eba);
             load(fb, vb, eab, ebb);
             fft512_wave_x2<(Spec::N_STEPS > 0 ? Spec::N_STEPS : 8)>(va, vb, scr, lane, t1, t2);
-            if (t < 2) {
+            if (t < DIRECT) {
               finish(fa, va, eaa, eba, unused, std::false_type{});
               if (two) finish(fb, vb, eab, ebb, unused, std::false_type{});
             } else {
-              finish(fa, va, eaa, eba, held[2 * (t & 1)], std::true_type{});
-              if (two) finish(fb, vb, eab, ebb, held[2 * (t & 1) + 1], std::true_type{});
+              finish(fa, va, eaa, eba, held[2 * (t - DIRECT)], std::true_type{});
+              if (two) finish(fb, vb, eab, ebb, held[2 * (t - DIRECT) + 1], std::true_type{});
             }
           }
         }
         wave_sync();  // the scratch is dead: rows 4..7 may be written
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (4 + q < (SVK_ABLATE(p, 2) ? 0 : nvalid)) {  // wave-uniform
-            float* row = ptile + (4 + q) * prow;
+        for (int q = 0; q < NHELD; ++q) {
+          const int f = 4 + FR_PER_FFT * q;  // first frame of held FFT q
+          if (f < (SVK_ABLATE(p, 2) ? 0 : nvalid)) {  // wave-uniform
+            float* rowa = ptile + f * prow;
+            float* rowb = rowa + prow;  // (nfft 512 only; a lone last frame's partner row is >= nvalid: masked at the output)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int k = lane + 64 * j;
-              if (64 * (j + 1) <= c_kp) row[k] = held[q][j];
-              else if (64 * j < c_kp && k < c_kp) row[k] = held[q][j];
+              if (64 * (j + 1) <= c_kp || (64 * j < c_kp && k < c_kp)) {
+                rowa[k] = held[q][j];
+                if (!SPLIT1024) rowb[k] = held[q][4 + j];
+              }
             }
-            if (c_need_energy && (lane & 7) == 7) row[c_kp + (lane >> 3)] = held[q][4];
+            if (c_need_energy && (lane & 7) == 7) {
+              rowa[c_kp + (lane >> 3)] = held[q][8];
+              if (!SPLIT1024) rowb[c_kp + (lane >> 3)] = held[q][9];
+            }
           }
         }
       } else {
@@ -560,7 +578,7 @@ __global__ __launch_bounds__(768) void frontend_kernel(const FrontendParams p) {
           load(fa, va, eaa, eba);
           load(fb, vb, eab, ebb);
           fft512_wave_x2<(Spec::N_STEPS > 0 ? Spec::N_STEPS : 8)>(va, vb, scr, lane, t1, t2);
-          float unused[5];
+          float unused[10];
           finish(fa, va, eaa, eba, unused, std::false_type{});
           if (two) finish(fb, vb, eab, ebb, unused, std::false_type{});
         }
@@ -697,8 +715,8 @@ struct LdsLayout {
   int sig_bytes, wave_bytes, waves;
   size_t total;
 };
-LdsLayout lds_layout(const svk_frontend_plan* plan, int tile, bool raw16, int lds_per_cu) {
-  const bool alias_scr = plan->cfg.nfft == 1024 && tile == 8;  // frontend_kernel: ALIAS_SCR
+LdsLayout lds_layout(const svk_frontend_plan* plan, int tile, bool raw16, int lds_per_cu, int max_waves = 12) {
+  const bool alias_scr = tile == 8;  // frontend_kernel: ALIAS_SCR
   const int span = (tile - 1) * plan->cfg.frame_stride + plan->flen_eff;
   LdsLayout l;
   if (raw16)
@@ -712,7 +730,8 @@ LdsLayout lds_layout(const svk_frontend_plan* plan, int tile, bool raw16, int ld
     l.wave_bytes = l.sig_bytes + (int)sizeof(float) * (tile * prow + 2 * SCR);
   l.wave_bytes = ((l.wave_bytes + 15) / 16) * 16;
   const int room = lds_per_cu - plan->table_bytes;
-  l.waves = room >= l.wave_bytes ? std::min(12, room / l.wave_bytes) : 0;  // 12 waves = 768 threads: up to 168 VGPRs each, no spills
+  // 12 waves = 768 threads: up to 168 VGPRs each; an instance built for 1 024 threads (<= 128 VGPRs) may take 16
+  l.waves = room >= l.wave_bytes ? std::min(max_waves, room / l.wave_bytes) : 0;
   l.total = (size_t)plan->table_bytes + (size_t)l.waves * l.wave_bytes;
   return l;
 }
@@ -967,18 +986,23 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.need_energy = (d_energy != nullptr) || (plan->cfg.out_kind == SVK_OUT_MFCC && plan->cfg.dc_elimination);
 
   const int64_t total = (int64_t)n_utt * p.tiles_per_utt;
-  // one workgroup of lds.waves waves per CU (it owns the CU's LDS); fewer when there is little work
-  int waves = (int)std::max<int64_t>(1, std::min<int64_t>(lds.waves, (total + ctx->num_cu - 1) / ctx->num_cu));
+  const bool generic_only = getenv("SVK_FE_GENERIC") != nullptr;  // tuning / tests: force the unspecialised instance
+  const bool split = plan->cfg.nfft == 1024;
+  // the int16 MFCC instance is compiled for 1 024 threads (SpecMfcc13::MAX_THREADS)
+  const bool mfcc13_i16 = pcm_dtype == SVK_PCM_I16 && raw16 && plan->tile == 8 && !generic_only && !split &&
+                          spec_matches<SpecMfcc13>(p);
+  const int wave_cap = mfcc13_i16 ? SpecMfcc13::MAX_THREADS / 64 : 12;
+  const int fit_waves = mfcc13_i16 ? lds_layout(plan, plan->tile, raw16, ctx->lds_per_cu, wave_cap).waves : lds.waves;
+  // one workgroup of that many waves per CU (it owns the CU's LDS); fewer when there is little work
+  int waves = (int)std::max<int64_t>(1, std::min<int64_t>(fit_waves, (total + ctx->num_cu - 1) / ctx->num_cu));
   if (const char* env = getenv("SVK_FE_WAVES")) waves = std::max(1, std::min(waves, atoi(env)));  // tuning only
   const int64_t grid = std::min<int64_t>((total + waves - 1) / waves, ctx->num_cu);
   if ((int64_t)n_utt * p.tiles_per_utt >= ((int64_t)1 << 31))
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "%lld frame tiles in one launch (limit 2^31): split the batch",
                     (long long)n_utt * p.tiles_per_utt);
   const size_t lds_total = (size_t)plan->table_bytes + (size_t)waves * lds.wave_bytes;
-  const bool split = plan->cfg.nfft == 1024;
   void (*kern)(const FrontendParams) = nullptr;
-  const bool generic_only = getenv("SVK_FE_GENERIC") != nullptr;  // tuning / tests: force the unspecialised instance
-  if (pcm_dtype == SVK_PCM_I16 && raw16 && plan->tile == 8 && !generic_only && !split && spec_matches<SpecMfcc13>(p))
+  if (mfcc13_i16)
     kern = frontend_kernel<int16_t, false, 8, true, SpecMfcc13>;
   else if (pcm_dtype == SVK_PCM_I16 && raw16 && plan->tile == 8 && !generic_only && split && spec_matches<SpecLmfe40>(p))
     kern = frontend_kernel<int16_t, true, 8, true, SpecLmfe40>;
