@@ -377,6 +377,39 @@ __global__ __launch_bounds__(256) void cube_windows_kernel(const float* __restri
   }
 }
 
+// The C3D2 geometry (kd = 3 crops x a 16-float window, 3 column groups: 12 float4 per matrix row) with
+// the index arithmetic on compile-time constants and four independent copies in flight per lane.
+__global__ __launch_bounds__(256) void cube_windows_c3d2_kernel(const float* __restrict__ feat, int max_frames,
+                                                                int ncols, const int32_t* __restrict__ crop,
+                                                                int n_crops, int crop_frames, int G, int od,
+                                                                float* __restrict__ out) {
+  constexpr int KD = 3, W4 = 4, NWG = 3, ROW4 = KD * W4;
+  const int u = blockIdx.x / od, d = blockIdx.x - u * od;
+  const int per_block = crop_frames * NWG * ROW4;
+  f32x4* dst = reinterpret_cast<f32x4*>(out) + (int64_t)blockIdx.x * per_block;
+  int start[KD];  // wave-uniform: scalar loads
+#pragma unroll
+  for (int k = 0; k < KD; ++k) start[k] = crop[(int64_t)u * n_crops + d + k];
+  const float* base = feat + (int64_t)u * max_frames * ncols;
+  for (int v0 = threadIdx.x; v0 < per_block; v0 += 4 * 256) {
+    f32x4 val[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int v = v0 + 256 * q;
+      const int m = v / ROW4, s = v - m * ROW4;
+      const int h = m / NWG, wg = m - h * NWG;
+      const int kdi = s / W4, j4 = s - kdi * W4;
+      const int st = kdi == 0 ? start[0] : (kdi == 1 ? start[1] : start[2]);
+      val[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (v < per_block && st >= 0 && st + h < max_frames)
+        val[q] = *reinterpret_cast<const f32x4*>(base + (int64_t)(st + h) * ncols + wg * G + 4 * j4);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (v0 + 256 * q < per_block) dst[v0 + 256 * q] = val[q];
+  }
+}
+
 // ---- crop starts drawn on device ---------------------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -625,8 +658,12 @@ int svk_cube_gather_windows(svk_ctx* ctx, const float* d_feat, int32_t n_utt, in
                     "svk_cube_gather_windows copies 16-byte pieces: group, kw + group - 1 and n_cols must be "
                     "multiples of 4 and the buffers 16-byte aligned (group %d, window %d, n_cols %d)", group, win, n_cols);
   SVK_REQUIRE(ctx, (int64_t)n_utt * od < ((int64_t)1 << 31), "too many (clip, depth) blocks for one launch");
-  hipLaunchKernelGGL(cube_windows_kernel, dim3((unsigned)(n_utt * od)), dim3(256), 0, ctx->stream, d_feat, max_frames,
-                     n_cols, d_crop_idx, n_crops, crop_frames, kd, win, group, ow / group, od, d_out);
+  if (kd == 3 && win == 16 && ow / group == 3)
+    hipLaunchKernelGGL(cube_windows_c3d2_kernel, dim3((unsigned)(n_utt * od)), dim3(256), 0, ctx->stream, d_feat,
+                       max_frames, n_cols, d_crop_idx, n_crops, crop_frames, group, od, d_out);
+  else
+    hipLaunchKernelGGL(cube_windows_kernel, dim3((unsigned)(n_utt * od)), dim3(256), 0, ctx->stream, d_feat, max_frames,
+                       n_cols, d_crop_idx, n_crops, crop_frames, kd, win, group, ow / group, od, d_out);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }

@@ -621,6 +621,10 @@ def test_cube_windows_equals_cube_path(eng, golden):
     assert torch.equal(emb.from_windows(win, n, 20, 80, C), emb(cube))
     with pytest.raises(Exception, match="multiples of 4"):
         eng.cube_windows(feat, idx, 80, kd, kw, 9)
+    # another geometry (one group of 36 columns: window 40) takes the generic kernel
+    win36 = eng.cube_windows(feat, idx, 80, kd, kw, 36)
+    want36 = xs.as_strided((n, od, 80, 1, kd, C), (20 * 80 * C, 80 * C, C, 36, 80 * C, 1)).reshape(-1, kd * C)
+    assert torch.equal(win36, want36)
 
 
 def test_overlapped_front_end_gives_the_same_embeddings(eng):
