@@ -19,7 +19,7 @@ from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OURS = ("frontend_kernel", "cmvn_kernel", "vad_kernel", "cube_gather_kernel", "cosine_kernel", "cosine_tiled_kernel",
-        "inv_norm_kernel", "draw_crops_kernel", "cube_windows_kernel", "decimate_kernel", "resample_kernel")
+        "inv_norm_kernel", "draw_crops_kernel", "cube_windows_kernel", "cube_windows_c3d2_kernel", "decimate_kernel", "resample_kernel")
 
 
 def short(name):
