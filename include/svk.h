@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 100 /* 0.1.0 */
+#define SVK_VERSION 101 /* 0.1.1 */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -82,6 +82,8 @@ typedef struct svk_frontend_cfg {
   int32_t preemph;        /* 0 = none, 1 = y[n] = x[n] - cof * x[(n-shift) mod N] */
   int32_t preemph_shift;
   float preemph_cof;
+  float input_scale;      /* amplitude factor applied to the PCM first; 0 = 1.  2^-15 reads int16 PCM as
+                             librosa.load hands it to lmfe (utils.py:170-173, load_data.py:50-70)          */
 } svk_frontend_cfg;
 
 /* h_filterbank: num_filters x (nfft/2+1) float64, row-major -- the matrix of

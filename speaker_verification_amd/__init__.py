@@ -9,5 +9,5 @@ gfx950 HIP kernels behind the C-ABI of `include/svk.h` (`libsvk.so`, loaded by
 Importing the package is cheap and needs no GPU; the first call into a device
 op loads `libsvk.so` and raises if it is missing -- there is no CPU fallback.
 """
-__all__ = ["speechpy", "vad", "model", "siamese", "evaluation", "pipeline",
-           "distributed", "synth", "frontend"]
+__all__ = ["speechpy", "vad", "model", "siamese", "evaluation", "pipeline", "distributed", "synth",
+           "utils", "load_data", "ingest", "engine", "constants", "train_siamese"]

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsvk.so")
 
 SVK_OK = 0
+VERSION = 101                      # include/svk.h SVK_VERSION
 SVK_ERR_BAD_ARG, SVK_ERR_UNSUPPORTED, SVK_ERR_HIP, SVK_ERR_NO_DEVICE, SVK_ERR_OOM = -1, -2, -3, -4, -5
 OUT_MFE, OUT_LMFE, OUT_MFCC = 0, 1, 2
 PCM_I16, PCM_F32 = 0, 1
@@ -31,7 +32,7 @@ class FrontendCfg(C.Structure):
     _fields_ = [("frame_len", C.c_int32), ("frame_stride", C.c_int32), ("nfft", C.c_int32),
                 ("num_filters", C.c_int32), ("num_ceps", C.c_int32), ("out_kind", C.c_int32),
                 ("dc_elimination", C.c_int32), ("preemph", C.c_int32), ("preemph_shift", C.c_int32),
-                ("preemph_cof", C.c_float)]
+                ("preemph_cof", C.c_float), ("input_scale", C.c_float)]
 
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -93,8 +94,9 @@ def load():
             fn = getattr(lib, name)            # AttributeError if the .so is stale
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.svk_version() != 100:
-            raise RuntimeError(f"libsvk.so version {lib.svk_version()} does not match this package (100)")
+        if lib.svk_version() != VERSION:
+            raise RuntimeError(f"libsvk.so version {lib.svk_version()} does not match this package ({VERSION}): "
+                               "rebuild it (make -C speaker_verification_amd/csrc)")
         _lib = lib
     return _lib
 

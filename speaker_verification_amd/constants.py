@@ -1,5 +1,14 @@
 """Signal-processing constants of the reference's model front end
-(`/root/reference/constants.py:13-19`), imported as `c` like the reference does."""
+(`/root/reference/constants.py:13-19`), imported as `c` like the reference does, plus the paths its
+file-driven entry points read (`constants.py:3-10`: `evaluation.evaluate()` and
+`model.create_speaker_models()` look under ROOT for `Models/model_14_percent_best_so_far.pt`,
+`50_first_ids.txt`, `50_first_ids.npy`, `speaker_models/`, and under DATA_ORIGIN for the WAVs)."""
+import os
+
+ROOT = os.path.abspath(os.path.dirname(__file__))
+DATA_TEMP = os.path.join(ROOT, 'data_temp/')
+DATA_ORIGIN = os.path.join(ROOT, 'data_temp_small/')
+NUM_FILES = 0                     # 0 = every listed file (load_data.py:42-45)
 DERIVATIVE = False
 NORMALIZE = False
 SAMPLE_RATE = 16000

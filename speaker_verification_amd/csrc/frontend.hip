@@ -73,6 +73,7 @@ struct FrontendParams {
   int32_t n_utt, max_frames, tiles_per_utt;
   int32_t flen, flen_eff, stride, nfilt, ncols, out_kind, dc_elim, preemph, pre_shift;
   float pre_cof;
+  float escale;      // input_scale^2: applied to the frame energy (the mel path carries it in the bank weights)
   int32_t kp;        // power bins kept for the mel product, multiple of 16
   int32_t sig_bytes; // LDS bytes reserved for the staged samples (multiple of 16)
   int32_t n_ft, n_ct;
@@ -458,9 +459,10 @@ __global__ __launch_bounds__(Spec::MAX_THREADS) void frontend_kernel(const Front
         }
       };
       // defer = false_type: power bins (and energy group sums) go to the frame's tile row(s); true_type: into
-      // hold[0..3] / hold[4..7] (first / second frame of the FFT, one float per 64-bin step) and hold[8], hold[9]
-      // (their energy partials): see ALIAS_SCR
-      auto finish = [&](int f, cplx (&v)[8], float ea, float eb, float (&hold)[10], auto defer) __attribute__((always_inline)) {
+      // hold[0..4] / hold[5..9] (first / second frame of the FFT, one float per 64-bin step) and hold[10], hold[11]
+      // (their energy partials): see ALIAS_SCR.  Step j = 4 (bins 256..287) exists only when the bank reaches
+      // bin 256 = nfft/4 of a 1024-point transform (kp = 288: SpeechPy's bank at any rate but 16 kHz, Q2).
+      auto finish = [&](int f, cplx (&v)[8], float ea, float eb, float (&hold)[12], auto defer) __attribute__((always_inline)) {
         constexpr bool DEFER = decltype(defer)::value;
         if (lane0 && c_need_energy) {
           if (SPLIT1024) {  // X[0] = Re + Im, X[512] = Re - Im of Z[0]
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(Spec::MAX_THREADS) void frontend_kernel(const Front
         float* rowb = rowa + prow;  // (a lone last frame writes its zero partner into a row >= nvalid of the tile: masked at the output)
         cplx carry = v[0];  // lane 0 pairs bin 64 j with bin 64 (8 - j): one register later
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 5; ++j) {
           if (64 * j < c_kp) {
             const cplx sm = shfl2(v[7 - j], mirror);
             const cplx zk = v[j], zn = lane0 ? carry : sm;
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(Spec::MAX_THREADS) void frontend_kernel(const Front
               const float pa = xa.x + xa.y, pb = xb.x + xb.y;  // 4 nfft |X[k]|^2
               if constexpr (DEFER) {
                 hold[j] = pa;
-                hold[4 + j] = pb;
+                hold[5 + j] = pb;
               } else if (64 * (j + 1) <= c_kp) {  // wave-uniform: no exec masking
                 rowa[k] = pa;
                 rowb[k] = pb;
@@ -514,8 +516,8 @@ __global__ __launch_bounds__(Spec::MAX_THREADS) void frontend_kernel(const Front
           // row's power bins; the mel stage adds them up with two more MFMAs against a matrix of ones.
           group8_sum2(ea, eb);  // (eb is idle for nfft 1024: its slot still hides ea's DPP wait states)
           if constexpr (DEFER) {
-            hold[8] = ea;
-            hold[9] = eb;
+            hold[10] = ea;
+            hold[11] = eb;
           } else if ((lane & 7) == 7) {
             rowa[c_kp + (lane >> 3)] = ea;
             if (!SPLIT1024) rowb[c_kp + (lane >> 3)] = eb;
@@ -526,8 +528,8 @@ __global__ __launch_bounds__(Spec::MAX_THREADS) void frontend_kernel(const Front
         // two FFTs per trip: trips that fill rows 0..3 store directly, the later ones (rows 4..7, under the
         // scratch) keep their results in `held` -- unrolled so that `held` is indexed statically
         constexpr int TRIPS = 8 / (2 * FR_PER_FFT), DIRECT = TRIPS / 2, NHELD = 2 * (TRIPS - DIRECT);
-        float held[NHELD][10] = {};
-        float unused[10];
+        float held[NHELD][12] = {};
+        float unused[12];
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
           const int fa = 2 * FR_PER_FFT * t;
@@ -556,16 +558,16 @@ __global__ __launch_bounds__(Spec::MAX_THREADS) void frontend_kernel(const Front
             float* rowa = ptile + f * prow;
             float* rowb = rowa + prow;  // (nfft 512 only; a lone last frame's partner row is >= nvalid: masked at the output)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 5; ++j) {
               const int k = lane + 64 * j;
               if (64 * (j + 1) <= c_kp || (64 * j < c_kp && k < c_kp)) {
                 rowa[k] = held[q][j];
-                if (!SPLIT1024) rowb[k] = held[q][4 + j];
+                if (!SPLIT1024) rowb[k] = held[q][5 + j];
               }
             }
             if (c_need_energy && (lane & 7) == 7) {
-              rowa[c_kp + (lane >> 3)] = held[q][8];
-              if (!SPLIT1024) rowb[c_kp + (lane >> 3)] = held[q][9];
+              rowa[c_kp + (lane >> 3)] = held[q][10];
+              if (!SPLIT1024) rowb[c_kp + (lane >> 3)] = held[q][11];
             }
           }
         }
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(Spec::MAX_THREADS) void frontend_kernel(const Front
           load(fa, va, eaa, eba);
           load(fb, vb, eab, ebb);
           fft512_wave_x2<(Spec::N_STEPS > 0 ? Spec::N_STEPS : 8)>(va, vb, scr, lane, t1, t2);
-          float unused[10];
+          float unused[12];
           finish(fa, va, eaa, eba, unused, std::false_type{});
           if (two) finish(fb, vb, eab, ebb, unused, std::false_type{});
         }
@@ -619,7 +621,8 @@ __global__ __launch_bounds__(Spec::MAX_THREADS) void frontend_kernel(const Front
         f32x4 oe = (f32x4){0.f, 0.f, 0.f, 0.f};
         oe = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, pe[0], oe, 0, 0, 0);
         oe = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, pe[4], oe, 0, 0, 0);
-        e_frame = oe[0] == 0.f ? EPS64 : oe[0];
+        const float e = oe[0] * p.escale;
+        e_frame = e == 0.f ? EPS64 : e;
       }
       if (SVK_ABLATE(p, 32)) continue;
       // lane (jf, g) now holds mel[filter 16 t + 4 g + reg][frame jf]
@@ -781,7 +784,6 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
                     cfg->num_filters);
   if (cfg->out_kind == SVK_OUT_MFCC)
     SVK_REQUIRE(ctx, cfg->num_ceps >= 1 && cfg->num_ceps <= cfg->num_filters, "1 <= num_ceps <= num_filters");
-  if (cfg->preemph) SVK_REQUIRE(ctx, cfg->preemph_shift != 0 || true, "preemph_shift");
 
   svk_frontend_plan* plan = new (std::nothrow) svk_frontend_plan();
   if (!plan) return SVK_ERR_OOM;
@@ -799,10 +801,12 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
   for (int i = 0; i < nf; ++i)
     for (int k = 0; k < nbins; ++k)
       if (h_filterbank[(size_t)i * nbins + k] != 0.0 && k > kmax) kmax = k;
-  if (kmax >= 256) {
+  // bins 0..255 are the four 64-bin steps of the untangling; bin 256 (= nfft/4 of a 1024-point transform, where
+  // SpeechPy's bank ends at every sampling rate but 16 kHz, Q2) costs a fifth, mostly idle step: kp = 288
+  if (kmax > 256) {
     delete plan;
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED,
-                    "filterbank reaches bin %d; the fused kernel keeps bins < 256 (the SpeechPy bank stops at "
+                    "filterbank reaches bin %d; the fused kernel keeps bins <= 256 (the SpeechPy bank stops at "
                     "(nfft/2+2)/2, Q2)", kmax);
   }
   plan->kp = ((kmax + 1 + 31) / 32) * 32;  // a multiple of 32 bins: the mel loop consumes chunks of 16 in pairs
@@ -873,7 +877,10 @@ int svk_frontend_plan_create(svk_ctx* ctx, const svk_frontend_cfg* cfg, const do
       h_tw3[2 * (q * 64 + l)] = (float)cos(a);
       h_tw3[2 * (q * 64 + l) + 1] = (float)sin(a);
     }
-  const double power_scale = cfg->nfft == 1024 ? 1.0 / 4096.0 : 1.0 / 2048.0;
+  // input_scale (e.g. 2^-15: int16 PCM read the way librosa hands it to the reference's lmfe call,
+  // load_data.py:50-70) enters every power as its square: folded into the weights, exact for powers of two
+  const double in_scale = cfg->input_scale != 0.f ? (double)cfg->input_scale : 1.0;
+  const double power_scale = (cfg->nfft == 1024 ? 1.0 / 4096.0 : 1.0 / 2048.0) * in_scale * in_scale;
   // A-operand fragments of the filterbank: lane l = (i = l & 15, kk = l >> 4), element e of
   // chunk u is fb[16 t + i][16 u + 4 kk + e]
   for (int t = 0; t < plan->n_ft; ++t)
@@ -958,6 +965,7 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.preemph = plan->cfg.preemph;
   p.pre_shift = plan->cfg.preemph_shift;
   p.pre_cof = plan->cfg.preemph_cof;
+  p.escale = plan->cfg.input_scale != 0.f ? plan->cfg.input_scale * plan->cfg.input_scale : 1.0f;
   p.kp = plan->kp;
   p.sig_bytes = lds.sig_bytes;
   p.wave_bytes = lds.wave_bytes;

@@ -103,8 +103,12 @@ __global__ __launch_bounds__(VAD_THREADS) void vad_kernel(const int16_t* __restr
         const int f = f0 + b;
         const int sbit = (int)((m >> b) & 1ull);
         if (since == ring_len) {  // deque(maxlen) drops the oldest: flag[f - ring_len]
+          // this chunk's or the previous chunk's ballot mask; a ring longer than 64 frames (10 ms
+          // frames with 1 s of padding: 100) reaches further back: one LDS broadcast read
           const int o = b - ring_len;
-          voiced_in_ring -= o >= 0 ? (int)((m >> o) & 1ull) : (int)((prev >> (64 + o)) & 1ull);
+          voiced_in_ring -= o >= 0     ? (int)((m >> o) & 1ull)
+                            : o >= -64 ? (int)((prev >> (64 + o)) & 1ull)
+                                       : (int)flag[f - ring_len];
         } else {
           ++since;
         }

@@ -26,11 +26,15 @@ class FrontendSpec:
     'a small frozen FrontEndConfig')."""
 
     __slots__ = ("fs", "frame_len", "frame_stride", "nfft", "num_filters", "num_ceps", "out_kind",
-                 "dc_elimination", "low_freq", "high_freq", "preemph", "preemph_shift", "preemph_cof")
+                 "dc_elimination", "low_freq", "high_freq", "preemph", "preemph_shift", "preemph_cof",
+                 "input_scale")
 
     def __init__(self, fs, frame_len, frame_stride, nfft, num_filters, num_ceps, out_kind,
                  dc_elimination=True, low_freq=0, high_freq=None, preemph=False, preemph_shift=1,
-                 preemph_cof=0.98):
+                 preemph_cof=0.98, input_scale=1.0):
+        """input_scale: amplitude factor applied to the PCM before anything else (1/32768 reads int16
+        PCM as the float signal librosa.load hands the reference's lmfe call, load_data.py:50-70)."""
+        self.input_scale = float(input_scale)
         self.fs, self.frame_len, self.frame_stride, self.nfft = fs, int(frame_len), int(frame_stride), int(nfft)
         self.num_filters, self.num_ceps, self.out_kind = int(num_filters), int(num_ceps), int(out_kind)
         self.dc_elimination, self.low_freq, self.high_freq = bool(dc_elimination), low_freq, high_freq
@@ -51,7 +55,7 @@ class FrontendSpec:
     def c_struct(self):
         return FrontendCfg(self.frame_len, self.frame_stride, self.nfft, self.num_filters,
                            max(1, self.num_ceps), self.out_kind, int(self.dc_elimination), int(self.preemph),
-                           self.preemph_shift, self.preemph_cof)
+                           self.preemph_shift, self.preemph_cof, self.input_scale)
 
 
 def spec_from_seconds(fs, frame_length, frame_stride, nfft, num_filters, num_ceps, out_kind, **kw):
@@ -80,8 +84,9 @@ class Engine:
 
     def __del__(self):
         try:
-            for plan, _ in self._plans.values():
-                self.lib.svk_frontend_plan_destroy(plan)
+            for hit in self._plans.values():
+                if not isinstance(hit, Exception):
+                    self.lib.svk_frontend_plan_destroy(hit[0])
             if self.ctx:
                 self.lib.svk_destroy(self.ctx)
         except Exception:
@@ -119,15 +124,22 @@ class Engine:
         from .speechpy import feature as _feature
         key = spec.key()
         hit = self._plans.get(key)
+        if isinstance(hit, Exception):           # a configuration the fused kernel refused before
+            raise hit
         if hit is None:
             bank = np.ascontiguousarray(
                 _feature.filterbanks(spec.num_filters, spec.nfft // 2 + 1, spec.fs, spec.low_freq,
                                      spec.high_freq or spec.fs / 2), dtype=np.float64)
             cfg = spec.c_struct()
             handle = C.c_void_p()
-            check(self.lib.svk_frontend_plan_create(self.ctx, C.byref(cfg),
-                                                    bank.ctypes.data_as(C.POINTER(C.c_double)), C.byref(handle)),
-                  self.ctx)
+            try:
+                check(self.lib.svk_frontend_plan_create(self.ctx, C.byref(cfg),
+                                                        bank.ctypes.data_as(C.POINTER(C.c_double)),
+                                                        C.byref(handle)), self.ctx)
+            except _lib.SvkError as err:
+                if err.code == _lib.SVK_ERR_UNSUPPORTED:
+                    self._plans[key] = err
+                raise
             hit = (handle, cfg)
             self._plans[key] = hit
         return hit
@@ -142,7 +154,15 @@ class Engine:
         returns (feat [n_utt, max_frames, cols] f32, n_frames [n_utt] i32, energy or None)
         """
         torch = _torch()
-        handle, _ = self.plan(spec)
+        try:
+            handle, _ = self.plan(spec)
+        except _lib.SvkError as err:
+            if err.code != _lib.SVK_ERR_UNSUPPORTED:
+                raise
+            # what the fused kernel does not cover (other fft lengths, > 64 filters, a bank past bin
+            # nfft/4 of 1024 or nfft/2 of 512, frames too long for a CU's LDS): the same stages as
+            # separate kernels, clip by clip
+            return self._features_staged(pcm, spec, lengths, offsets, clip_len, max_frames, want_energy)
         pcm = self.to_device(pcm)
         if pcm.dtype == torch.int16:
             kind = _lib.PCM_I16
@@ -174,6 +194,52 @@ class Engine:
                                         self._ptr(lengths), stride, length, n_utt, max_frames,
                                         self._ptr(feat), self._ptr(energy), self._ptr(n_frames)), self.ctx)
         return feat, n_frames, energy
+
+    def _features_staged(self, pcm, spec, lengths, offsets, clip_len, max_frames, want_energy):
+        """`features` for any configuration: svk_preemphasis -> svk_stack_frames -> svk_spectrum ->
+        svk_mel_features per clip (feature.py:156-219 stage by stage).  Same outputs and layout."""
+        torch = _torch()
+        from .speechpy import feature as _feature
+        pcm = self.to_device(pcm)
+        if pcm.dtype not in (torch.int16, torch.float32):
+            pcm = pcm.to(torch.float32)
+        if offsets is not None:
+            if lengths is None:
+                raise ValueError("offsets need lengths")
+            offs = [int(v) for v in torch.as_tensor(offsets).cpu().tolist()]
+            lens = [int(v) for v in torch.as_tensor(lengths).cpu().tolist()]
+            clips = [pcm.reshape(-1)[o:o + n] for o, n in zip(offs, lens)]
+        else:
+            if pcm.dim() == 1:
+                pcm = pcm[None]
+            full = pcm.shape[1] if clip_len is None else int(clip_len)
+            lens = [full] * pcm.shape[0] if lengths is None else \
+                [int(v) for v in torch.as_tensor(lengths).cpu().tolist()]
+            clips = [pcm[i, :n] for i, n in enumerate(lens)]
+        if max_frames is None:
+            max_frames = spec.num_frames(max(lens) if lens else 0)
+        bank = _feature.filterbanks(spec.num_filters, spec.nfft // 2 + 1, spec.fs, spec.low_freq,
+                                    spec.high_freq or spec.fs / 2)
+        bank_dev = self.to_device(bank, torch.float32)
+        cols = spec.num_cols
+        feat = torch.zeros((len(clips), max_frames, cols), dtype=torch.float32, device=self.device)
+        n_frames = torch.zeros((len(clips),), dtype=torch.int32)
+        energy = torch.zeros((len(clips), max_frames), dtype=torch.float32, device=self.device) if want_energy else None
+        for i, clip in enumerate(clips):
+            T = min(spec.num_frames(int(clip.numel())), max_frames)
+            n_frames[i] = T
+            if T <= 0:
+                continue
+            sig = self.preemphasis(clip, spec.preemph_shift, spec.preemph_cof) if spec.preemph else clip.to(torch.float32)
+            if spec.input_scale != 1.0:
+                sig = sig * spec.input_scale
+            frames = self.stack_frames(sig, spec.frame_len, spec.frame_stride, T)
+            power = self.spectrum(frames, spec.nfft, power=True)
+            f, e = self.mel_features(power, bank_dev, spec.out_kind, spec.num_ceps, spec.dc_elimination, want_energy)
+            feat[i, :T] = f
+            if want_energy:
+                energy[i, :T] = e
+        return feat, n_frames.to(self.device), energy
 
     # ---- stage-level kernels ------------------------------------------------------
     def preemphasis(self, signal, shift=1, cof=0.98):

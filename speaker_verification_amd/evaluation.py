@@ -133,10 +133,103 @@ def labels_from_ids(test_ids, speaker_ids):
     return labels
 
 
-def evaluate(model, cubes, test_ids, speaker_models, k=1, plot_path='eer_auc.png'):
-    """The loop of evaluation.py:90-146 on in-memory data (the reference's files --
-    checkpoint, id lists, WAVs -- do not ship): score every cube against every
-    enrolled speaker, build one-hot labels, report EER / AUC / top-1 accuracy."""
+def dataset_embeddings(dataset, model, batch=256):
+    """Embeddings [len(dataset), 128] (device) of every file of a `load_data.AudioDataset`, in order:
+    the per-item chain of the reference (load_data.py:50-87 `load_wav` -> `lmfe`; utils.py:382-397 CMVN;
+    utils.py:351-379 FeatureCube with crop starts from the GLOBAL NumPy RNG, drawn in file order;
+    `model(cube, development=False)`) run `batch` files at a time: one ragged front-end launch, one
+    CMVN, one cube gather, one network call per batch."""
+    from . import _lib
+    from . import constants as c
+    from .engine import spec_from_seconds
+    eng = get_engine()
+    model = model.to(eng.device).eval()
+    n = len(dataset)
+    out = torch.empty((n, 128), dtype=torch.float32, device=eng.device)
+    if c.DERIVATIVE:
+        # three-channel cubes (utils.py:385-391): the per-item transform chain, network call batched
+        for lo in range(0, n, batch):
+            cubes = np.stack([np.asarray(dataset[i][0], dtype=np.float32) for i in range(lo, min(n, lo + batch))])
+            with torch.no_grad():
+                out[lo:lo + len(cubes)] = model(eng.to_device(cubes), development=False)
+        return out
+    spec = spec_from_seconds(c.SAMPLE_RATE, c.FRAME_LEN, c.FRAME_STEP, c.NUM_FFT, c.NUM_COEF, c.NUM_COEF,
+                             _lib.OUT_LMFE)
+    embed = model.fused_inference(channels_last=True) if hasattr(model, "fused_inference") else None
+    for lo in range(0, n, batch):
+        hi = min(n, lo + batch)
+        sigs = [np.asarray(dataset.load_signal(i), dtype=np.float32) for i in range(lo, hi)]
+        lens = np.array([s.size for s in sigs], dtype=np.int32)
+        offs = np.zeros(len(sigs), dtype=np.int64)
+        offs[1:] = np.cumsum((lens[:-1] + 3) // 4 * 4)               # 16-byte aligned clip starts
+        buf = np.zeros(int(offs[-1] + (lens[-1] + 3) // 4 * 4), dtype=np.float32)
+        for o, s in zip(offs, sigs):
+            buf[o:o + s.size] = s
+        frames = [spec.num_frames(int(v)) for v in lens]
+        feat, n_frames, _ = eng.features(buf, spec, lengths=lens, offsets=offs, max_frames=max(frames))
+        if c.NORMALIZE:
+            eng.cmvn_(feat, n_frames, variance=True)
+        # utils.py:372, one draw per file in file order (numpy raises for clips of <= 80 frames, as there)
+        idx = np.stack([np.random.randint(T - c.CUBE_FRAMES, size=c.CUBE_CROPS) for T in frames]).astype(np.int32)
+        cube = eng.cube_gather(feat, idx, c.CUBE_FRAMES)
+        with torch.no_grad():
+            out[lo:hi] = embed(cube) if embed is not None else model(cube, development=False)
+    return out
+
+
+def load_indexed_labels(path):
+    """{speaker id: class index} of the reference's `50_first_ids.npy` (a pickled dict inside an .npy,
+    evaluation.py:100) -- or of a `.json` file of the same stem, preferred when present."""
+    import json
+    alt = os.path.splitext(path)[0] + '.json'
+    if os.path.exists(alt):
+        with open(alt) as fh:
+            return json.load(fh)
+    return np.load(path, allow_pickle=True).item()          # the user's own id table, in the reference's format
+
+
+def _evaluate_files(k, plot_path):
+    """evaluation.py:90-146 as written: checkpoint, id list, id table, WAV tree and enrolled models
+    under `constants.ROOT` / `constants.DATA_ORIGIN`."""
+    from . import constants as c
+    from .model import C3D2
+    from .utils import create_dataset
+    model_path = os.path.join(c.ROOT, 'Models/model_14_percent_best_so_far.pt')
+    checkpoint = torch.load(model_path, map_location="cpu", weights_only=True)
+    model = C3D2(100, 1).load_checkpoint(checkpoint)
+    dir_path = os.path.join(c.ROOT, 'speaker_models')
+    test_set = os.path.join(c.ROOT, '50_first_ids.txt')
+    indexed_labels = load_indexed_labels(c.ROOT + '/50_first_ids.npy')
+    dataset = create_dataset(indexed_labels=indexed_labels, origin_file_path=test_set)
+    ev = Evaluation(model, dir_path)
+    speaker_model_ids = list(ev.speaker_models.keys())
+    emb = dataset_embeddings(dataset, model)
+    scores = get_engine().cosine_scores(emb, ev._enroll_matrix()).to("cpu").numpy().astype(np.float64)
+    labels = np.zeros_like(scores)
+    correct = 0
+    ids = np.array(speaker_model_ids)
+    for i in range(len(dataset)):
+        current_id = dataset.sound_files[i][0:7]
+        closest = speaker_model_ids[int(np.argmax(scores[i]))]
+        print('correct speaker {} , the speaker was closer to {}'.format(current_id, closest))
+        correct += int(current_id == closest)
+        labels[i][np.where(current_id == ids)] = 1                   # an id that was never enrolled: all zeros
+    eer, auc = get_and_plot_k_eer_auc(labels.flatten(), scores.flatten(), k=k, plot_path=plot_path)
+    accuracy = correct * 100 / len(dataset)
+    print(f'Accuracy: {accuracy}%')
+    return {"eer": eer, "auc": auc, "accuracy": accuracy, "scores": scores, "labels": labels,
+            "speaker_ids": speaker_model_ids, "test_ids": [f[0:7] for f in dataset.sound_files]}
+
+
+def evaluate(model=None, cubes=None, test_ids=None, speaker_models=None, k=1, plot_path='eer_auc.png'):
+    """`evaluate()` -- no arguments, like evaluation.py:90-146: read the checkpoint, the id list, the WAVs and
+    the enrolled `{id}.pt` models from the paths in `constants`, score every utterance against every
+    enrolled speaker (one batched front end + network + ONE cosine launch instead of the reference's
+    per-utterance, per-speaker loop), print the reference's lines, save the ROC plot.
+    `evaluate(model, cubes, test_ids, speaker_models)` is the same loop on in-memory data.
+    Returns a dict (the reference returns None): eer, auc, accuracy, scores, labels."""
+    if model is None and cubes is None:
+        return _evaluate_files(k, plot_path)
     ev = Evaluation(model, speaker_models)
     speaker_ids = list(ev.speaker_models.keys())
     scores = ev.score_all(cubes).to("cpu").numpy().astype(np.float64)

@@ -18,9 +18,9 @@ from .speechpy import feature as speech
 from .utils import ToTensor
 
 
-def load_wav(path, sample_rate=c.SAMPLE_RATE):
+def load_wav(filename, sample_rate=c.SAMPLE_RATE):
     """float32 mono signal in [-1, 1) at `sample_rate` of a 16-bit PCM WAV (utils.py:170-173)."""
-    return load_audio(path, sample_rate)
+    return load_audio(filename, sample_rate)
 
 
 class AudioDataset(object):
@@ -43,13 +43,16 @@ class AudioDataset(object):
                 kept.append(str(rel))
             except OSError as err:
                 print("OS error: {0}".format(err))
-        self.sound_files = kept
+        self.sound_files = kept if c.NUM_FILES == 0 else kept[:c.NUM_FILES]      # load_data.py:42-45
 
     def __len__(self):
         return len(self.sound_files)
 
+    def load_signal(self, idx):
+        return load_wav(os.path.join(self.audio_dir, self.sound_files[idx]))
+
     def __getitem__(self, idx):
-        signal = load_wav(os.path.join(self.audio_dir, self.sound_files[idx]))
+        signal = self.load_signal(idx)
         logenergy = speech.lmfe(signal, sampling_frequency=c.SAMPLE_RATE, frame_length=c.FRAME_LEN,
                                 frame_stride=c.FRAME_STEP, num_filters=c.NUM_COEF, fft_length=c.NUM_FFT)
         sample = {'feature': logenergy, 'label': self.indexed[self.sound_files[idx][0:7]]}   # load_data.py:73

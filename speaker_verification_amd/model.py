@@ -217,6 +217,8 @@ class FusedEmbedder:
                 n_, c2, d_, hp_, w_ = x.shape
                 xv = x.as_strided((n_, c2 // 2, d_, hp_, 2 * w_), (x.stride(0), 1, x.stride(2), x.stride(3), c2 // 2))
                 y = F.prelu(F.conv3d(xv, w, b, dilation=(1, 1, 2)), slope)
+                # the view below re-reads y's memory as NDHWC; a convolution solver may hand back NCDHW
+                y = y.contiguous(memory_format=torch.channels_last_3d)
                 co = y.shape[1]
                 x = y.as_strided((n_, 2 * co, y.shape[2], hp_, y.shape[4] // 2),
                                  (y.stride(0), 1, y.stride(2), y.stride(3), 2 * co))
@@ -301,14 +303,42 @@ def perturb_inference_state(state_dict, seed):
     return state_dict
 
 
-def create_speaker_models(model, cubes, speaker_ids, save_dir=None, batch=256):
-    """Enrolment as `/root/reference/model.py:351-388` does it, on in-memory data (the
-    reference's checkpoint, id lists and WAVs do not ship): every utterance cube is embedded
+def _create_speaker_models_files():
+    """model.py:351-388 as written: checkpoint, enrolment list, id table and WAV tree under
+    `constants.ROOT` / `constants.DATA_ORIGIN`; one `{speaker_id}.pt` (a (1, 128) tensor) per
+    speaker under ROOT/speaker_models, the LAST listed utterance winning (Q17)."""
+    import os
+    from . import constants as c
+    from .evaluation import dataset_embeddings, load_indexed_labels
+    from .utils import create_dataset
+    model_path = os.path.join(c.ROOT, 'Models/model_14_percent_best_so_far.pt')
+    save_speaker_models_path = os.path.join(c.ROOT, 'speaker_models')
+    enrollment_set = os.path.join(c.ROOT, '50_first_ids.txt')
+    indexed_labels = load_indexed_labels(c.ROOT + '/50_first_ids.npy')
+    dataset = create_dataset(indexed_labels=indexed_labels, origin_file_path=enrollment_set)
+    if not os.path.exists(save_speaker_models_path):
+        os.mkdir(save_speaker_models_path)
+    model = C3D2(100, 1).load_checkpoint(torch.load(model_path, map_location="cpu", weights_only=True))
+    emb = dataset_embeddings(dataset, model).cpu()
+    store = {}
+    for i in range(len(dataset)):
+        store[dataset.sound_files[i][0:7]] = emb[i:i + 1].clone()
+    for sid, vec in store.items():
+        torch.save(vec, '{}/{}.pt'.format(save_speaker_models_path, sid))
+    return store
+
+
+def create_speaker_models(model=None, cubes=None, speaker_ids=None, save_dir=None, batch=256):
+    """Enrolment as `/root/reference/model.py:351-388` does it.  With no arguments: file-driven, the
+    paths of `constants` (see `_create_speaker_models_files`).  With `(model, cubes, speaker_ids)`: the
+    same on in-memory cubes.  Every utterance cube is embedded
     with `development=False`; the speaker model is the embedding of that speaker's LAST listed
     utterance -- the reference overwrites `{speaker_id}.pt` on each utterance, no averaging
     (Q17).  Returns `{speaker_id: (1, 128) CPU tensor}` and, with `save_dir`, writes the
     reference's `{speaker_id}.pt` files (readable by `evaluation.Evaluation`)."""
     import os
+    if model is None and cubes is None:
+        return _create_speaker_models_files()
     device = next(model.parameters()).device
     model.eval()
     store = {}

@@ -19,19 +19,26 @@ from .engine import get_engine, spec_from_seconds
 class VerificationPipeline:
     def __init__(self, model, use_vad=True, vad_threshold=c.VAD_ENERGY_THRESHOLD, normalize=c.NORMALIZE,
                  fused_model=True, crop_seed=12345, micro_batch=1024, channels_last=True, preemph_cof=None,
-                 crop_rng="reference", miopen_find=True, overlap_front=False):
+                 crop_rng="reference", miopen_find=True, overlap_front=False, pcm_scale=1.0 / 32768.0):
         """crop_rng: "reference" draws crop starts on the host exactly like utils.py:372 (needs the
         per-clip frame counts on the host: one small D2H per micro-batch); "device" draws them
         in a kernel keyed by (crop_seed, global clip index) -- no host round trip.
         preemph_cof: fuse processing.preemphasis(clip, cof=...) in front of the log-mel stage.
+        pcm_scale: amplitude factor on the int16 PCM before the front end.  The reference's model path
+        reads audio with librosa (utils.py:170-173): float32 in [-1, 1) = int16 / 32768 -> lmfe
+        (load_data.py:50-70), and ships NORMALIZE = False, so a reference-format checkpoint expects
+        log-mel values of THAT scale (2 ln 32768 = 20.79 below those of raw int16 amplitudes).  The
+        default reproduces it (a power of two folded into the filterbank weights: exact); 1.0 gives
+        speechpy-on-raw-int16 values.
         overlap_front: build the cube of micro-batch k+1 (VAD, front end, CMVN, crops, gather) on a
         second HIP stream while the network runs on micro-batch k (device-drawn crops only)."""
         self.eng = get_engine()
-        if miopen_find:
-            # MIOpen's exhaustive find picks 1.7x faster f32 Conv3d kernels for these odd filter
-            # shapes than its immediate-mode heuristic (46.8 -> 27.5 ms per 1 024 cubes; with
-            # channels_last_3d 22.3 ms); it costs a few seconds on the first call per input shape.
-            torch.backends.cudnn.benchmark = True
+        # MIOpen's exhaustive find picks 1.7x faster f32 Conv3d kernels for these odd filter
+        # shapes than its immediate-mode heuristic (46.8 -> 27.5 ms per 1 024 cubes; with
+        # channels_last_3d 22.3 ms); it costs a few seconds on the first call per input shape.
+        # The switch is process-global in torch: it is set around this pipeline's own network
+        # calls only (`_find_mode`), not left on for the rest of the process.
+        self.miopen_find = bool(miopen_find)
         self.model = model.to(self.eng.device).eval()
         self.fused_model, self.channels_last = fused_model, channels_last
         self.refresh_model()
@@ -40,7 +47,8 @@ class VerificationPipeline:
         # model front end: lmfe(signal, 16000, 0.025, 0.01, 40, 1024)  (load_data.py:64-70, Q14)
         self.spec = spec_from_seconds(c.SAMPLE_RATE, c.FRAME_LEN, c.FRAME_STEP, c.NUM_FFT, c.NUM_COEF, c.NUM_COEF,
                                       _lib.OUT_LMFE, preemph=preemph_cof is not None,
-                                      preemph_cof=0.0 if preemph_cof is None else preemph_cof)
+                                      preemph_cof=0.0 if preemph_cof is None else preemph_cof,
+                                      input_scale=float(pcm_scale))
         assert crop_rng in ("reference", "device")
         self.crop_rng, self.crop_seed = crop_rng, int(crop_seed)
         self.bad_clips = torch.zeros((1,), dtype=torch.int32, device=self.eng.device)
@@ -106,8 +114,21 @@ class VerificationPipeline:
     def cubes(self, feat, crop_idx):
         return self.eng.cube_gather(feat, crop_idx, c.CUBE_FRAMES)
 
+    def _find_mode(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            saved = torch.backends.cudnn.benchmark
+            torch.backends.cudnn.benchmark = self.miopen_find or saved
+            try:
+                yield
+            finally:
+                torch.backends.cudnn.benchmark = saved
+        return scope()
+
     def embed_cubes(self, cubes):
-        with torch.no_grad():
+        with torch.no_grad(), self._find_mode():
             if self.embedder is not None:
                 return self.embedder(cubes)
             return self.model(cubes, development=False)
@@ -121,7 +142,9 @@ class VerificationPipeline:
             kd, kw, G = geo
             if G % 4 == 0 and (kw + G - 1) % 4 == 0 and feat.shape[2] % 4 == 0:
                 windows = self.eng.cube_windows(feat, crop_idx, c.CUBE_FRAMES, kd, kw, G)
-                return self.embedder.from_windows(windows, feat.shape[0], c.CUBE_CROPS, c.CUBE_FRAMES, feat.shape[2])
+                with self._find_mode():
+                    return self.embedder.from_windows(windows, feat.shape[0], c.CUBE_CROPS, c.CUBE_FRAMES,
+                                                      feat.shape[2])
         return self.embed_cubes(self.cubes(feat, crop_idx))
 
     # ---- whole path ---------------------------------------------------------------------
@@ -191,7 +214,8 @@ class VerificationPipeline:
             kind, data, n_rows, n_cols = cube
             data.record_stream(main)               # allocated on the side stream, consumed on the main one
             if kind == "windows":
-                emb[lo:hi] = self.embedder.from_windows(data, n_rows, c.CUBE_CROPS, c.CUBE_FRAMES, n_cols)
+                with self._find_mode():
+                    emb[lo:hi] = self.embedder.from_windows(data, n_rows, c.CUBE_CROPS, c.CUBE_FRAMES, n_cols)
             else:
                 emb[lo:hi] = self.embed_cubes(data)
         side.wait_stream(main)
@@ -268,11 +292,18 @@ class VerificationPipeline:
             self._staged = [torch.empty((size, L), dtype=torch.int16, device=dev) for _ in range(2)]
             from concurrent.futures import ThreadPoolExecutor
             self._copy_pool = ThreadPoolExecutor(max_workers=8)           # np.copyto releases the GIL
+            self._copy_stream = torch.cuda.Stream(device=dev)
         pinned, staged = self._pinned, self._staged
         copied = [torch.cuda.Event() for _ in range(2)]
         consumed = [torch.cuda.Event() for _ in range(2)]
-        copy_stream = torch.cuda.Stream(device=dev)
+        copy_stream = self._copy_stream
         main = torch.cuda.current_stream(dev)
+        # The pinned and staged buffers outlive the call.  A previous call may still have H2D copies
+        # queued that READ a pinned buffer (the host refills it below) and kernels on `main` that READ a
+        # staged buffer (the copy stream overwrites it): the host waits for the old copies, the copy
+        # stream for everything queued on `main`.
+        copy_stream.synchronize()
+        copy_stream.wait_stream(main)
         emb = torch.empty((n, 128), dtype=torch.float32, device=dev)
 
         def launch_copy(k):

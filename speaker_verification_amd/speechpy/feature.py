@@ -56,18 +56,11 @@ def _run_one(signal, sampling_frequency, frame_length, frame_stride, num_filters
     n_frames = spec.num_frames(sig.shape[0])
     if n_frames <= 0:
         return np.empty((0, spec.num_cols)), np.empty((0,))
-    eng = get_engine()
-    if fft_length in (512, 1024) and num_filters <= 64:
-        feat, _, energy = eng.features(sig[None, :], spec, max_frames=n_frames, want_energy=want_energy)
-        feat, energy = feat[0], (energy[0] if want_energy else None)
-    else:
-        # configurations the fused kernel does not cover (other fft lengths, > 64 filters) run the
-        # same stages as separate kernels: framing -> spectrum (direct DFT) -> mel / log / DCT
-        bank = filterbanks(num_filters, fft_length // 2 + 1, sampling_frequency, low_frequency,
-                           high_frequency or sampling_frequency / 2)
-        frames = eng.stack_frames(sig, spec.frame_len, spec.frame_stride, n_frames)
-        power = eng.spectrum(frames, fft_length, power=True)
-        feat, energy = eng.mel_features(power, bank, out_kind, num_cepstral, dc_elimination, want_energy)
+    # the fused kernel where it applies (fft_length 512 / 1024, <= 64 filters, bank within its bins);
+    # Engine.features falls through to the staged kernels (framing -> spectrum -> mel / log / DCT)
+    # for everything else, so every call the reference accepts computes (feature.py:77-99)
+    feat, _, energy = get_engine().features(sig[None, :], spec, max_frames=n_frames, want_energy=want_energy)
+    feat, energy = feat[0], (energy[0] if want_energy else None)
     out = feat.to("cpu").numpy().astype(np.float64)
     en = energy.to("cpu").numpy().astype(np.float64) if want_energy else None
     return out, en

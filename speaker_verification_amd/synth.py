@@ -155,3 +155,46 @@ def corpus_device(n_clips, device, first_clip=0, utts_per_speaker=123, n_samples
         x = gate * mod * voice + 500.0 * gate * breath + 60.0 * noise
         out[lo:hi] = x.round().clamp(-32768, 32767).to(torch.int16)
     return out, speakers
+
+
+# --------------------------------------------------------------------------------------
+# A small file tree in the layout the reference's file-driven entry points read
+# --------------------------------------------------------------------------------------
+def write_verification_tree(root, n_speakers=3, utts_per_speaker=3, n_samples=24000, model_seed=11, n_labels=100):
+    """Everything `evaluation.evaluate()` / `model.create_speaker_models()` look for
+    (/root/reference/evaluation.py:90-101, model.py:351-361), synthetic and seeded:
+        root/50_first_ids.txt                       one relative WAV path per line
+        root/50_first_ids.npy (+ .json)             {speaker id: class index}
+        root/Models/model_14_percent_best_so_far.pt {"state_dict": seeded C3D2 weights}
+        root/data/idNNNNN/rec/0000U.wav             16 kHz mono 16-bit `speaker_clip`s
+    Returns (data_dir, relative paths, state_dict)."""
+    import json
+    import os
+    import wave
+
+    import torch
+
+    from .model import perturb_inference_state, seeded_model
+    data = os.path.join(root, "data") + os.sep
+    rel = []
+    for s in range(n_speakers):
+        for u in range(utts_per_speaker):
+            path = "id%05d/rec/%05d.wav" % (10001 + s, u)
+            full = os.path.join(data, path)
+            os.makedirs(os.path.dirname(full), exist_ok=True)
+            with wave.open(full, "wb") as wf:
+                wf.setnchannels(1)
+                wf.setsampwidth(2)
+                wf.setframerate(SAMPLE_RATE)
+                wf.writeframes(speaker_clip(40 + s, u, n_samples).tobytes())
+            rel.append(path)
+    np.savetxt(os.path.join(root, "50_first_ids.txt"), np.array(rel), fmt="%s")
+    table = {"id%05d" % (10001 + s): s for s in range(n_speakers)}
+    np.save(os.path.join(root, "50_first_ids.npy"), table, allow_pickle=True)
+    with open(os.path.join(root, "50_first_ids.json"), "w") as fh:
+        json.dump(table, fh)
+    model = seeded_model(model_seed, n_labels=n_labels)
+    state = perturb_inference_state(model.state_dict(), model_seed + 1)
+    os.makedirs(os.path.join(root, "Models"), exist_ok=True)
+    torch.save({"state_dict": state}, os.path.join(root, "Models", "model_14_percent_best_so_far.pt"))
+    return data, rel, state

@@ -15,6 +15,26 @@ from .speechpy import feature as _feature, processing as _processing
 np.random.seed(12345)          # the reference seeds the global NumPy RNG at import (utils.py:15, Q15)
 
 
+class Compose(object):
+    """`torchvision.transforms.Compose` (absent here): call the transforms in order."""
+
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, sample):
+        for t in self.transforms:
+            sample = t(sample)
+        return sample
+
+
+def create_dataset(indexed_labels, origin_file_path):
+    """`AudioDataset` over the WAVs under `constants.DATA_ORIGIN` listed in `origin_file_path`, with the
+    transform chain CMVN -> FeatureCube((80, 40, 20)) -> ToTensor (utils.py:18-31)."""
+    from .load_data import AudioDataset
+    transform = Compose([CMVN(), FeatureCube((c.CUBE_FRAMES, c.NUM_COEF, c.CUBE_CROPS)), ToTensor()])
+    return AudioDataset(origin_file_path, c.DATA_ORIGIN, indexed_labels=indexed_labels, transform=transform)
+
+
 class ToTensor(object):
     """`(feature, label)` from a sample dict (utils.py:316-322)."""
 

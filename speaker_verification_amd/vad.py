@@ -77,6 +77,23 @@ class EnergyVad(object):
                                       frame_samples=n, ring_len=1)
         return bool(res["keep"][0, 0].item())
 
+    def speech_flags(self, frames, sample_rate):
+        """The decisions for ALL `frames` (equal-length `Frame`s, as `frame_generator` yields) with one
+        launch: a caller that walks frames the reference's way (vad.py:90, one `is_speech` per 30 ms
+        frame = one launch + one D2H each) should ask for them together."""
+        frames = list(frames)
+        if not frames:
+            return np.zeros((0,), dtype=bool)
+        n = len(frames[0].bytes) // 2
+        pcm = np.frombuffer(b"".join(f.bytes[:2 * n] for f in frames) + b"\0\0", dtype=np.int16)
+        # every frame is its own one-frame "clip" of n + 1 samples (the framer wants offset + n < len, Q12)
+        # in the offsets / lengths form of the C-ABI; with a ring of one frame, keep == the speech flag
+        count = len(frames)
+        res = get_engine().vad_energy(pcm, self.threshold, fs=sample_rate, compact=False, frame_samples=n,
+                                      ring_len=1, lengths=np.full((count,), n + 1, dtype=np.int32),
+                                      offsets=np.arange(count, dtype=np.int64) * n)
+        return res["keep"][:, 0].to("cpu").numpy().astype(bool)
+
 
 def vad_collector(sample_rate, frame_duration_ms, padding_duration_ms, vad, frames):
     """Yield the voiced segments (bytes) of `frames` (vad.py:60-129): a ring
@@ -99,8 +116,10 @@ def vad_collector(sample_rate, frame_duration_ms, padding_duration_ms, vad, fram
     num_padding_frames = int(padding_duration_ms / frame_duration_ms)
     ring = collections.deque(maxlen=num_padding_frames)
     triggered, voiced = False, []
-    for frame in frames:
-        is_speech = vad.is_speech(frame.bytes, sample_rate)
+    # a decision object that can answer for all frames at once (one launch) is asked once
+    flags = vad.speech_flags(frames, sample_rate) if hasattr(vad, "speech_flags") else None
+    for k, frame in enumerate(frames):
+        is_speech = bool(flags[k]) if flags is not None else vad.is_speech(frame.bytes, sample_rate)
         sys.stdout.write('1' if is_speech else '0')
         ring.append((frame, is_speech))
         if not triggered:

@@ -36,7 +36,9 @@ def test_header_and_binding_agree(lib):
 
 def test_version_and_pure_host_entry_points(lib):
     from speaker_verification_amd._lib import FrontendCfg
-    assert lib.svk_version() == 100
+    from speaker_verification_amd import _lib as binding
+    header = open(os.path.join(REPO, "include", "svk.h")).read()
+    assert lib.svk_version() == binding.VERSION == int(re.search(r"#define SVK_VERSION (\d+)", header).group(1))
     cfg = FrontendCfg(320, 160, 512, 40, 13, 2, 1, 0, 1, 0.98)
     assert lib.svk_frontend_num_frames(ctypes.byref(cfg), 48000) == 298       # Q3
     assert lib.svk_frontend_num_frames(ctypes.byref(cfg), 319) == 0

@@ -667,13 +667,19 @@ def test_load_wav_resamples_on_device(tmp_path):
 
 def test_error_paths(eng):
     """Unsupported configurations fail loudly with the library's message; nothing falls back."""
+    from speaker_verification_amd import _lib
     from speaker_verification_amd._lib import SvkError
+    from speaker_verification_amd.engine import spec_from_seconds
     from speaker_verification_amd.speechpy import feature, processing
     sig = synth.noise_clip(1, 4000)
-    with pytest.raises(SvkError, match="fft_length 512 or 1024"):
-        feature.features_batch(sig[None], 16000, fft_length=256)            # the batched entry point is the fused kernel
+    with pytest.raises(SvkError, match="fft_length 512 or 1024"):                # the fused kernel itself refuses ...
+        eng.plan(spec_from_seconds(16000, 0.02, 0.01, 256, 40, 13, _lib.OUT_MFCC))
     with pytest.raises(SvkError, match="filters"):
-        feature.features_batch(sig[None], 16000, num_filters=80)
+        eng.plan(spec_from_seconds(16000, 0.02, 0.01, 512, 80, 13, _lib.OUT_MFCC))
+    # ... and the entry points route such configurations to the staged kernels instead (feature.py:77-99 computes)
+    f, nf, _ = feature.features_batch(np.stack([sig, sig[::-1]]), 16000, fft_length=256)
+    assert f.shape == (2, 23, 13) and nf.tolist() == [23, 23]
+    np.testing.assert_allclose(f[1].cpu().numpy(), ref.mfcc(sig[::-1], 16000, fft_length=256), **FEAT_TOL)
     with pytest.raises(AssertionError):
         feature.mfcc(sig, 16000, high_frequency=9000)                     # feature.py:58
     with pytest.raises(AssertionError):
@@ -878,7 +884,8 @@ def test_pipeline_end_to_end_and_eer(eng):
     ref_emb = []
     for i in range(pcm.shape[0]):
         _, _, voiced = vad_ref.vad_energy(pcm[i], 16000, c.VAD_FRAME_MS, c.VAD_PADDING_MS, c.VAD_ENERGY_THRESHOLD)
-        feat = ref.lmfe(voiced, 16000, c.FRAME_LEN, c.FRAME_STEP, c.NUM_COEF, c.NUM_FFT)
+        # the pipeline reads int16 PCM the way librosa hands it to the reference's lmfe call: / 32768
+        feat = ref.lmfe(voiced / 32768.0, 16000, c.FRAME_LEN, c.FRAME_STEP, c.NUM_COEF, c.NUM_FFT)
         assert feat.shape[0] == nfr[i]
         ref_emb.append(model_ref.c3d2_embed(state, model_ref.feature_cube(feat, crops[i])[None]).numpy()[0])
     ref_emb = np.stack(ref_emb)
@@ -896,11 +903,15 @@ def test_pipeline_end_to_end_and_eer(eng):
     eer_ref, auc_ref, _, _ = scoring_ref.get_eer_auc(labels.flatten(), ref_scores.astype(np.float64).flatten())
     assert eer_gpu == pytest.approx(eer_ref, abs=1e-4)                          # EER parity
     assert auc_gpu == pytest.approx(auc_ref, abs=1e-4)
-    # host-fed path (pinned double buffer + copy stream) == resident path, bit for bit
+    # host-fed path (pinned double buffer + copy stream) == resident path, bit for bit -- also when called
+    # twice back to back with no synchronisation in between (the buffers are reused across calls)
     pipe_dev = VerificationPipeline(pipe.model, use_vad=True, micro_batch=7, crop_rng="device")
     a = pipe_dev.embed(pcm)
     b = pipe_dev.embed_host(pcm)
-    assert torch.equal(a, b)
+    b2 = pipe_dev.embed_host(pcm[::-1].copy())
+    b3 = pipe_dev.embed_host(pcm)
+    assert torch.equal(a, b) and torch.equal(a, b3)
+    assert torch.equal(b2, pipe_dev.embed(pcm[::-1].copy()))
     # device-side crop draw: in range, reproducible, keyed by the global clip index
     nf_dev = eng.to_device(nfr.astype(np.int32))
     d1 = eng.draw_crops(nf_dev, 20, 80, seed=7, first_utt=100).cpu().numpy()
@@ -912,3 +923,155 @@ def test_pipeline_end_to_end_and_eer(eng):
     assert (short[0] == -1).all() and (short[2] == -1).all() and (short[1] >= 0).all() and int(bad.item()) == 2
     z = eng.cube_gather(eng.to_device(np.ones((3, 300, 40), dtype=np.float32)), short).cpu().numpy()
     assert not z[0].any() and not z[2].any() and (z[1] == 1).all()
+
+
+# ---- round 2 ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fs", [8000, 32000, 44100])
+def test_nfft1024_other_sampling_rates(sp, eng, golden, fs):
+    """fft_length 1024 away from 16 kHz: SpeechPy's bank then ends on bin 256 = nfft/4 (feature.py:77-99),
+    one bin past what the fused kernel kept in round 1 (it raised).  Against the reference's own outputs,
+    through the fused kernel (5th untangling step) and, forced, through the staged kernels."""
+    from speaker_verification_amd import _lib
+    from speaker_verification_amd.engine import spec_from_seconds
+    g = golden["round2"]
+    sig = synth.speaker_clip(9, fs // 1000, fs // 2, fs)
+    np.testing.assert_allclose(sp.feature.lmfe(sig, fs, 0.025, 0.01, 40, 1024), g[f"lmfe_1024_fs{fs}"], **FEAT_TOL)
+    np.testing.assert_allclose(sp.feature.mfcc(sig, fs, fft_length=1024), g[f"mfcc_1024_fs{fs}"], **FEAT_TOL)
+    f, e = sp.feature.mfe((sig / 32768.0).astype(np.float32), fs, fft_length=1024, num_filters=26)
+    np.testing.assert_allclose(f, g[f"mfe_1024_fs{fs}_feat"], rtol=2e-4, atol=1e-12)
+    np.testing.assert_allclose(e, g[f"mfe_1024_fs{fs}_energy"], rtol=2e-4, atol=1e-12)
+    spec = spec_from_seconds(fs, 0.025, 0.01, 1024, 40, 40, _lib.OUT_LMFE)
+    eng.plan(spec)                                                      # the fused kernel takes it (no SvkError)
+    staged, nf, _ = eng._features_staged(sig[None], spec, None, None, None, None, False)
+    np.testing.assert_allclose(staged[0, :int(nf[0])].cpu().numpy(), g[f"lmfe_1024_fs{fs}"], **FEAT_TOL)
+    # batched + ragged + fused pre-emphasis at that rate
+    clips = np.stack([sig, synth.speaker_clip(3, 2, fs // 2, fs)])
+    lens = np.array([sig.size, sig.size - 777], dtype=np.int32)
+    feat, nfr, _ = sp.feature.features_batch(clips, fs, "lmfe", 0.025, 0.01, num_filters=40, fft_length=1024,
+                                             preemphasis_cof=0.97, lengths=lens)
+    for i in range(2):
+        want = ref.lmfe(ref.preemphasis(clips[i, :lens[i]], cof=0.97), fs, 0.025, 0.01, 40, 1024)
+        assert int(nfr[i]) == want.shape[0]
+        np.testing.assert_allclose(feat[i, :want.shape[0]].cpu().numpy(), want, **FEAT_TOL)
+
+
+def test_pipeline_reads_int16_like_librosa(eng):
+    """the reference's model path feeds lmfe the float signal librosa returns (int16 / 32768,
+    utils.py:170-173, load_data.py:50-70) with NORMALIZE = False; the pipeline's int16 front end must give
+    THOSE log-mel values (2 ln 32768 below raw-int16 ones), with and without the fused pre-emphasis."""
+    from speaker_verification_amd.model import seeded_model
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    pcm, _ = synth.corpus(2, 2)
+    for cof in (0.97, None):
+        pipe = VerificationPipeline(seeded_model(3, n_labels=4), use_vad=False, normalize=False, preemph_cof=cof)
+        feat, nf = pipe.features(eng.to_device(pcm))
+        for i in range(pcm.shape[0]):
+            sig = pcm[i] / 32768.0
+            sig = ref.preemphasis(sig, cof=cof) if cof is not None else sig
+            want = ref.lmfe(sig, 16000, c.FRAME_LEN, c.FRAME_STEP, c.NUM_COEF, c.NUM_FFT)
+            np.testing.assert_allclose(feat[i, :int(nf[i])].cpu().numpy(), want, **FEAT_TOL)
+    raw = VerificationPipeline(seeded_model(3, n_labels=4), use_vad=False, normalize=False, pcm_scale=1.0)
+    feat_raw, _ = raw.features(eng.to_device(pcm))
+    np.testing.assert_allclose((feat_raw - feat).cpu().numpy()[:, :200], 2 * np.log(32768.0), atol=1e-4)
+    # MFCC with c0 := log(frame energy): the energy path carries the scale too
+    from speaker_verification_amd import _lib
+    from speaker_verification_amd.engine import spec_from_seconds
+    spec = spec_from_seconds(16000, 0.020, 0.01, 512, 40, 13, _lib.OUT_MFCC, input_scale=1.0 / 32768.0)
+    m, _, en = eng.features(pcm[:1], spec, want_energy=True)
+    np.testing.assert_allclose(m[0].cpu().numpy(), ref.mfcc(pcm[0] / 32768.0, 16000), **FEAT_TOL)
+    np.testing.assert_allclose(en[0].cpu().numpy(), ref.mfe(pcm[0] / 32768.0, 16000)[1], rtol=1e-4)
+
+
+def test_vad_rings_longer_than_64_frames(eng, golden):
+    """10 ms frames with 1 s of padding = a ring of 100 frames (vad.py:81): keep / segment masks equal the
+    reference's own collector (golden) and the packed samples equal the oracle's, bit for bit."""
+    from speaker_verification_amd import vad
+    g = golden["round2"]
+    thr = int(g["vad_threshold"][0])
+    clips = {"spk_0_0": synth.speaker_clip(0, 0), "spk_5_0_long": synth.speaker_clip(5, 0, 112000),
+             "noise_loud": synth.noise_clip(3, 48000, 3000.0), "spk_3_1": synth.speaker_clip(3, 1, 80000),
+             "pattern10": g["vad_pattern10_pcm"]}
+    for name, pcm in clips.items():
+        for frame_ms, pad_ms in ((10, 1000), (10, 700), (20, 1500)):
+            res = eng.vad_energy(pcm[None], thr, frame_ms=frame_ms, padding_ms=pad_ms, want_segments=True)
+            want_keep, want_seg = g[f"vad_{name}_{frame_ms}_{pad_ms}_keep"], g[f"vad_{name}_{frame_ms}_{pad_ms}_seg"]
+            n = want_keep.size
+            assert int(res["n_vad_frames"][0]) == n
+            np.testing.assert_array_equal(res["keep"][0, :n].cpu().numpy().astype(bool), want_keep)
+            np.testing.assert_array_equal(res["seg"][0, :n].cpu().numpy(), want_seg)
+            _, _, voiced = vad_ref.vad_energy(pcm, 16000, frame_ms, pad_ms, thr)
+            assert int(res["voiced_len"][0]) == voiced.size
+            np.testing.assert_array_equal(res["voiced"][0, :voiced.size].cpu().numpy(), voiced)
+    # the drop-in collector with those durations, and the all-frames-at-once decision call
+    pcm = clips["pattern10"]
+    frames = list(vad.frame_generator(10, pcm.tobytes(), 16000))
+    ev = vad.EnergyVad(thr)
+    flags = ev.speech_flags(frames, 16000)
+    np.testing.assert_array_equal(flags, vad_ref.frame_flags(pcm, 10, 16000, thr))
+    assert ev.is_speech(frames[40].bytes, 16000) == bool(flags[40]) and ev.is_speech(frames[5].bytes, 16000) == bool(flags[5])
+    segs = list(vad.vad_collector(16000, 10, 1000, ev, frames))
+    keep = g["vad_pattern10_10_1000_keep"]
+    assert b"".join(segs) == b"".join(f.bytes for i, f in enumerate(frames) if keep[i])
+
+    class Opaque:                                   # any object with is_speech: the host-side protocol loop
+        def is_speech(self, b, sr):
+            return vad_ref.energy_is_speech(np.frombuffer(b, dtype=np.int16), thr)
+
+    class Batched(Opaque):                          # ... which asks for all decisions at once when it can
+        calls = 0
+
+        def speech_flags(self, frs, sr):
+            Batched.calls += 1
+            return ev.speech_flags(frs, sr)
+
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert b"".join(vad.vad_collector(16000, 10, 1000, Opaque(), frames)) == b"".join(segs)
+        assert b"".join(vad.vad_collector(16000, 10, 1000, Batched(), frames)) == b"".join(segs)
+    assert Batched.calls == 1
+
+
+def test_file_driven_enrol_and_evaluate(eng, golden, tmp_path, monkeypatch, capsys):
+    """`create_speaker_models()` and `evaluate()` with NO arguments (model.py:351-388, evaluation.py:90-146):
+    checkpoint, id list, id table, WAV tree and `{id}.pt` store under constants.ROOT / DATA_ORIGIN, row by
+    row against what the reference's own functions produced on the same tree (golden `eval_*`)."""
+    from speaker_verification_amd import constants, evaluation, model as model_mod
+    g = golden["round2"]
+    root = str(tmp_path)
+    data_dir, rel, state = synth.write_verification_tree(root)
+    monkeypatch.setattr(constants, "ROOT", root)
+    monkeypatch.setattr(constants, "DATA_ORIGIN", data_dir)
+    monkeypatch.chdir(tmp_path)                                        # eer_auc.png lands in the CWD, as there
+    np.random.seed(int(g["eval_seeds"][0]))
+    store = model_mod.create_speaker_models()
+    order = [str(s) for s in g["eval_speaker_order"]]
+    assert sorted(store) == sorted(order)
+    assert sorted(os.listdir(os.path.join(root, "speaker_models"))) == sorted(s + ".pt" for s in order)
+    got_enrolled = np.concatenate([store[s].numpy() for s in order])
+    scale = np.abs(g["eval_enrolled"]).max()
+    np.testing.assert_allclose(got_enrolled, g["eval_enrolled"], rtol=0, atol=2e-4 * scale)
+    np.random.seed(int(g["eval_seeds"][1]))
+    res = evaluation.evaluate()
+    cols = [res["speaker_ids"].index(s) for s in order]                # the reference's os.listdir order
+    np.testing.assert_allclose(res["scores"][:, cols], g["eval_scores"], rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(res["labels"][:, cols], g["eval_labels"])
+    out = capsys.readouterr().out
+    assert out.count("correct speaker") == len(rel) and "EER=" in out and "AUC=" in out and "Accuracy:" in out
+    assert os.path.exists(tmp_path / "eer_auc.png")
+    # EER / AUC / accuracy: the reference's numbers unless two scores of a row sit within the tolerance
+    gap = np.sort(g["eval_scores"], axis=1)
+    if (gap[:, -1] - gap[:, -2]).min() > 2e-4:
+        assert res["accuracy"] == pytest.approx(float(g["eval_accuracy_pct"][0]))
+    assert res["eer"] * 100 == pytest.approx(float(g["eval_eer_pct"][0]), abs=12.0)
+    eer_o, auc_o = scoring_ref.k_fold_eer_auc(res["labels"].flatten(), res["scores"].flatten())
+    assert res["eer"] == pytest.approx(eer_o, abs=1e-9) and res["auc"] == pytest.approx(auc_o, abs=1e-9)
+    # the oracle chain, item by item, on the same tree and seeds
+    from oracle import evaluation_ref
+    np.random.seed(int(g["eval_seeds"][1]))
+    o_scores, o_labels, _, _, _ = evaluation_ref.evaluate(data_dir, rel, state, {s: store[s].numpy() for s in order}, order)
+    np.testing.assert_allclose(res["scores"][:, cols], o_scores, rtol=0, atol=1e-4)
+    # load_wav keeps the reference's keyword (utils.py:170)
+    from speaker_verification_amd import load_data
+    sig = load_data.load_wav(filename=os.path.join(data_dir, rel[0]), sample_rate=16000)
+    np.testing.assert_array_equal(sig, evaluation_ref.load_wav(os.path.join(data_dir, rel[0])))

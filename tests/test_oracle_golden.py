@@ -244,3 +244,51 @@ def test_ingest_resampler_against_scipy():
     stereo = np.array([[100, 300], [-32768, 32767], [7, 8]], dtype=np.int16)
     np.testing.assert_allclose(ingest_ref.to_mono(stereo), np.array([200.0, -0.5, 7.5]) / 32768.0)
     assert ingest_ref.to_int16([0.5, -1.5, 1.0, 1.5 / 32768, 2.5 / 32768]).tolist() == [16384, -32768, 32767, 2, 2]
+
+
+# ---- round 2: nfft 1024 away from 16 kHz, long VAD rings, the file-driven entry points --------------
+@pytest.mark.parametrize("fs", [8000, 32000, 44100])
+def test_nfft1024_other_rates(golden, fs):
+    g = golden["round2"]
+    sig = synth.speaker_clip(9, fs // 1000, fs // 2, fs)
+    bank = sp.filterbanks(40, 513, fs, 0, fs / 2)
+    assert np.nonzero(bank.any(axis=0))[0].max() == 256          # the bank ends on bin nfft/4 (Q2)
+    np.testing.assert_allclose(sp.lmfe(sig, fs, 0.025, 0.01, 40, 1024), g[f"lmfe_1024_fs{fs}"], **TIGHT)
+    np.testing.assert_allclose(sp.mfcc(sig, fs, fft_length=1024), g[f"mfcc_1024_fs{fs}"], rtol=1e-10, atol=1e-10)
+    f, e = sp.mfe((sig / 32768.0).astype(np.float32), fs, fft_length=1024, num_filters=26)
+    np.testing.assert_allclose(f, g[f"mfe_1024_fs{fs}_feat"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(e, g[f"mfe_1024_fs{fs}_energy"], rtol=1e-10, atol=1e-300)
+
+
+def _round2_vad_clips(g):
+    return {"spk_0_0": synth.speaker_clip(0, 0), "spk_5_0_long": synth.speaker_clip(5, 0, 112000),
+            "noise_loud": synth.noise_clip(3, 48000, 3000.0), "spk_3_1": synth.speaker_clip(3, 1, 80000),
+            "pattern10": g["vad_pattern10_pcm"]}
+
+
+def test_vad_long_rings(golden):
+    """10 ms frames with 1 s of padding = a ring of 100 frames (vad.py:81), against the reference's collector."""
+    g = golden["round2"]
+    thr = int(g["vad_threshold"][0])
+    for name, pcm in _round2_vad_clips(g).items():
+        for frame_ms, pad_ms in ((10, 1000), (10, 700), (20, 1500)):
+            keep, seg, _ = vad_ref.vad_energy(pcm, 16000, frame_ms, pad_ms, thr)
+            np.testing.assert_array_equal(keep, g[f"vad_{name}_{frame_ms}_{pad_ms}_keep"])
+            np.testing.assert_array_equal(seg, g[f"vad_{name}_{frame_ms}_{pad_ms}_seg"])
+
+
+def test_file_driven_enrol_and_evaluate(golden, tmp_path):
+    from oracle import evaluation_ref
+    g = golden["round2"]
+    data_dir, rel, state = synth.write_verification_tree(str(tmp_path))
+    order = [str(s) for s in g["eval_speaker_order"]]
+    np.random.seed(int(g["eval_seeds"][0]))
+    store = evaluation_ref.create_speaker_models(data_dir, rel, state)
+    np.testing.assert_allclose(np.concatenate([store[s] for s in order]), g["eval_enrolled"], rtol=0, atol=2e-6)
+    np.random.seed(int(g["eval_seeds"][1]))
+    scores, labels, acc, eer, auc = evaluation_ref.evaluate(data_dir, rel, state, store, order)
+    np.testing.assert_allclose(scores, g["eval_scores"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(labels, g["eval_labels"])
+    assert acc == pytest.approx(float(g["eval_accuracy_pct"][0]))
+    assert eer * 100 == pytest.approx(float(g["eval_eer_pct"][0]), abs=1e-6)
+    assert auc * 100 == pytest.approx(float(g["eval_auc_pct"][0]), abs=1e-6)

@@ -316,13 +316,147 @@ def scoring_fixture(ref_eval, ref_siamese):
     print("scoring.npz", sum(v.nbytes for v in g.values()) // 1024, "KiB raw")
 
 
+def _collector_masks(ref_vad, pcm, frame_ms, padding_ms, thr):
+    """keep / segment masks of the REFERENCE's vad_collector (vad.py:60-129) for any frame / padding
+    duration, read off its own trace ('+(t)' start time of a segment, '-(t)' end time)."""
+    audio = pcm.tobytes()
+    frames = list(ref_vad.frame_generator(frame_ms, audio, 16000))
+    sink = io.StringIO()
+    real_stdout, sys.stdout = sys.stdout, sink
+    try:
+        segments = list(ref_vad.vad_collector(16000, frame_ms, padding_ms, _EnergyVad(thr), frames))
+    finally:
+        sys.stdout = real_stdout
+    dur = frame_ms / 1000.0
+    n = len(frames[0].bytes) // 2 if frames else 0
+    keep = np.zeros(len(frames), dtype=bool)
+    seg = np.full(len(frames), -1, dtype=np.int32)
+    marks = re.findall(r"([+-])\(([0-9.eE+-]+)\)", sink.getvalue())
+    for k in range(0, len(marks) - 1, 2):
+        assert marks[k][0] == "+" and marks[k + 1][0] == "-", marks
+        lo, hi = int(round(float(marks[k][1]) / dur)), int(round(float(marks[k + 1][1]) / dur))
+        keep[lo:hi] = True
+        seg[lo:hi] = k // 2
+    if len(marks) % 2:                      # a segment still open at the end: no '-(t)' is printed (vad.py:126-129)
+        assert marks[-1][0] == "+"
+        lo = int(round(float(marks[-1][1]) / dur))
+        keep[lo:] = True
+        seg[lo:] = len(marks) // 2
+    rebuilt = b"".join(fr.bytes for i, fr in enumerate(frames) if keep[i])
+    assert rebuilt == b"".join(segments), "trace parsing disagrees with the yielded segments"
+    assert [int((seg == k).sum()) * n for k in range(len(segments))] == [len(s) // 2 for s in segments]
+    return keep, seg
+
+
+class _Compose:
+    """what `torchvision.transforms.Compose` does (torchvision is absent here)"""
+
+    def __init__(self, transforms):
+        self.transforms = transforms
+
+    def __call__(self, sample):
+        for t in self.transforms:
+            sample = t(sample)
+        return sample
+
+
+def _wav_as_librosa(path, sample_rate=16000):
+    """What `librosa.load(path, sr=16000, mono=True)[0]` returns for a 16 kHz mono 16-bit WAV: the samples
+    as float32 / 32768, no resampling (librosa is absent here; files of this fixture are all of that kind)."""
+    import wave
+    with wave.open(path, "rb") as wf:
+        assert wf.getframerate() == sample_rate and wf.getnchannels() == 1 and wf.getsampwidth() == 2
+        pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16)
+    return pcm.astype(np.float32) / np.float32(32768.0)
+
+
+def round2_fixture(ref_vad, ref_eval, ref_model, ref_utils):
+    """Round-2 additions: nfft 1024 at other sampling rates (bank reaches bin 256), a VAD ring longer than
+    64 frames, and the reference's FILE-DRIVEN create_speaker_models() / evaluate() on a synthetic tree."""
+    import tempfile
+    g = {"versions": versions()}
+    # ---- fft_length 1024 away from 16 kHz (feature.py:77-99: the bank's last filter ends on bin 256) ----
+    for fs in (8000, 32000, 44100):
+        sig = synth.speaker_clip(9, fs // 1000, fs // 2, fs)          # 0.5 s at that rate
+        g[f"lmfe_1024_fs{fs}"] = rf.lmfe(sig, fs, 0.025, 0.01, 40, 1024)
+        g[f"mfcc_1024_fs{fs}"] = rf.mfcc(sig, fs, fft_length=1024)
+        f, e = rf.mfe((sig / 32768.0).astype(np.float32), fs, fft_length=1024, num_filters=26)
+        g[f"mfe_1024_fs{fs}_feat"], g[f"mfe_1024_fs{fs}_energy"] = f, e
+    # ---- 10 ms frames with 1 s of padding: a ring of 100 frames ----
+    thr = 250000
+    g["vad_threshold"] = np.array([thr])
+    pat = np.array([0] * 30 + [1] * 120 + [0] * 130 + [1] * 95 + [0] * 20 + [1] * 200 + [0] * 150 + [1] * 50 + [0] * 7,
+                   dtype=np.int64)
+    loud = np.repeat(pat, 160) * 4000
+    g["vad_pattern10_pcm"] = (loud * np.where(np.arange(loud.size) % 2, 1, -1)).astype(np.int16)
+    for name, pcm in (("spk_0_0", synth.speaker_clip(0, 0)), ("spk_5_0_long", synth.speaker_clip(5, 0, 112000)),
+                      ("noise_loud", synth.noise_clip(3, 48000, 3000.0)), ("spk_3_1", synth.speaker_clip(3, 1, 80000)),
+                      ("pattern10", g["vad_pattern10_pcm"])):
+        for frame_ms, pad_ms in ((10, 1000), (10, 700), (20, 1500)):
+            keep, seg = _collector_masks(ref_vad, pcm, frame_ms, pad_ms, thr)
+            g[f"vad_{name}_{frame_ms}_{pad_ms}_keep"] = keep
+            g[f"vad_{name}_{frame_ms}_{pad_ms}_seg"] = seg
+    # ---- file-driven enrolment + evaluation (model.py:351-388, evaluation.py:90-146) ----
+    import constants as ref_c
+    import load_data as ref_load_data
+    with tempfile.TemporaryDirectory() as root:
+        data_dir, rel, state = synth.write_verification_tree(root)
+        ref_c.ROOT, ref_c.DATA_ORIGIN = root, data_dir
+        ref_load_data.load_wav = _wav_as_librosa                         # librosa.load stand-in, see its docstring
+        ref_utils.transforms = types.SimpleNamespace(Compose=_Compose)   # torchvision stand-in
+        captured = {}
+        real_plot = ref_eval.get_and_plot_k_eer_auc
+
+        def spy(label, scores, k=1):
+            captured["labels"], captured["scores"] = np.array(label), np.array(scores)
+            return real_plot(label, scores, k)
+
+        cwd = os.getcwd()
+        sink = io.StringIO()
+        real_stdout, sys.stdout = sys.stdout, sink
+        try:
+            os.chdir(root)                                               # evaluate() saves eer_auc.png in the CWD
+            np.random.seed(4242)
+            ref_model.create_speaker_models()
+            order = [f.replace(".pt", "") for f in os.listdir(os.path.join(root, "speaker_models"))]
+            enrolled = np.concatenate([torch.load(os.path.join(root, "speaker_models", sid + ".pt")).detach().numpy()
+                                       for sid in order])
+            np.random.seed(4343)
+            ref_eval.get_and_plot_k_eer_auc = spy
+            ref_eval.evaluate()
+        finally:
+            ref_eval.get_and_plot_k_eer_auc = real_plot
+            sys.stdout = real_stdout
+            os.chdir(cwd)
+        out = sink.getvalue()
+        g["eval_speaker_order"] = np.array(order)
+        g["eval_enrolled"] = enrolled
+        n_spk = len(order)
+        g["eval_scores"] = captured["scores"].reshape(-1, n_spk)
+        g["eval_labels"] = captured["labels"].reshape(-1, n_spk)
+        g["eval_eer_pct"] = np.array([float(re.search(r"EER= ([0-9.eE+-]+)", out).group(1))])
+        g["eval_auc_pct"] = np.array([float(re.search(r"AUC= ([0-9.eE+-]+)", out).group(1))])
+        g["eval_accuracy_pct"] = np.array([float(re.search(r"Accuracy: ([0-9.eE+-]+)%", out).group(1))])
+        g["eval_closest"] = np.array(re.findall(r"the speaker was closer to (\S+)", out))
+        g["eval_seeds"] = np.array([4242, 4343])
+    np.savez_compressed(os.path.join(OUT, "round2.npz"), **g)
+    print("round2.npz", sum(v.nbytes for v in g.values()) // 1024, "KiB raw")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    speechpy_fixture()
+    only = sys.argv[1:]                      # e.g. `python tools/make_golden.py round2`
     ref_eval, ref_siamese, ref_utils, ref_vad, ref_model = _import_reference_app_modules()
-    vad_fixture(ref_vad)
-    model_fixture(ref_model, ref_utils)
-    scoring_fixture(ref_eval, ref_siamese)
+    if not only or "speechpy" in only:
+        speechpy_fixture()
+    if not only or "vad" in only:
+        vad_fixture(ref_vad)
+    if not only or "model" in only:
+        model_fixture(ref_model, ref_utils)
+    if not only or "scoring" in only:
+        scoring_fixture(ref_eval, ref_siamese)
+    if not only or "round2" in only:
+        round2_fixture(ref_vad, ref_eval, ref_model, ref_utils)
 
 
 if __name__ == "__main__":
