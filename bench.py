@@ -3,25 +3,35 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One STEP = one pass of the whole path over this rank's shard of synthetic clips:
-    int16 PCM (resident in HBM) -> energy VAD -> fused pre-emphasis + log-mel(40) front end -> CMVN
-    -> 20x80x40 cube -> C3D2 embedding (PyTorch-ROCm, f32) -> all-gather of the [clips,128] shards
-    (RCCL) -> 4 874 x 40 cosine score matrix (MFMA).
-Per-rank work is fixed (weak scaling): 18 581 clips = ceil(148 642 / 8), the per-GPU shard of
-BASELINE.json's 148 642-clip corpus.  value = clips processed by all ranks / max-over-ranks time.
+One STEP = one pass of the whole path over BASELINE.json's corpus, 148 642 synthetic 3 s / 16 kHz clips,
+sharded over the N ranks (rank r owns the contiguous range of ceil(148 642 / N) clips; STRONG scaling:
+the total is fixed), PCM resident in HBM:
+    int16 PCM -> energy VAD -> fused pre-emphasis + log-mel(40) front end -> CMVN -> 20x80x40 cube
+    -> C3D2 embedding (PyTorch-ROCm, f32) -> all-gather of the [clips,128] shards (RCCL)
+    -> 4 874 x 40 cosine score matrix (MFMA).
+value = 148 642 clips x steps / max-over-ranks time.
+
+Launch: with WORLD_SIZE in the environment (torch.distributed.run) this process is one rank; without it
+and --gpus N > 1 this process only starts N fresh rank processes of itself (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), relays rank 0's JSON line and exits with the worst code.
 
 The JSON line also carries
-  roofline      -- the fused front-end kernel (the dominant hand-written kernel): algorithmic
-                   HBM bytes / launch over its HIP-event duration inside the timed region;
-  frontend_A    -- BASELINE config 2 measured beside it: 1 024 clips, SpeechPy defaults
-                   (pre-emph + MFCC-13 + CMVN), utterances/s and roofline fraction;
-  cpu_baseline  -- the CPU oracle (NumPy/torch-CPU restatement of the reference, kind "port")
-                   timed on a bounded sample on rank 0, N = 1 only;
+  roofline      -- the fused front-end kernel (the dominant HAND-WRITTEN kernel): algorithmic HBM bytes
+                   of the launches it actually ran (VAD-shortened clips) over their HIP-event durations;
+  roofline_e2e  -- the whole step against the f32 matrix peak: value x 0.6766 GFLOP (the C3D2 forward is
+                   95 % of the step) / 157.3 TFLOP/s -- the ceiling SURVEY 8(d) names (232 k utt/s/GPU);
+  ranks_seen / backend / allgather_us -- what torch.distributed reports and the HIP-event time of the
+                   embedding all-gather;
+  frontend_A, cosine_mfma, stage_kernels, ingest_resample -- the other hand-written kernels on their own;
+  cpu_baseline  -- the CPU oracle (NumPy/torch-CPU restatement of the reference, kind "port") timed in a
+                   fresh child process on rank 0, N = 1 only: all host cores on the per-utterance chain
+                   (`value`), plus 1-core / all-core and batch-1 / batch-64 variants per stage;
   parity        -- GPU vs oracle on that sample + EER of the 4 874 x 40 score matrix.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,26 +42,109 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA peak
+C3D2_GFLOP_PER_UTT = 0.6766      # 338.3 M multiply-adds per cube
+N_CORPUS = 148642                # VoxCeleb1 dev utterances (README.md:5-7) = BASELINE configs[4]
 N_TEST, N_TEST_SPK = 4874, 40    # VoxCeleb1 verification split (README.md:4-7)
 UTTS_PER_SPK = 123
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips", type=int, default=18581, help="clips per rank and step")
+    ap.add_argument("--corpus", type=int, default=N_CORPUS, help="clips in the whole job (all ranks), per step")
     ap.add_argument("--micro-batch", type=int, default=1024)
-    ap.add_argument("--cpu-sample", type=int, default=48, help="clips of the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="clips of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--no-vad", action="store_true")
     ap.add_argument("--no-cmvn", action="store_true")
     ap.add_argument("--no-preemph", action="store_true")
     ap.add_argument("--no-channels-last", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel side benches (profiling runs)")
     ap.add_argument("--frontend-only", action="store_true", help="time BASELINE config 2 only (for rocprof)")
-    return ap.parse_args()
+    ap.add_argument("--stages-only", action="store_true", help="time the stage-level kernels only (for rocprof)")
+    ap.add_argument("--backend", default=os.environ.get("SVK_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="gloo: rehearse N ranks on ONE GPU (RCCL refuses two ranks on a device)")
+    ap.add_argument("--selftest", action="store_true",
+                    help="launcher / collective logic only, on CPU with gloo (tests/test_distributed_cpu.py)")
+    ap.add_argument("--cpu-child", default=None, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
 
+# --------------------------------------------------------------------------------------------------
+# launcher: python bench.py --gpus N  ->  N fresh rank processes (never a re-exec of this one)
+# --------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank(s) failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+class _stdout_to_stderr:
+    """RCCL and gloo print a banner on STDOUT when a communicator comes up; stdout is reserved for the one
+    JSON line, so fd 1 points at stderr while the process group is created."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
+def selftest_rank():
+    """--selftest: the distributed plumbing of a step without a GPU (gloo): shard bounds, padded
+    all-gather, max-over-ranks reduction, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    from speaker_verification_amd import distributed as svdist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        with _stdout_to_stderr():
+            dist.init_process_group("gloo")
+            dist.barrier()
+    n_total = 1003
+    lo, hi = svdist.shard_bounds(n_total, world, rank)
+    local = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 4)
+    full = svdist.all_gather_embeddings(local, n_total)
+    ok = bool(torch.equal(full[:, 0], torch.arange(n_total, dtype=torch.float32)))
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                          "backend": dist.get_backend() if world > 1 else None, "gathered_ok": ok,
+                          "max_over_ranks": float(t.item()), "n_gpus": world}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# --------------------------------------------------------------------------------------------------
+# side benches of the hand-written kernels
+# --------------------------------------------------------------------------------------------------
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
     (profiles/rNN_frontend_pmc.json, written by tools/summarize_prof.py from separate --pmc
@@ -66,6 +159,21 @@ def pmc_traffic(kernel):
     except (OSError, ValueError):
         return None, None
     return rec.get("hbm_traffic_bytes_per_launch"), os.path.basename(files[-1])
+
+
+def _median_ms(torch, fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts))
 
 
 def frontend_A_bench(eng, torch, reps=20, n_clips=1024):
@@ -107,16 +215,7 @@ def frontend_B_bench(eng, torch, reps=20, n_clips=1024):
     spec = spec_from_seconds(16000, 0.025, 0.01, 1024, 40, 40, _lib.OUT_LMFE, preemph=True, preemph_cof=0.98)
     base = np.stack([synth.noise_clip(s) for s in range(16)])
     pcm = eng.to_device(np.tile(base, (n_clips // 16, 1)))
-    for _ in range(3):
-        eng.features(pcm, spec)
-    torch.cuda.synchronize()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(reps)]
-    for a, b in ev:
-        a.record()
-        eng.features(pcm, spec)
-        b.record()
-    torch.cuda.synchronize()
-    t = float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e-3
+    t = _median_ms(torch, lambda: eng.features(pcm, spec), reps) * 1e-3
     bytes_per_utt = 48000 * 2 + 297 * 40 * 4
     gbs = n_clips * bytes_per_utt / t / 1e9
     traffic, src = pmc_traffic("frontend_kernel<int16,nfft1024>")
@@ -126,6 +225,52 @@ def frontend_B_bench(eng, torch, reps=20, n_clips=1024):
                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                          "algorithmic_bytes_per_launch": n_clips * bytes_per_utt,
                          "kernel": "frontend_kernel<int16,nfft1024>", "bytes_per_utt": bytes_per_utt}}
+
+
+def stage_kernels_bench(eng, torch, reps=10):
+    """The stage-level kernels behind the individual speechpy.processing functions, each on
+    its own: HIP-event ms, algorithmic HBM bytes (reads + writes of the arrays the function is defined
+    on), GB/s and the fraction of the 8 TB/s roof."""
+    from speaker_verification_amd import _lib
+    from speaker_verification_amd.speechpy import feature as ffeat
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(5)
+    rows = {}
+
+    def add(name, fn, nbytes, note):
+        ms = _median_ms(torch, fn, reps)
+        gbs = nbytes / ms / 1e6
+        rows[name] = {"ms": ms, "algorithmic_bytes": int(nbytes), "GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "workload": note}
+
+    # cmvnw: 1 024 clips x 298 frames x 13 cepstra, window 301 (processing.py:274-327), with variance
+    x = torch.randn((1024, 298, 13), device=eng.device, generator=g)
+    add("cmvnw(win 301, variance)", lambda: eng.cmvnw(x, 301, True), 2 * 2 * x.numel() * 4,
+        "1024 x (298, 13) f32, two passes (mean, then std of the centred rows): each reads + writes the array")
+    xl = torch.randn((64, 6000, 40), device=eng.device, generator=g)
+    add("cmvnw(win 301) long", lambda: eng.cmvnw(xl, 301, False), 2 * xl.numel() * 4, "64 x (6000, 40) f32 (60 s clips)")
+    # spectrum: 32 768 frames
+    nfr = 32768
+    for nfft, flen in ((512, 320), (1024, 400), (256, 200), (2048, 400), (400, 400)):
+        fr = torch.randn((nfr, flen), device=eng.device, generator=g)
+        add("power_spectrum(nfft %d)" % nfft, lambda fr=fr, nfft=nfft: eng.spectrum(fr, nfft, True),
+            nfr * (flen + nfft // 2 + 1) * 4, "%d frames of %d samples -> %d bins" % (nfr, flen, nfft // 2 + 1))
+    # mel / log / DCT stage on a power spectrum
+    for bins, nf in ((1025, 80), (129, 40)):
+        p = torch.rand((nfr, bins), device=eng.device, generator=g) + 0.1
+        bank = eng.to_device(ffeat.filterbanks(nf, bins, 16000, 0, 8000), torch.float32)
+        add("mel_features(%d bins, %d filters, mfcc-13)" % (bins, nf),
+            lambda p=p, bank=bank: eng.mel_features(p, bank, _lib.OUT_MFCC, 13, True, False),
+            nfr * (bins + 13) * 4, "%d frames" % nfr)
+    sig = torch.randn((4800000,), device=eng.device, generator=g)
+    add("preemphasis", lambda: eng.preemphasis(sig), sig.numel() * 8, "4.8 M f32 samples")
+    add("stack_frames(400/160)", lambda: eng.stack_frames(sig, 400, 160, 29997), sig.numel() * 4 + 29997 * 400 * 4,
+        "4.8 M samples -> 29 997 frames")
+    feat = torch.randn((1024 * 298, 40), device=eng.device, generator=g)
+    add("derivative_extraction", lambda: eng.derivative(feat, 2), 2 * feat.numel() * 4, "305 152 x 40 f32")
+    pw = torch.rand((nfr, 257), device=eng.device, generator=g)
+    add("log_power_spectrum(normalize)", lambda: eng.log_power_(pw.clone(), True), 3 * pw.numel() * 4,
+        "32 768 x 257 f32: log pass (read + write) + subtract-max pass; timed with the clone (1 read + 1 write more)")
+    return rows
 
 
 def stage_breakdown(pipe, eng, torch, chunk, first_utt):
@@ -158,17 +303,8 @@ def stage_breakdown(pipe, eng, torch, chunk, first_utt):
     rows["cmvn"] = (t, 2 * frames * 40 * 4)
     t, idx = timed(lambda: eng.draw_crops(nf, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, first_utt, pipe.bad_clips))
     rows["draw_crops"] = (t, n * (4 + 80))
-    geo = pipe.embedder.first_layer_windows(c.CUBE_CROPS, 40) if pipe.embedder is not None else None
-    if geo is not None:
-        kd, kw, G = geo
-        t, win = timed(lambda: eng.cube_windows(feat, idx, c.CUBE_FRAMES, kd, kw, G))
-        rows["cube as first-layer patch matrix"] = (t, frames * 40 * 4 + float(win.numel()) * 4)
-        t, emb = timed(lambda: pipe.embedder.from_windows(win, n, c.CUBE_CROPS, c.CUBE_FRAMES, 40))
-    else:
-        t, cube = timed(lambda: pipe.cubes(feat, idx))
-        rows["cube_gather"] = (t, frames * 40 * 4 + n * 256000)
-        t, emb = timed(lambda: pipe.embed_cubes(cube))
-    rows["C3D2 forward (PyTorch-ROCm)"] = (t, None)
+    t, emb = timed(lambda: pipe.embed_features(feat, idx))
+    rows["cube + C3D2 forward"] = (t, None)
     t, _ = timed(lambda: pipe.score(emb, emb[:40]))
     rows["cosine %dx40" % n] = (t, (n + 40) * 128 * 4 + n * 40 * 4)
     total = sum(v[0] for v in rows.values())
@@ -185,21 +321,11 @@ def cosine_mfma_bench(eng, torch, reps=10):
     nt, ns, d = 148642, 1211, 128
     t = torch.randn(nt, d, device=eng.device)
     e = torch.randn(ns, d, device=eng.device)
-    for _ in range(3):
-        eng.cosine_scores(t, e)
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        eng.cosine_scores(t, e)
-        b.record()
-        torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b))
-    ms = float(np.median(ts))
+    ms = _median_ms(torch, lambda: eng.cosine_scores(t, e), reps)
     tf = 2.0 * nt * ns * d / ms / 1e9
     return {"workload": "%d x %d x %d cosine score matrix" % (nt, ns, d), "ms": ms,
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / F32_MATRIX_PEAK_TFLOPS,
                          "traffic": None, "kernel": "cosine_tiled_kernel<true> (v_mfma_f32_16x16x4_f32)",
                          "output_GBps": nt * ns * 4 / ms / 1e6}}
 
@@ -211,18 +337,7 @@ def ingest_bench(eng, torch, reps=10, n_clips=1024):
     pcm = (torch.randn(n_clips, 144000, device=eng.device) * 3000).to(torch.int16)
     up, down = ingest.rational_ratio(48000, 16000)
     taps = ingest.resample_taps(up, down)
-    for _ in range(3):
-        eng.resample(pcm, up, down, taps)
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        eng.resample(pcm, up, down, taps)
-        b.record()
-        torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b))
-    ms = float(np.median(ts))
+    ms = _median_ms(torch, lambda: eng.resample(pcm, up, down, taps), reps)
     gbs = n_clips * 480000 / ms / 1e6
     return {"workload": "%d x 3 s clips, 48 kHz mono int16 -> 16 kHz float32" % n_clips, "ms": ms,
             "utt_per_s": n_clips / ms * 1e3,
@@ -231,82 +346,201 @@ def ingest_bench(eng, torch, reps=10, n_clips=1024):
                          "bytes_per_utt": 480000}}
 
 
-def cpu_baseline(pcm_host, crop_idx, state, preemph, cmvn, use_vad, passes=3):
-    """The oracle (kind 'port') doing exactly the reference's per-utterance sequence on the host:
-    vad -> preemphasis -> lmfe -> cmvn -> cube -> C3D2 at batch 1 -> per-pair cosine.  The sample is
-    walked `passes` times (about 10 s of host work); the embeddings of the last pass are returned."""
+# --------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle ("port") in a fresh child process that never touches the GPU
+# --------------------------------------------------------------------------------------------------
+_CPU = {}
+
+
+def _cpu_init(sample_dir, flags):
     import torch
-    from oracle import model_ref, scoring_ref, speechpy_ref, vad_ref
+    torch.set_num_threads(1)
+    _CPU["pcm"] = np.load(os.path.join(sample_dir, "pcm.npy"), mmap_mode="r")
+    _CPU["crops"] = np.load(os.path.join(sample_dir, "crops.npy"))
+    _CPU["state"] = torch.load(os.path.join(sample_dir, "state.pt"), map_location="cpu", weights_only=True)
+    _CPU["flags"] = flags
+
+
+def _cpu_features(i):
+    """vad -> /32768 (what librosa hands lmfe) -> preemphasis -> lmfe -> cmvn of sample clip i (one core)."""
+    from oracle import speechpy_ref, vad_ref
     from speaker_verification_amd import constants as c
+    preemph, cmvn, use_vad = _CPU["flags"]
+    clip = np.asarray(_CPU["pcm"][i])
+    if use_vad:
+        _, _, clip = vad_ref.vad_energy(clip, c.SAMPLE_RATE, c.VAD_FRAME_MS, c.VAD_PADDING_MS, c.VAD_ENERGY_THRESHOLD)
+    sig = clip / 32768.0
+    sig = speechpy_ref.preemphasis(sig, cof=0.98) if preemph else sig
+    feat = speechpy_ref.lmfe(sig, c.SAMPLE_RATE, c.FRAME_LEN, c.FRAME_STEP, c.NUM_COEF, c.NUM_FFT)
+    return speechpy_ref.cmvn(feat, variance_normalization=True) if cmvn else feat
+
+
+def _cpu_chain(i):
+    """The reference's per-utterance sequence: features -> cube -> C3D2 at batch 1."""
+    from oracle import model_ref
+    cube = model_ref.feature_cube(_cpu_features(i), _CPU["crops"][i])[None]
+    return model_ref.c3d2_embed(_CPU["state"], cube).numpy()[0]
+
+
+def _cpu_count_frames(i):
+    return _cpu_features(i).shape[0]
+
+
+def cpu_child(sample_dir):
+    """Runs with OMP/MKL/OPENBLAS_NUM_THREADS=1 in the environment (set by the parent before this
+    interpreter started, i.e. before NumPy was imported).  Prints one JSON object."""
+    import multiprocessing as mp
+    import platform
+
+    import scipy
+    import torch
+    from oracle import model_ref, scoring_ref
+    meta = json.load(open(os.path.join(sample_dir, "meta.json")))
+    flags = (meta["preemph"], meta["cmvn"], meta["vad"])
+    _cpu_init(sample_dir, flags)
+    n = _CPU["pcm"].shape[0]
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    cpu_model = platform.processor() or ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    out = {"cores": cores, "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model,
+           "versions": {"python": platform.python_version(), "numpy": np.__version__, "scipy": scipy.__version__,
+                        "torch": torch.__version__}, "sample_clips": n, "stages": {}}
+
+    def rate(fn, count):
+        t0 = time.perf_counter()
+        res = fn()
+        return count / (time.perf_counter() - t0), res
+
+    # ---- front end (vad -> preemph -> lmfe -> cmvn): 1 core, then a process pool over utterances ----
+    n1 = min(n, 384)
+    r, _ = rate(lambda: [_cpu_features(i) for i in range(n1)], n1)
+    out["stages"]["frontend_1core"] = {"utt_per_s": r, "clips": n1, "cores": 1}
+    ctx = mp.get_context("fork")               # this process has never touched the GPU: fork is safe
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_count_frames, range(min(n, 2 * cores)), chunksize=1)            # warm the workers
+        r, _ = rate(lambda: pool.map(_cpu_count_frames, range(n), chunksize=max(1, n // (8 * cores))), n)
+        out["stages"]["frontend_allcores"] = {"utt_per_s": r, "clips": n, "cores": cores, "how": "multiprocessing.Pool"}
+        # ---- the whole per-utterance chain on all cores: one single-threaded worker per core, batch 1 ----
+        t0 = time.perf_counter()
+        embs = np.stack(pool.map(_cpu_chain, range(n), chunksize=max(1, n // (8 * cores))))
+        enroll = embs[::max(1, n // 40)][:40]
+        for i in range(n):                                                           # evaluation.py:73-77, pair by pair
+            scoring_ref.compute_similarity(embs[i], enroll)
+        dt = time.perf_counter() - t0
+    out["value"] = n / dt
+    out["seconds"] = dt
+    np.save(os.path.join(sample_dir, "cpu_emb.npy"), embs)
+    # ---- C3D2 alone: batch 1 (evaluation.py:113-121) and batch 64, 1 thread and all threads ----
+    cubes = np.stack([model_ref.feature_cube(_cpu_features(i), _CPU["crops"][i]) for i in range(64)])
+
+    def bounded(fn, per_call, budget=4.0, most=64):
+        """utt/s of repeated `fn()` calls: one untimed call, then as many as fit `budget` seconds (torch-CPU
+        with every hardware thread on a batch of one can take seconds per call)."""
+        fn()
+        t0 = time.perf_counter()
+        calls = 0
+        while calls < most and (calls == 0 or time.perf_counter() - t0 < budget):
+            fn()
+            calls += 1
+        return per_call * calls / (time.perf_counter() - t0), per_call * calls
+
+    for threads in (1, cores):
+        torch.set_num_threads(threads)
+        tag = "1thread" if threads == 1 else "allthreads"
+        k = [0]
+
+        def one():
+            k[0] += 1
+            return model_ref.c3d2_embed(_CPU["state"], cubes[k[0] % 64][None])
+        r, cnt = bounded(one, 1)
+        out["stages"]["c3d2_batch1_" + tag] = {"utt_per_s": r, "clips": cnt, "threads": threads}
+        r, cnt = bounded(lambda: model_ref.c3d2_embed(_CPU["state"], cubes), 64, most=8)
+        out["stages"]["c3d2_batch64_" + tag] = {"utt_per_s": r, "clips": cnt, "threads": threads}
+    print(json.dumps(out))
+    return 0
+
+
+def run_cpu_baseline(sample_pcm, crops, state, preemph, cmvn, use_vad):
+    """Write the sample, run `bench.py --cpu-child` in a fresh interpreter pinned to one BLAS/OpenMP thread
+    per process, read its JSON and the embeddings it computed."""
+    import tempfile
+
+    import torch
+    d = tempfile.mkdtemp(prefix="svk_cpu_")
+    np.save(os.path.join(d, "pcm.npy"), sample_pcm)
+    np.save(os.path.join(d, "crops.npy"), crops)
+    torch.save(state, os.path.join(d, "state.pt"))
+    json.dump({"preemph": preemph, "cmvn": cmvn, "vad": use_vad}, open(os.path.join(d, "meta.json"), "w"))
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1",
+               HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     t0 = time.perf_counter()
-    for _ in range(max(1, passes)):
-        embs = _cpu_pass(pcm_host, crop_idx, state, preemph, cmvn, use_vad, model_ref, scoring_ref, speechpy_ref,
-                         vad_ref, c)
-    dt = (time.perf_counter() - t0) / max(1, passes)
-    return embs, dt, torch.get_num_threads()
+    proc = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", d], env=env,
+                          stdout=subprocess.PIPE, timeout=900)
+    wall = time.perf_counter() - t0
+    if proc.returncode != 0:
+        raise RuntimeError("cpu baseline child failed with code %d" % proc.returncode)
+    rec = json.loads(proc.stdout.decode().strip().splitlines()[-1])
+    rec["wall_s"] = wall
+    emb = np.load(os.path.join(d, "cpu_emb.npy"))
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    return rec, emb
 
 
-def _cpu_pass(pcm_host, crop_idx, state, preemph, cmvn, use_vad, model_ref, scoring_ref, speechpy_ref, vad_ref, c):
-    embs = []
-    for i in range(pcm_host.shape[0]):
-        clip = pcm_host[i]
-        if use_vad:
-            _, _, clip = vad_ref.vad_energy(clip, c.SAMPLE_RATE, c.VAD_FRAME_MS, c.VAD_PADDING_MS,
-                                            c.VAD_ENERGY_THRESHOLD)
-        sig = speechpy_ref.preemphasis(clip, cof=0.98) if preemph else clip
-        feat = speechpy_ref.lmfe(sig, c.SAMPLE_RATE, c.FRAME_LEN, c.FRAME_STEP, c.NUM_COEF, c.NUM_FFT)
-        if cmvn:
-            feat = speechpy_ref.cmvn(feat, variance_normalization=True)
-        cube = model_ref.feature_cube(feat, crop_idx[i])[None]
-        embs.append(model_ref.c3d2_embed(state, cube).numpy()[0])
-    embs = np.stack(embs)
-    enroll = embs[::max(1, len(embs) // 8)]
-    for i in range(len(embs)):
-        scoring_ref.compute_similarity(embs[i], enroll)
-    return embs
-
-
+# --------------------------------------------------------------------------------------------------
 def main():
     args = parse()
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if args.cpu_child:
+        return cpu_child(args.cpu_child)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])             # before torch / any GPU call in this process
+    if args.selftest:
+        return selftest_rank()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
         # one MIOpen find-db / kernel cache per rank: N processes searching kernels at once would
         # otherwise contend for the same sqlite files under ~/.config/miopen and ~/.cache/miopen
         import tempfile
-        tag = os.path.join(tempfile.gettempdir(), "svk_miopen_rank%s" % os.environ.get("LOCAL_RANK", "0"))
+        tag = os.path.join(tempfile.gettempdir(), "svk_miopen_rank%d" % local_rank)
         os.makedirs(tag, exist_ok=True)
         os.environ.setdefault("MIOPEN_USER_DB_PATH", tag)
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", tag)
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    device_index = local_rank if args.backend == "nccl" else local_rank % max(1, n_dev)
+    torch.cuda.set_device(device_index)
     use_dist = world > 1 or os.environ.get("SVK_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL with one rank
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL prints a version banner on STDOUT when the communicator comes up; stdout is reserved
-        # for the one JSON line, so fd 1 points at stderr until the first collective has run.
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        with _stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            else:
+                dist.init_process_group("gloo")
             dist.barrier()
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
 
     from speaker_verification_amd import constants as c, distributed as svdist, evaluation, synth
     from speaker_verification_amd.engine import get_engine
     from speaker_verification_amd.model import calibrate_batchnorm, seeded_model
     from speaker_verification_amd.pipeline import VerificationPipeline, enroll_last_utterance
 
-    eng = get_engine(local_rank)
+    eng = get_engine(device_index)
     dev = eng.device
 
     if args.frontend_only:
@@ -314,18 +548,23 @@ def main():
                "B": frontend_B_bench(eng, torch, reps=max(args.steps, 5)),
                "ingest_resample": ingest_bench(eng, torch)}
         print(json.dumps(res))
-        return
+        return 0
+    if args.stages_only:
+        print(json.dumps({"stage_kernels": stage_kernels_bench(eng, torch, reps=max(args.steps, 5)),
+                          "cosine_mfma": cosine_mfma_bench(eng, torch)}))
+        return 0
 
-    n_local = args.clips
-    n_total = n_local * world
-    pcm, speakers_local = synth.corpus_device(n_local, dev, first_clip=rank * n_local, utts_per_speaker=UTTS_PER_SPK)
+    n_total = args.corpus
+    lo_r, hi_r = svdist.shard_bounds(n_total, world, rank)
+    n_local = hi_r - lo_r
+    pcm, _ = synth.corpus_device(n_local, dev, first_clip=lo_r, utts_per_speaker=UTTS_PER_SPK)
     model = seeded_model(2024, n_labels=1211)
     pipe = VerificationPipeline(model, use_vad=not args.no_vad, normalize=not args.no_cmvn,
                                 preemph_cof=None if args.no_preemph else 0.98, crop_rng="device",
                                 micro_batch=args.micro_batch, channels_last=not args.no_channels_last,
                                 overlap_front=os.environ.get("SVK_BENCH_OVERLAP", "0") == "1")
-    # random-init weights (no checkpoint ships) with BatchNorm statistics calibrated on 256 clips of
-    # rank 0's shard, identically on every rank (model.calibrate_batchnorm explains why)
+    # random-init weights (no checkpoint ships) with BatchNorm statistics calibrated on the first 256 clips
+    # of the corpus, identically on every rank (model.calibrate_batchnorm explains why)
     cal_pcm, _ = synth.corpus_device(256, dev, first_clip=0, utts_per_speaker=UTTS_PER_SPK)
     _, cal = pipe.embed(cal_pcm, return_intermediates=True)
     calibrate_batchnorm(pipe.model, torch.cat([d["cube"] for d in cal]))
@@ -335,13 +574,14 @@ def main():
     spk_all = (np.arange(n_total) // UTTS_PER_SPK).astype(np.int32)
     ids, last = enroll_last_utterance(None, spk_all[:n_test])                  # Q17: last utterance enrols
     last_dev = torch.from_numpy(last).to(dev)
+    spans = pipe.chunks(n_local)
 
-    fe_events = []
+    fe_events, ag_events = [], []
 
     def one_step(record):
         # timed region: everything from resident PCM to the score matrix
         local = torch.empty((n_local, 128), dtype=torch.float32, device=dev)
-        for lo, hi in pipe.chunks(n_local):
+        for lo, hi in spans:
             chunk = pcm[lo:hi]
             voiced, vlen = pipe.voiced(chunk)
             if record:
@@ -350,13 +590,18 @@ def main():
             feat, n_frames, _ = eng.features(voiced, pipe.spec, lengths=vlen)
             if record:
                 b.record()
-                fe_events.append((a, b, hi - lo))
+                fe_events.append((a, b))
             if pipe.normalize:
                 eng.cmvn_(feat, n_frames, variance=True)
-            idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, rank * n_local + lo,
-                                 pipe.bad_clips)
+            idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, lo_r + lo, pipe.bad_clips)
             local[lo:hi] = pipe.embed_features(feat, idx)      # cube (as the first layer's patch matrix) -> C3D2
+        if record:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
         full = svdist.all_gather_embeddings(local, n_total)
+        if record:
+            b.record()
+            ag_events.append((a, b))
         scores = pipe.score(full[:n_test], full[:n_test][last_dev])
         return full, scores
 
@@ -374,7 +619,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     bad = int(pipe.bad_clips.item())
@@ -383,42 +628,65 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = n_total * args.steps / dt
-        # roofline of the fused front-end kernel, from HIP events on the launch stream
-        fe_ms = np.array([a.elapsed_time(b) for a, b, _ in fe_events])
-        fe_clips = np.array([n for _, _, n in fe_events])
-        bytes_per_utt = 48000 * 2 + 297 * 40 * 4                 # SURVEY 8(d) front end B: 143 520 B
+        # roofline of the fused front-end kernel: HIP events on the launch stream around each launch of the
+        # timed region; algorithmic bytes of the launches as they ran (clips shortened by the VAD): kept
+        # samples x 2 B read + produced frames x 40 x 4 B written, counted in one extra untimed VAD pass
+        fe_ms = np.array([a.elapsed_time(b) for a, b in fe_events])
+        kept = torch.zeros((), dtype=torch.float64, device=dev)
+        frames = torch.zeros((), dtype=torch.float64, device=dev)
+        for lo, hi in spans:
+            _, vlen = pipe.voiced(pcm[lo:hi])
+            vl = vlen.to(torch.float64) if vlen is not None else torch.full((hi - lo,), float(pcm.shape[1]), device=dev,
+                                                                           dtype=torch.float64)
+            kept += vl.sum()
+            frames += torch.clamp(torch.floor((vl - pipe.spec.frame_len) / pipe.spec.frame_stride), min=0).sum()
+        launches = len(spans)
+        bytes_per_launch = (float(kept.item()) * 2 + float(frames.item()) * 40 * 4) / launches
         avg_launch_s = float(fe_ms.mean()) * 1e-3
-        gbs = float(fe_clips.mean()) * bytes_per_utt / avg_launch_s / 1e9
+        gbs = bytes_per_launch / avg_launch_s / 1e9
         traffic, traffic_src = pmc_traffic("frontend_kernel<int16,nfft1024>")
         labels = (spk_all[:n_test, None] == ids[None, :]).astype(np.float64)
         sc = scores.cpu().numpy().astype(np.float64)
         eer, auc, _, _ = evaluation.get_eer_auc(labels.flatten(), sc.flatten())
         eer_dev, auc_dev = evaluation.get_eer_auc_device(labels, scores)       # svk_roc_eer on the same matrix
+        e2e_tflops = value * C3D2_GFLOP_PER_UTT / 1e3
         result = {
             "metric": "utterances/sec (MFCC->embed->cosine)", "value": value, "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded formant 'voices', 3 s / 16 kHz int16, generated on device; random-init C3D2)",
-            "config": {"workload": "configs[4] per-GPU shard: %d clips/rank x %d rank(s): energy-VAD -> pre-emph + "
+            "config": {"workload": "configs[4]: %d-clip corpus over %d rank(s) (%d clips on rank 0): energy-VAD -> pre-emph + "
                                    "lmfe(25ms/10ms/1024/40) -> CMVN -> 20x80x40 cube -> C3D2(f32) -> all-gather -> "
-                                   "%dx%d cosine" % (n_local, world, n_test, len(ids)),
-                       "clips_per_rank": n_local, "micro_batch": pipe.chunks(n_local)[0][1], "vad": pipe.use_vad,
-                       "cmvn": pipe.normalize, "preemph": not args.no_preemph, "parallelism": "dp%d" % world,
-                       "crop_rng": "device"},
+                                   "%dx%d cosine" % (n_total, world, n_local, n_test, len(ids)),
+                       "corpus_clips": n_total, "clips_per_rank": n_local, "micro_batch": spans[0][1] - spans[0][0],
+                       "vad": pipe.use_vad, "cmvn": pipe.normalize, "preemph": not args.no_preemph,
+                       "parallelism": "dp%d" % world, "crop_rng": "device"},
+            "ranks_seen": dist.get_world_size() if use_dist else 1,
+            "backend": ("rccl (torch 'nccl')" if args.backend == "nccl" else "gloo") if use_dist else None,
+            "allgather_us": float(np.median([a.elapsed_time(b) for a, b in ag_events])) * 1e3 if use_dist else None,
+            "allgather_bytes_per_rank": svdist.shard_rows(n_total, world) * 128 * 4,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_note": "PMC pass ran this kernel on 1 024 FULL 3 s clips per launch "
-                                         "(algorithmic 146 964 480 B); launches here carry VAD-shortened clips",
+                                         "(algorithmic 146 964 480 B); `achieved` uses the VAD-shortened bytes of "
+                                         "the launches timed here",
                          "kernel": "frontend_kernel<int16,nfft1024>", "avg_launch_ms": avg_launch_s * 1e3,
-                         "clips_per_launch": float(fe_clips.mean()), "bytes_per_utt": bytes_per_utt,
+                         "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "full_clip_bytes_per_utt": 48000 * 2 + 297 * 40 * 4,
                          "frontend_share_of_step": float(fe_ms.sum()) / args.steps / ms_per_step},
+            "roofline_e2e": {"bound": "mfma", "achieved": e2e_tflops, "peak": F32_MATRIX_PEAK_TFLOPS * world,
+                             "unit": "TFLOP/s", "frac": e2e_tflops / (F32_MATRIX_PEAK_TFLOPS * world),
+                             "gflop_per_utt": C3D2_GFLOP_PER_UTT,
+                             "note": "whole step vs the dense f32 matrix peak of the N GPUs: the C3D2 forward "
+                                     "(676.6 MFLOP per utterance, PyTorch-ROCm / MIOpen) is ~95 % of the step; "
+                                     "SURVEY 8(d) ceiling = 232 k utt/s per GPU"},
             "eer": {"eer": eer, "auc": auc, "eer_device": eer_dev, "auc_device": auc_dev, "pairs": int(labels.size),
                     "short_clips": bad},
         }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_extras:
         # host-fed variant (PCIe included; NOT `value`): 4 micro-batches of the shard from pageable host memory
-        n_host = min(n_local, 4 * pipe.chunks(n_local)[0][1])
+        n_host = min(n_local, 4 * (spans[0][1] - spans[0][0]))
         host_pcm = pcm[:n_host].cpu().numpy()
         pipe.embed_host(host_pcm)
         torch.cuda.synchronize()
@@ -433,38 +701,37 @@ def main():
         emb_p = pipe.embed_host(pinned_pcm)
         torch.cuda.synchronize()
         t_p = time.perf_counter() - t_p
+        # the resident path draws crops keyed by the global clip index: the same clips, the same embeddings
+        same = pipe.embed(pcm[:n_host])
         result["host_fed"] = {"utt_per_s": n_host / t_h, "utt_per_s_from_pinned": n_host / t_p, "clips": n_host,
-                              "max_abs_diff_vs_resident": float(max((emb_h - full[:n_host]).abs().max().item(),
-                                                                    (emb_p - full[:n_host]).abs().max().item())),
+                              "max_abs_diff_vs_resident": float(max((emb_h - same).abs().max().item(),
+                                                                    (emb_p - same).abs().max().item())),
                               "note": "pageable int16 NumPy -> 8-thread staging into a pinned double buffer -> copy "
                                       "stream -> same kernels; from_pinned: the caller's buffer is already pinned"}
-        del pinned_pcm
-        lo0, hi0 = pipe.chunks(n_local)[0]
+        del pinned_pcm, host_pcm
+        lo0, hi0 = spans[0]
         result["micro_batch_breakdown"] = stage_breakdown(pipe, eng, torch, pcm[lo0:hi0], 0)
         result["frontend_A"] = frontend_A_bench(eng, torch)
         result["cosine_mfma"] = cosine_mfma_bench(eng, torch)
+        result["stage_kernels"] = stage_kernels_bench(eng, torch)
         result["ingest_resample"] = ingest_bench(eng, torch)
         if args.cpu_sample > 0:
+            # sample: whole speakers from the start of the corpus (the last utterance of each enrols, Q17)
             ns = min(args.cpu_sample, n_local)
-            # three utterances each of ns/3 speakers spread over the shard (the last one enrols, Q17)
-            n_spk_s = max(1, ns // 3)
-            spk_step = max(1, (n_local // UTTS_PER_SPK) // n_spk_s)
-            pick = np.array([min(n_local - 1, (k * spk_step) * UTTS_PER_SPK + u) for k in range(n_spk_s)
-                             for u in range(3)], dtype=np.int64)
-            ns = pick.size
-            sample = pcm[torch.from_numpy(pick).to(dev)]
+            sample = pcm[:ns]
             emb, inter = pipe.embed(sample, return_intermediates=True)
             crops = np.zeros((ns, c.CUBE_CROPS), dtype=np.int32)
             for d in inter:
                 crops[d["lo"]:d["hi"]] = d["crop_idx"].cpu().numpy()
+            del inter
             state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-            ref_emb, cpu_dt, threads = cpu_baseline(sample.cpu().numpy(), crops, state, not args.no_preemph,
-                                                    pipe.normalize, pipe.use_vad)
+            rec, ref_emb = run_cpu_baseline(sample.cpu().numpy(), crops, state, not args.no_preemph, pipe.normalize,
+                                            pipe.use_vad)
             got = emb.cpu().numpy()
             from oracle import scoring_ref
-            spk_s = spk_all[pick]
-            lab = (spk_s[:, None] == np.unique(spk_s)[None, :]).astype(np.float64)
-            _, last_s = enroll_last_utterance(None, spk_s)
+            spk_s = spk_all[:ns]
+            uniq, last_s = enroll_last_utterance(None, spk_s)
+            lab = (spk_s[:, None] == uniq[None, :]).astype(np.float64)
             s_gpu = pipe.score(emb, emb[torch.from_numpy(last_s).to(dev)]).cpu().numpy().astype(np.float64)
             s_ref = scoring_ref.cosine_matrix(ref_emb, ref_emb[last_s]).astype(np.float64)
             par = {"sample_clips": ns, "embed_max_abs_diff": float(np.abs(got - ref_emb).max()),
@@ -479,16 +746,20 @@ def main():
             par["full_matrix_score_max_abs_diff"] = float(np.abs(s_or - sc).max())
             par["full_matrix_eer_cpu_ref"] = float(scoring_ref.get_eer_auc(labels.flatten(), s_or.flatten())[0])
             result["parity"] = par
-            result["cpu_baseline"] = {"value": ns / cpu_dt, "unit": "utterances/s", "cores": threads, "kind": "port",
-                                      "sample": "%d clips spread over the same shard through oracle/ (vad -> preemph -> lmfe "
-                                                "-> cmvn -> cube -> C3D2 batch 1 -> per-pair cosine), 3 passes of %.1f s" %
-                                                (ns, cpu_dt)}
+            result["cpu_baseline"] = {
+                "value": rec["value"], "unit": "utterances/s", "cores": rec["cores"], "kind": "port",
+                "sample": "the first %d clips of the corpus through oracle/ in a fresh process: vad -> /32768 -> preemph "
+                          "-> lmfe -> cmvn -> cube -> C3D2 batch 1 -> per-pair cosine, one single-threaded worker "
+                          "per core (multiprocessing.Pool(%d)); %.1f s" % (ns, rec["cores"], rec["seconds"]),
+                "cpu_model": rec["cpu_model"], "os_cpu_count": rec["os_cpu_count"], "versions": rec["versions"],
+                "variants": rec["stages"], "child_wall_s": rec["wall_s"]}
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -36,6 +36,11 @@ def all_gather_embeddings(local, n_total, group=None):
     if local.shape[0] != rows:
         send = torch.zeros((rows, local.shape[1]), dtype=local.dtype, device=local.device)
         send[:local.shape[0]] = local
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of N ranks on one GPU (RCCL refuses two ranks on a device): gloo moves host memory
+        parts = [torch.empty((rows, local.shape[1]), dtype=local.dtype) for _ in range(world)]
+        dist.all_gather(parts, send.cpu().contiguous(), group=group)
+        return torch.cat(parts)[:n_total].to(local.device)
     recv = torch.empty((world * rows, local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
     # ranks hold consecutive ranges of `rows` items, so the valid rows are a prefix

@@ -110,3 +110,33 @@ def test_siamese_train_step_single_process():
     before = model.FC5.weight.detach().clone()
     l1 = siamese_train_step(model, make_criterion(), opt, a, b, y)
     assert np.isfinite(l1) and not torch.equal(before, model.FC5.weight)
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` without WORLD_SIZE starts two fresh rank processes itself (no torchrun),
+    relays rank 0's one JSON line and reports what torch.distributed saw (--selftest: gloo, no GPU)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for n in (2, 1):
+        proc = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(n), "--selftest"],
+                              env=env, stdout=subprocess.PIPE, timeout=300)
+        assert proc.returncode == 0
+        lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
+        assert len(lines) == 1
+        rec = json.loads(lines[0])
+        assert rec["ranks_seen"] == n and rec["n_gpus"] == n and rec["gathered_ok"] and rec["max_over_ranks"] == n
+        assert rec["backend"] == ("gloo" if n > 1 else None)
+
+
+def test_bench_launcher_reports_a_failed_rank(tmp_path):
+    """A rank that dies makes the launcher exit non-zero (it never re-execs itself: plain child processes)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    proc = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--selftest", "--steps", "x"],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert proc.returncode != 0
