@@ -48,13 +48,17 @@ __global__ __launch_bounds__(256) void stack_frames_kernel(const float* __restri
 }
 
 // ---- spectrum: wave FFT for nfft 512 / 1024 ------------------------------------------
-// One wave per workgroup; nfft = 512 handles two frames per FFT, nfft = 1024 one.
+// Four independent waves per workgroup, each with its own scratch (they never wait for each other);
+// nfft = 512 handles two frames per FFT, nfft = 1024 one.
+constexpr int SPEC_WAVES = 4;
 template <bool SPLIT1024>
-__global__ __launch_bounds__(64) void spectrum_fft_kernel(const float* __restrict__ frames, int nframes, int flen,
-                                                          int power, const cplx* __restrict__ tw,
-                                                          float* __restrict__ out) {
-  __shared__ cplx scr[SCR];
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * SPEC_WAVES) void spectrum_fft_kernel(const float* __restrict__ frames, int nframes,
+                                                                       int flen, int power,
+                                                                       const cplx* __restrict__ tw,
+                                                                       float* __restrict__ out) {
+  __shared__ cplx scr_all[SPEC_WAVES][SCR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  cplx* scr = scr_all[wave];
   const int nfft = SPLIT1024 ? 1024 : 512;
   const int nbins = nfft / 2 + 1;
   const int feff = flen < nfft ? flen : nfft;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(64) void spectrum_fft_kernel(const float* __restric
   const bool lane0 = lane == 0;
   constexpr int PER = SPLIT1024 ? 1 : 2;
   const float scale = power ? (SPLIT1024 ? 1.f / 1024.f : 1.f / 2048.f) : (SPLIT1024 ? 1.f : 0.25f);
-  for (int fa = blockIdx.x * PER; fa < nframes; fa += gridDim.x * PER) {
+  for (int fa = (blockIdx.x * SPEC_WAVES + wave) * PER; fa < nframes; fa += gridDim.x * SPEC_WAVES * PER) {
     const float* sa = frames + (int64_t)fa * flen;
     const bool hasb = !SPLIT1024 && fa + 1 < nframes;
     const float* sb = frames + (int64_t)(hasb ? fa + 1 : fa) * flen;
@@ -123,26 +127,123 @@ __global__ __launch_bounds__(64) void spectrum_fft_kernel(const float* __restric
   }
 }
 
-// ---- spectrum: direct DFT for every other length (O(n^2), float64 phase) -----------------
+// ---- spectrum: any other power of two (4 .. 8192) -- Stockham radix-2 FFT in LDS -----------------------
+// The real frame of nfft samples is packed as M = nfft/2 complex numbers (even, odd samples), transformed by
+// log2(M) autosort passes between two LDS buffers and untangled (X[k] = E[k] + W_nfft^k O[k]).  A frame is
+// worked on by TPF = min(256, M/2) threads, 256 / TPF frames per workgroup; `tw` holds W_nfft^i, i < nfft/2
+// (f64-computed, rounded once): pass twiddles W_M^j are its even entries.
+__global__ __launch_bounds__(256) void spectrum_pow2_kernel(const float* __restrict__ frames, int nframes, int flen,
+                                                            int nfft, int power, const cplx* __restrict__ tw_g,
+                                                            float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_fft[];
+  const int M = nfft >> 1, nbins = M + 1;
+  const int feff = flen < nfft ? flen : nfft;
+  const int tpf = M / 2 < 256 ? (M / 2 < 1 ? 1 : M / 2) : 256;  // threads per frame
+  const int fpb = 256 / tpf;                                    // frames per workgroup
+  cplx* tw = reinterpret_cast<cplx*>(smem_fft);                 // [M]  W_nfft^i
+  cplx* buf = tw + M;                                           // [fpb][2][M]
+  for (int i = threadIdx.x; i < M; i += 256) tw[i] = tw_g[i];
+  const int sub = threadIdx.x / tpf, t = threadIdx.x - sub * tpf;
+  cplx* a = buf + (size_t)sub * 2 * M;
+  cplx* b = a + M;
+  const float scale = power ? 1.0f / (float)nfft : 1.0f;
+  for (int64_t f0 = (int64_t)blockIdx.x * fpb; f0 < nframes; f0 += (int64_t)gridDim.x * fpb) {
+    const int64_t f = f0 + sub;
+    const bool live = f < nframes;
+    const float* src = frames + (live ? f : 0) * flen;
+    __syncthreads();  // previous frame's readers are done (and the table is in place)
+    for (int j = t; j < M; j += tpf) {
+      const int i0 = 2 * j;
+      a[j] = mk(live && i0 < feff ? src[i0] : 0.f, live && i0 + 1 < feff ? src[i0 + 1] : 0.f);
+    }
+    cplx* x = a;
+    cplx* y = b;
+    for (int ns = 1; ns < M; ns <<= 1) {
+      __syncthreads();
+      const int tstep = M / ns;  // W_{2 ns}^k = W_nfft^(k * nfft / (2 ns)) = tw[k * M / ns]
+      for (int j = t; j < M / 2; j += tpf) {
+        const int k = j & (ns - 1);
+        const cplx w = tw[k * tstep];
+        const cplx u = x[j], v0 = x[j + M / 2];
+        const cplx v = mk(v0.x * w.x - v0.y * w.y, v0.x * w.y + v0.y * w.x);
+        const int j0 = ((j - k) << 1) + k;
+        y[j0] = u + v;
+        y[j0 + ns] = u - v;
+      }
+      cplx* tmp = x;
+      x = y;
+      y = tmp;
+    }
+    __syncthreads();
+    // untangle: Z = FFT_M(even + i odd);  E[k] = (Z[k] + conj Z[M-k]) / 2,  O[k] = (Z[k] - conj Z[M-k]) / (2i)
+    if (live) {
+      float* o = out + f * nbins;
+      for (int k = t; k <= M; k += tpf) {
+        const cplx zk = x[k == M ? 0 : k], zn = x[k == 0 ? 0 : M - k];
+        const float er = 0.5f * (zk.x + zn.x), ei = 0.5f * (zk.y - zn.y);
+        const float orr = 0.5f * (zk.y + zn.y), oi = -0.5f * (zk.x - zn.x);
+        const cplx w = k == M ? mk(-1.f, 0.f) : tw[k];
+        const float xr = er + orr * w.x - oi * w.y, xi = ei + orr * w.y + oi * w.x;
+        const float p = (xr * xr + xi * xi) * scale;
+        o[k] = power ? p : sqrtf(p);
+      }
+    }
+  }
+}
+
+// ---- spectrum: every other length -- direct DFT, O(n^2), phases from a table ----------------------------
+// `tw` holds W_nfft^i for i < nfft (f64-computed, rounded once to f32); a workgroup keeps it and FR frames
+// in LDS; thread -> output bin k walks the phase index k n mod nfft by addition (no division, no sincos
+// in the loop) with float64 accumulators.
+constexpr int DFT_FR = 4;
 __global__ __launch_bounds__(256) void spectrum_dft_kernel(const float* __restrict__ frames, int nframes, int flen,
-                                                           int nfft, int power, float* __restrict__ out) {
+                                                           int nfft, int power, const cplx* __restrict__ tw_g,
+                                                           float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dft[];
   const int nbins = nfft / 2 + 1;
   const int feff = flen < nfft ? flen : nfft;
-  const int64_t total = (int64_t)nframes * nbins;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t f = i / nbins;
-    const int k = (int)(i - f * nbins);
-    const float* s = frames + f * flen;
-    double re = 0.0, im = 0.0;
-    for (int nn = 0; nn < feff; ++nn) {
-      const int ph = (int)(((int64_t)k * nn) % nfft);
-      double sn, cs;
-      sincospi(2.0 * (double)ph / (double)nfft, &sn, &cs);
-      re += (double)s[nn] * cs;
-      im -= (double)s[nn] * sn;
+  cplx* tw = reinterpret_cast<cplx*>(smem_dft);                 // [nfft]
+  float* x = reinterpret_cast<float*>(tw + nfft);              // [DFT_FR][feff]
+  for (int i = threadIdx.x; i < nfft; i += 256) tw[i] = tw_g[i];
+  for (int64_t f0 = (int64_t)blockIdx.x * DFT_FR; f0 < nframes; f0 += (int64_t)gridDim.x * DFT_FR) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < DFT_FR * feff; i += 256) {
+      const int q = i / feff, n = i - q * feff;
+      x[i] = f0 + q < nframes ? frames[(f0 + q) * flen + n] : 0.f;
     }
-    const double mag2 = re * re + im * im;
-    out[i] = (float)(power ? mag2 / (double)nfft : sqrt(mag2));
+    __syncthreads();
+    for (int k = threadIdx.x; k < nbins; k += 256) {
+      double re[DFT_FR] = {0.0}, im[DFT_FR] = {0.0};
+      int ph = 0;
+      for (int n = 0; n < feff; ++n) {
+        const cplx w = tw[ph];
+        ph += k;
+        ph = ph >= nfft ? ph - nfft : ph;
+#pragma unroll
+        for (int q = 0; q < DFT_FR; ++q) {
+          const double v = (double)x[q * feff + n];
+          re[q] += v * (double)w.x;
+          im[q] += v * (double)w.y;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < DFT_FR; ++q)
+        if (f0 + q < nframes) {
+          const double mag2 = re[q] * re[q] + im[q] * im[q];
+          out[(f0 + q) * nbins + k] = (float)(power ? mag2 / (double)nfft : sqrt(mag2));
+        }
+    }
+  }
+}
+
+// W_n^i = exp(-2 pi i / n), i < count, computed on the device in float64 (one launch per call: the table
+// depends on nfft and lives in the handle's workspace)
+__global__ __launch_bounds__(256) void twiddle_table_kernel(cplx* __restrict__ tw, int n, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) {
+    double sn, cs;
+    sincospi(-2.0 * (double)i / (double)n, &sn, &cs);
+    tw[i] = mk((float)cs, (float)sn);
   }
 }
 
@@ -200,46 +301,102 @@ __global__ __launch_bounds__(256) void cmvn_kernel(float* __restrict__ feat, int
   }
 }
 
-// ---- general mel / log / DCT stage (any fft length): one workgroup per frame, one thread per filter ----
-__global__ __launch_bounds__(1024) void mel_features_kernel(const float* __restrict__ power, int nbins,
-                                                            const float* __restrict__ bank, int nf, int out_kind,
-                                                            int ncep, int dc_elim, float* __restrict__ feat,
-                                                            float* __restrict__ energy) {
-  extern __shared__ float lmel[];  // [nf] (log) mel energies of this frame, then [blockDim/64] partial sums
-  float* part = lmel + nf;
-  const int t = blockIdx.x, i = threadIdx.x;
-  const float* p = power + (int64_t)t * nbins;
+// ---- general mel / log / DCT stage (any fft length, any bank) ------------------------------------------------
+// mel[T][nf] = power[T][nbins] x bank^T: a workgroup owns MEL_FR frames and walks the filters in blocks of 64
+// and the bins in chunks of 64, both operands staged in LDS with coalesced loads (the bank row stride + 1
+// makes the per-filter reads conflict-free; the power value is a wave-wide broadcast).  Thread = (filter of
+// the block, group of 4 frames).  The frame energy (sum over ALL bins, feature.py:202) is taken from the
+// staged power chunks of the first filter block.  (log) mel energies of the tile stay in LDS; the DCT-II
+// (ortho) rows come from a table built once per call (dct_table_kernel).
+constexpr int MEL_FR = 16, MEL_CH = 64;
+__global__ __launch_bounds__(256) void mel_features_kernel(const float* __restrict__ power, int nframes, int nbins,
+                                                           const float* __restrict__ bank, int nf, int out_kind,
+                                                           int ncep, int dc_elim, const float* __restrict__ dct,
+                                                           float* __restrict__ feat, float* __restrict__ energy) {
+  extern __shared__ __attribute__((aligned(16))) char smem_mel[];
+  float* ptile = reinterpret_cast<float*>(smem_mel);      // [MEL_FR][MEL_CH]
+  float* btile = ptile + MEL_FR * MEL_CH;                  // [64][MEL_CH + 1]
+  float* etot = btile + 64 * (MEL_CH + 1);                 // [MEL_FR]
+  float* lmel = etot + MEL_FR;                             // [MEL_FR][nf]
   const float EPS = 2.220446049250313e-16f;
-  float e = 0.f;
-  for (int k = i; k < nbins; k += blockDim.x) e += p[k];
-  e = wave_sum(e);
-  if ((i & 63) == 0) part[i >> 6] = e;
-  float m = 0.f;
-  if (i < nf) {
-    const float* w = bank + (int64_t)i * nbins;
-    for (int k = 0; k < nbins; ++k) m = fmaf(p[k], w[k], m);
-    m = m == 0.f ? EPS : m;                       // feature.py:217
-    lmel[i] = out_kind == SVK_OUT_MFE ? m : logf(m);
+  const int t = threadIdx.x, fi = t & 63, fg = t >> 6;     // filter inside the block, frame group (wave-uniform)
+  const int64_t f0 = (int64_t)blockIdx.x * MEL_FR;
+  const int nfr = (int)(nframes - f0 < MEL_FR ? nframes - f0 : MEL_FR);
+  float esum = 0.f;                                        // thread (frame t / 16, part t % 16): energy partial
+  for (int fb = 0; fb < nf; fb += 64) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < nbins; k0 += MEL_CH) {
+      __syncthreads();
+      for (int i = t; i < MEL_FR * MEL_CH; i += 256) {
+        const int r = i / MEL_CH, k = i - r * MEL_CH;
+        ptile[i] = (r < nfr && k0 + k < nbins) ? power[(f0 + r) * nbins + k0 + k] : 0.f;
+      }
+      for (int i = t; i < 64 * MEL_CH; i += 256) {
+        const int r = i / MEL_CH, k = i - r * MEL_CH;
+        btile[r * (MEL_CH + 1) + k] = (fb + r < nf && k0 + k < nbins) ? bank[(int64_t)(fb + r) * nbins + k0 + k] : 0.f;
+      }
+      __syncthreads();
+      if (fb == 0) {
+        const float* pr = ptile + (t >> 4) * MEL_CH + (t & 15) * 4;
+        esum += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+      }
+      const float* br = btile + fi * (MEL_CH + 1);
+      const float* pr = ptile + fg * 4 * MEL_CH;
+#pragma unroll 8
+      for (int k = 0; k < MEL_CH; ++k) {
+        const float w = br[k];
+        acc[0] = fmaf(pr[k], w, acc[0]);
+        acc[1] = fmaf(pr[MEL_CH + k], w, acc[1]);
+        acc[2] = fmaf(pr[2 * MEL_CH + k], w, acc[2]);
+        acc[3] = fmaf(pr[3 * MEL_CH + k], w, acc[3]);
+      }
+    }
+    if (fb + fi < nf) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float m = acc[q] == 0.f ? EPS : acc[q];  // feature.py:217
+        lmel[(fg * 4 + q) * nf + fb + fi] = out_kind == SVK_OUT_MFE ? m : logf(m);
+      }
+    }
   }
+  // frame energies: 16 partials per frame sit in 16 consecutive lanes
+  esum += __shfl_xor(esum, 8, 64);
+  esum += __shfl_xor(esum, 4, 64);
+  esum += __shfl_xor(esum, 2, 64);
+  esum += __shfl_xor(esum, 1, 64);
+  if ((t & 15) == 0) etot[t >> 4] = esum == 0.f ? EPS : esum;  // feature.py:205
   __syncthreads();
-  float etot = 0.f;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) etot += part[w];
-  etot = etot == 0.f ? EPS : etot;                // feature.py:205
-  if (i == 0 && energy) energy[t] = etot;
+  if (energy && t < nfr) energy[f0 + t] = etot[t];
   const int cols = out_kind == SVK_OUT_MFCC ? ncep : nf;
-  if (i < cols) {
+  for (int i = t; i < nfr * cols; i += 256) {
+    const int r = i / cols, cc = i - r * cols;
     float v;
     if (out_kind != SVK_OUT_MFCC) {
-      v = lmel[i];
-    } else if (i == 0 && dc_elim) {
-      v = logf(etot);                             // feature.py:151-152
+      v = lmel[r * nf + cc];
+    } else if (cc == 0 && dc_elim) {
+      v = logf(etot[r]);                             // feature.py:151-152
     } else {
-      // scipy.fftpack.dct(type=2, norm='ortho'): sqrt(2/N) sum_n x_n cos(pi k (2n+1) / 2N), k = 0: sqrt(1/N)
-      double acc = 0.0;
-      for (int n = 0; n < nf; ++n) acc += (double)lmel[n] * cospi((double)i * (2.0 * n + 1.0) / (2.0 * nf));
-      v = (float)(acc * (i == 0 ? sqrt(1.0 / nf) : sqrt(2.0 / nf)));
+      const float* d = dct + (int64_t)cc * nf;
+      const float* lm = lmel + r * nf;
+      float a0 = 0.f, a1 = 0.f;
+      int n = 0;
+      for (; n + 1 < nf; n += 2) {
+        a0 = fmaf(lm[n], d[n], a0);
+        a1 = fmaf(lm[n + 1], d[n + 1], a1);
+      }
+      if (n < nf) a0 = fmaf(lm[n], d[n], a0);
+      v = a0 + a1;
     }
-    feat[(int64_t)t * cols + i] = v;
+    feat[(f0 + r) * cols + cc] = v;
+  }
+}
+
+// scipy.fftpack.dct(type=2, norm='ortho'): D[k][n] = sqrt(2/N) cos(pi k (2n+1) / 2N), D[0][n] = sqrt(1/N)
+__global__ __launch_bounds__(256) void dct_table_kernel(float* __restrict__ d, int ncep, int nf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncep * nf) {
+    const int k = i / nf, n = i - k * nf;
+    d[i] = (float)(cospi((double)k * (2.0 * n + 1.0) / (2.0 * nf)) * (k == 0 ? sqrt(1.0 / nf) : sqrt(2.0 / nf)));
   }
 }
 
@@ -252,31 +409,47 @@ __device__ __forceinline__ int sym_index(int k, int T) {
   return m < T ? m : 2 * T - 1 - m;
 }
 
-// pass 0: out = x - mean(window);  pass 1: out = src / (std(window of src) + 2^-30), src = pass-0 result
+// pass 0: out = x - mean(window);  pass 1: out = src / (std(window of src) + 2^-30), src = pass-0 result.
+// Thread = (clip, segment of `seg` consecutive rows, column): the window sums of the segment's first row are
+// taken directly (win loads), every further row costs one row entering and one leaving the window: win / seg + 2
+// loads per output instead of win (301 -> 11 at seg = 32), float64 running sums.
 __global__ __launch_bounds__(256) void cmvnw_kernel(const float* __restrict__ src, int max_frames, int ncols,
-                                                    const int32_t* __restrict__ n_frames, int win, int pass,
+                                                    const int32_t* __restrict__ n_frames, int win, int pass, int seg,
                                                     float* __restrict__ dst) {
   const int utt = blockIdx.y;
   int T = n_frames ? n_frames[utt] : max_frames;
   T = T < max_frames ? T : max_frames;
+  if (T <= 0) return;
   const int half = (win - 1) / 2;
   const float* base = src + (int64_t)utt * max_frames * ncols;
   float* out = dst + (int64_t)utt * max_frames * ncols;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < T * ncols; i += gridDim.x * blockDim.x) {
-    const int r = i / ncols, c = i - r * ncols;
+  const int nseg = (T + seg - 1) / seg;
+  const double inv_win = 1.0 / (double)win;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nseg * ncols; i += gridDim.x * blockDim.x) {
+    const int sg = i / ncols, c = i - sg * ncols;  // consecutive threads -> consecutive columns of one row
+    const int r0 = sg * seg, r1 = r0 + seg < T ? r0 + seg : T;
     double s = 0.0, q = 0.0;
-    for (int k = r - half; k <= r + half; ++k) {
+    for (int k = r0 - half; k <= r0 + half; ++k) {
       const double v = (double)base[(int64_t)sym_index(k, T) * ncols + c];
       s += v;
       q += v * v;
     }
-    const double mean = s / (double)win;
-    if (pass == 0) {
-      out[i] = (float)((double)base[i] - mean);
-    } else {
-      double var = q / (double)win - mean * mean;
-      var = var > 0.0 ? var : 0.0;
-      out[i] = (float)((double)base[i] / (sqrt(var) + 9.313225746154785e-10));
+    for (int r = r0; r < r1; ++r) {
+      if (r > r0) {
+        const double vin = (double)base[(int64_t)sym_index(r + half, T) * ncols + c];
+        const double vout = (double)base[(int64_t)sym_index(r - half - 1, T) * ncols + c];
+        s += vin - vout;
+        q += vin * vin - vout * vout;
+      }
+      const double mean = s * inv_win;
+      const double x = (double)base[(int64_t)r * ncols + c];
+      if (pass == 0) {
+        out[(int64_t)r * ncols + c] = (float)(x - mean);
+      } else {
+        double var = q * inv_win - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        out[(int64_t)r * ncols + c] = (float)(x / (sqrt(var) + 9.313225746154785e-10));
+      }
     }
   }
 }
@@ -515,18 +688,40 @@ int svk_spectrum(svk_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t 
     int rc = spectrum_tables(ctx, &tw);
     if (rc != SVK_OK) return rc;
     if (nfft == 512) {
-      const unsigned grid = capped_grid(ctx, (n_frames + 1) / 2, 1);
-      hipLaunchKernelGGL(spectrum_fft_kernel<false>, dim3(grid), dim3(64), 0, ctx->stream, d_frames, n_frames,
-                         frame_len, power, tw, d_out);
+      const unsigned grid = capped_grid(ctx, (n_frames + 1) / 2, SPEC_WAVES);
+      hipLaunchKernelGGL(spectrum_fft_kernel<false>, dim3(grid), dim3(64 * SPEC_WAVES), 0, ctx->stream, d_frames,
+                         n_frames, frame_len, power, tw, d_out);
     } else {
-      const unsigned grid = capped_grid(ctx, n_frames, 1);
-      hipLaunchKernelGGL(spectrum_fft_kernel<true>, dim3(grid), dim3(64), 0, ctx->stream, d_frames, n_frames,
-                         frame_len, power, tw, d_out);
+      const unsigned grid = capped_grid(ctx, n_frames, SPEC_WAVES);
+      hipLaunchKernelGGL(spectrum_fft_kernel<true>, dim3(grid), dim3(64 * SPEC_WAVES), 0, ctx->stream, d_frames,
+                         n_frames, frame_len, power, tw, d_out);
     }
   } else {
-    const int64_t total = (int64_t)n_frames * (nfft / 2 + 1);
-    hipLaunchKernelGGL(spectrum_dft_kernel, dim3(capped_grid(ctx, total, 256)), dim3(256), 0, ctx->stream, d_frames,
-                       n_frames, frame_len, nfft, power, d_out);
+    const bool pow2 = (nfft & (nfft - 1)) == 0 && nfft >= 4 && nfft <= 8192;
+    const int feff = frame_len < nfft ? frame_len : nfft;
+    const int count = pow2 ? nfft / 2 : nfft;
+    const size_t lds = pow2 ? sizeof(cplx) * ((size_t)nfft / 2 + (size_t)(256 / std::max(1, std::min(256, nfft / 4))) * nfft)
+                            : sizeof(cplx) * (size_t)nfft + sizeof(float) * (size_t)DFT_FR * feff;
+    if (lds > (size_t)ctx->lds_per_cu)
+      return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "fft_points %d with %d-sample frames needs %zu bytes of LDS (limit %d)", nfft,
+                      frame_len, lds, ctx->lds_per_cu);
+    int rc = svk_ensure_work(ctx, sizeof(cplx) * (size_t)count);
+    if (rc != SVK_OK) return rc;
+    cplx* tw = reinterpret_cast<cplx*>(ctx->work);
+    hipLaunchKernelGGL(twiddle_table_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, tw, nfft, count);
+    SVK_LAUNCH_CHECK(ctx);
+    if (pow2) {
+      const int fpb = 256 / std::max(1, std::min(256, nfft / 4));
+      SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(spectrum_pow2_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(spectrum_pow2_kernel, dim3(capped_grid(ctx, n_frames, fpb)), dim3(256), lds, ctx->stream, d_frames,
+                         n_frames, frame_len, nfft, power, tw, d_out);
+    } else {
+      SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(spectrum_dft_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(spectrum_dft_kernel, dim3(capped_grid(ctx, n_frames, DFT_FR)), dim3(256), lds, ctx->stream, d_frames,
+                         n_frames, frame_len, nfft, power, tw, d_out);
+    }
   }
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
@@ -554,10 +749,22 @@ int svk_mel_features(svk_ctx* ctx, const float* d_power, int32_t n_frames, int32
   if (out_kind == SVK_OUT_MFCC) SVK_REQUIRE(ctx, num_ceps >= 1 && num_ceps <= num_filters, "1 <= num_ceps <= num_filters");
   if (n_frames == 0) return SVK_OK;
   SVK_REQUIRE(ctx, d_power && d_bank && d_feat, "NULL buffer");
-  const int threads = ((num_filters + 63) / 64) * 64;
-  const size_t lds = sizeof(float) * (size_t)(num_filters + threads / 64);
-  hipLaunchKernelGGL(mel_features_kernel, dim3(n_frames), dim3(threads), lds, ctx->stream, d_power, n_bins, d_bank,
-                     num_filters, out_kind, num_ceps, dc_elimination, d_feat, d_energy);
+  const float* dct = nullptr;
+  if (out_kind == SVK_OUT_MFCC) {  // DCT-II rows, rebuilt per call in the handle's workspace (stream-ordered)
+    const int n = num_ceps * num_filters;
+    int rc = svk_ensure_work(ctx, sizeof(float) * (size_t)n);
+    if (rc != SVK_OK) return rc;
+    hipLaunchKernelGGL(dct_table_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<float*>(ctx->work), num_ceps, num_filters);
+    SVK_LAUNCH_CHECK(ctx);
+    dct = reinterpret_cast<const float*>(ctx->work);
+  }
+  const size_t lds = sizeof(float) * (size_t)(MEL_FR * MEL_CH + 64 * (MEL_CH + 1) + MEL_FR + MEL_FR * num_filters);
+  SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(mel_features_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(mel_features_kernel, dim3((unsigned)((n_frames + MEL_FR - 1) / MEL_FR)), dim3(256), lds, ctx->stream,
+                     d_power, n_frames, n_bins, d_bank, num_filters, out_kind, num_ceps, dc_elimination, dct, d_feat,
+                     d_energy);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }
@@ -570,13 +777,16 @@ int svk_cmvnw(svk_ctx* ctx, const float* d_in, int32_t n_utt, int32_t max_frames
   if (n_utt == 0 || max_frames == 0 || n_cols == 0) return SVK_OK;
   SVK_REQUIRE(ctx, d_in && d_out && d_in != d_out, "NULL or aliased buffer");
   SVK_REQUIRE(ctx, !variance || (d_tmp && d_tmp != d_in && d_tmp != d_out), "variance pass needs a distinct d_tmp");
-  const int64_t per = (int64_t)max_frames * n_cols;
+  // rows per thread: long enough to amortise the direct window sum of a segment's first row, short enough
+  // to keep a few hundred threads per clip
+  const int seg = max_frames <= 1024 ? 32 : 128;
+  const int64_t per = (int64_t)((max_frames + seg - 1) / seg) * n_cols;
   const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((per + 255) / 256, ctx->num_cu * 4)), (unsigned)n_utt);
-  hipLaunchKernelGGL(cmvnw_kernel, grid, dim3(256), 0, ctx->stream, d_in, max_frames, n_cols, d_n_frames, win, 0,
+  hipLaunchKernelGGL(cmvnw_kernel, grid, dim3(256), 0, ctx->stream, d_in, max_frames, n_cols, d_n_frames, win, 0, seg,
                      variance ? d_tmp : d_out);
   SVK_LAUNCH_CHECK(ctx);
   if (variance) {
-    hipLaunchKernelGGL(cmvnw_kernel, grid, dim3(256), 0, ctx->stream, d_tmp, max_frames, n_cols, d_n_frames, win, 1,
+    hipLaunchKernelGGL(cmvnw_kernel, grid, dim3(256), 0, ctx->stream, d_tmp, max_frames, n_cols, d_n_frames, win, 1, seg,
                        d_out);
     SVK_LAUNCH_CHECK(ctx);
   }

@@ -1075,3 +1075,60 @@ def test_file_driven_enrol_and_evaluate(eng, golden, tmp_path, monkeypatch, caps
     from speaker_verification_amd import load_data
     sig = load_data.load_wav(filename=os.path.join(data_dir, rel[0]), sample_rate=16000)
     np.testing.assert_array_equal(sig, evaluation_ref.load_wav(os.path.join(data_dir, rel[0])))
+
+
+@pytest.mark.parametrize("nfft", [8, 64, 128, 256, 2048, 4096, 8192, 300, 400, 1000, 1023])
+def test_spectrum_any_length(sp, nfft):
+    """processing.fft_spectrum / power_spectrum for every fft_points (processing.py:142-174): powers of two run the
+    LDS Stockham FFT, other lengths the table-driven DFT; frames shorter than nfft are zero-padded, longer cropped (Q6)."""
+    rng = np.random.default_rng(nfft)
+    for flen in (min(nfft, 200), nfft + 37):
+        frames = (rng.standard_normal((37, flen)) * 1000.0)
+        want_p = ref.power_spectrum(frames, nfft)
+        got_p = sp.processing.power_spectrum(frames, nfft)
+        assert got_p.shape == want_p.shape == (37, nfft // 2 + 1)
+        np.testing.assert_allclose(got_p, want_p, rtol=2e-4, atol=2e-5 * want_p.max())
+        np.testing.assert_allclose(sp.processing.fft_spectrum(frames, nfft), ref.fft_spectrum(frames, nfft),
+                                   rtol=2e-4, atol=2e-5 * np.sqrt(want_p.max() * nfft))
+
+
+def test_mel_stage_wide_banks(eng):
+    """svk_mel_features on banks the fused kernel never sees: 200 filters over 1 025 bins (dense random bank), MFE /
+    LMFE / MFCC with and without c0 := log E, a frame count that is not a multiple of the tile."""
+    from speaker_verification_amd import _lib
+    from scipy.fftpack import dct
+    rng = np.random.default_rng(8)
+    T, bins, nf = 77, 1025, 200
+    power = rng.random((T, bins)) * 50.0
+    power[5] = 0.0                                                     # zero frame: energy and mel energies -> eps
+    bank = rng.random((nf, bins)) * (rng.random((nf, bins)) < 0.1)
+    mel = ref.zero_handling(power @ bank.T)
+    energy = ref.zero_handling(power.sum(axis=1))
+    f, e = eng.mel_features(power, bank, _lib.OUT_MFE, want_energy=True)
+    np.testing.assert_allclose(f.cpu().numpy(), mel, rtol=2e-4)
+    np.testing.assert_allclose(e.cpu().numpy(), energy, rtol=2e-4)
+    f, _ = eng.mel_features(power, bank, _lib.OUT_LMFE)
+    np.testing.assert_allclose(f.cpu().numpy(), np.log(mel), **FEAT_TOL)
+    cep = dct(np.log(mel), type=2, axis=-1, norm="ortho")[:, :30]
+    f, _ = eng.mel_features(power, bank, _lib.OUT_MFCC, num_ceps=30, dc_elimination=False)
+    np.testing.assert_allclose(f.cpu().numpy(), cep, **FEAT_TOL)
+    cep[:, 0] = np.log(energy)
+    f, _ = eng.mel_features(power, bank, _lib.OUT_MFCC, num_ceps=30, dc_elimination=True)
+    np.testing.assert_allclose(f.cpu().numpy(), cep, **FEAT_TOL)
+
+
+def test_cmvnw_long_clips_and_windows(eng):
+    """Sliding-window sums (one row in, one row out per step) against the oracle's direct window means: clips
+    longer and shorter than the window, the 128-row segment path (> 1 024 frames), ragged batch."""
+    rng = np.random.default_rng(17)
+    for T, C, win in ((2500, 40, 301), (90, 13, 301), (1024, 8, 31), (1025, 8, 5)):
+        x = rng.standard_normal((T, C)) * 3.0 + 1.0
+        for var in (False, True):
+            got = eng.cmvnw(x.astype(np.float32), win, var).cpu().numpy()
+            np.testing.assert_allclose(got, ref.cmvnw(x.astype(np.float32), win, var), rtol=2e-4, atol=2e-5)
+    batch = rng.standard_normal((3, 700, 13)).astype(np.float32)
+    nfr = np.array([700, 301, 12], dtype=np.int32)
+    got = eng.cmvnw(batch, 301, True, n_frames=nfr).cpu().numpy()
+    for u in range(3):
+        np.testing.assert_allclose(got[u, :nfr[u]], ref.cmvnw(batch[u, :nfr[u]], 301, True), rtol=2e-4, atol=2e-5)
+        np.testing.assert_array_equal(got[u, nfr[u]:], batch[u, nfr[u]:])
