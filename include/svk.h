@@ -37,7 +37,8 @@ typedef enum svk_status {
   SVK_ERR_UNSUPPORTED = -2,  /* a parameter combination the kernels do not cover  */
   SVK_ERR_HIP = -3,          /* a HIP runtime call failed (message has the code)  */
   SVK_ERR_NO_DEVICE = -4,    /* no usable gfx950 device                           */
-  SVK_ERR_OOM = -5
+  SVK_ERR_OOM = -5,
+  SVK_ERR_RCCL = -6          /* RCCL could not be loaded or a collective failed   */
 } svk_status;
 
 typedef struct svk_ctx svk_ctx;
@@ -233,6 +234,24 @@ int svk_l2_dist(svk_ctx* ctx, const float* d_a, const float* d_b, int32_t n, int
 size_t svk_roc_workspace_bytes(int64_t n);
 int svk_roc_eer(svk_ctx* ctx, const float* d_scores, const uint8_t* d_labels, int64_t n, void* d_workspace,
                 size_t workspace_bytes, double* h_out);
+
+/* ---- multi-GPU: the one exchange step of the path ------------------------------------------------
+ * Utterances shard over the GPUs of a node with no data-path exchange until scoring; then every rank needs
+ * the enrolled embeddings: ONE all-gather of the [rows_per_rank][dim] float32 shards over RCCL / xGMI
+ * (the reference has no collective, only in-process DataParallel, train.py:40-41).  One process
+ * per GPU, one context per process.  A torch host uses torch.distributed instead (distributed.py); these
+ * entry points serve a host without torch.  RCCL is loaded at the first call (dlopen), not at link time.
+ *   rank 0: svk_comm_unique_id(ctx, id)  -> ship the 128 bytes to the other ranks by any host channel
+ *   all   : svk_comm_init(ctx, id, n_ranks, rank)            (collective: every rank must call it)
+ *   all   : svk_allgather_f32(ctx, d_send, d_recv, count)    d_recv holds n_ranks x count floats, rank-major;
+ *           asynchronous on the context's stream like every launch
+ *   all   : svk_comm_destroy(ctx)                                                                          */
+int svk_comm_unique_id(svk_ctx* ctx, char out[128]);
+int svk_comm_init(svk_ctx* ctx, const char id[128], int32_t n_ranks, int32_t rank);
+int svk_allgather_f32(svk_ctx* ctx, const float* d_send, float* d_recv, size_t count_per_rank);
+int svk_comm_destroy(svk_ctx* ctx);
+/* out[0] = ranks of the context's communicator (0 = none), out[1] = this rank */
+int svk_comm_info(const svk_ctx* ctx, int32_t out[2]);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,7 @@ int svk_create(int device_id, svk_ctx** out) {
 
 void svk_destroy(svk_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->comm) (void)svk_comm_destroy(ctx);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->work) (void)hipFree(ctx->work);
   delete ctx;

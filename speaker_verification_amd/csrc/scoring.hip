@@ -92,6 +92,12 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float* __restrict__ t
 // issue never overlap.  Blocks that lie wholly inside both matrices (all but the last row / column
 // block) take wave-uniform fast paths for the loads and the stores: no per-element predicates.
 constexpr int CT_BM = 128, CT_BN = 32, CT_KB = 128, CT_LD = CT_KB + 8;
+// Epilogue staging: a wave parks its 32 x 32 score block in LDS (row stride 36 floats: the accumulator
+// layout writes conflict-free) and writes it out as whole 128-byte row segments, 8 rows per store
+// instruction (4 store instructions per block instead of 16 that each touch four 64-byte pieces of four
+// rows 4 844 bytes apart).
+constexpr int CT_SLD = 36;
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access on a 4-byte boundary (row pitch 4 ns)
 
 // out[row] = 1 / ||x[row]||, a zero norm divides by 1 (sklearn normalize()).  One wave per row.
 __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__ x, int n, int dim,
@@ -109,8 +115,10 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
 template <bool HOIST>
 __device__ __forceinline__ void cosine_tiled_body(const float* __restrict__ test, const float* __restrict__ enroll,
                                                   const float* __restrict__ einv, int nt, int ns, int dim,
-                                                  float* __restrict__ out, long long total_units, float (&bs)[2][CT_BN * CT_LD]) {
+                                                  float* __restrict__ out, long long total_units, float (&bs)[2][CT_BN * CT_LD],
+                                                  float* __restrict__ stage_all) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* const stage = stage_all + wave * 32 * CT_SLD;  // private to this wave
   const int i = lane & 15, kk = lane >> 4;
   const int nkb = (dim + CT_KB - 1) / CT_KB;
   const bool vec_ok = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(test) | reinterpret_cast<uintptr_t>(enroll)) & 15) == 0;
@@ -179,8 +187,6 @@ __device__ __forceinline__ void cosine_tiled_body(const float* __restrict__ test
 #pragma unroll
     for (int r = 0; r < 4; ++r) rinv[rt][r] = 1.0f / __shfl(tn[rt], 4 * kk + r, 64);
   const bool rows_in = m0 + 32 <= nt;  // wave-uniform
-  // element offsets of this lane's first output of each (row tile, r): row (m0 + 16 rt + 4 kk + r), column i
-  float* const orow = out + (int64_t)(m0 + 4 * kk) * ns + i;
 
   f32x4 pre[4];
   fetch(st_begin, 0, pre);
@@ -235,31 +241,38 @@ __device__ __forceinline__ void cosine_tiled_body(const float* __restrict__ test
       __syncthreads();  // everyone is done with bs[cur]; bs[cur ^ 1] is complete
       cur ^= 1;
     }
-    float* const o = orow + st * CT_BN;
-    if (rows_in) {  // wave-uniform: all 32 rows are inside: 16 stores, masked by column only in the ragged last block
+    // Epilogue through LDS for every block, ragged ones included (the per-element path this replaces ran only
+    // in the corpus's LAST row block -- all of it in the last workgroup, which then finished ~10 % after the
+    // others -- and in the last column block).  One wave's DS instructions execute in order: fences only.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        if (st * CT_BN + 16 * ct + i < ns) {
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              o[(int64_t)(16 * rt + r) * ns + 16 * ct] = acc[rt][ct][r] * rinv[rt][r] * sinv[ct];
-        }
-      }
-    } else {
+        for (int r = 0; r < 4; ++r)
+          stage[(16 * rt + 4 * kk + r) * CT_SLD + 16 * ct + i] = acc[rt][ct][r] * rinv[rt][r] * sinv[ct];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int c4 = 4 * (lane & 7);
+    float* const ob = out + (int64_t)m0 * ns + st * CT_BN + c4;
+    const bool cols_in = (st + 1) * CT_BN <= ns;  // wave-uniform
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int col = st * CT_BN + 16 * ct + i;
-        if (col < ns) {
+    for (int j = 0; j < 4; ++j) {
+      const int row = (lane >> 3) + 8 * j;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * CT_SLD + c4);
+      if (rows_in || m0 + row < nt) {
+        float* const dst = ob + (int64_t)row * ns;
+        if (cols_in) {
+#ifdef SVK_COS_NOSTORE
+          if (v[0] == 123456.0f)
+#endif
+          *reinterpret_cast<f32x4_u*>(dst) = v;
+        } else {
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = m0 + 16 * rt + 4 * kk + r;
-              if (row < nt) out[(int64_t)row * ns + col] = acc[rt][ct][r] * rinv[rt][r] * sinv[ct];
-            }
-          }
+          for (int e = 0; e < 4; ++e)
+            if (st * CT_BN + c4 + e < ns) dst[e] = v[e];
         }
       }
     }
@@ -275,14 +288,16 @@ __global__ __launch_bounds__(256) void cosine_tiled_kernel(const float* __restri
                                                            const float* __restrict__ einv, int nt, int ns, int dim,
                                                            float* __restrict__ out, long long total_units) {
   __shared__ __attribute__((aligned(16))) float bs[2][CT_BN * CT_LD];
-  cosine_tiled_body<HOIST>(test, enroll, einv, nt, ns, dim, out, total_units, bs);
+  __shared__ __attribute__((aligned(16))) float stage[4 * 32 * CT_SLD];
+  cosine_tiled_body<HOIST>(test, enroll, einv, nt, ns, dim, out, total_units, bs, stage);
 }
 template <bool HOIST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void cosine_tiled_kernel_w3(
     const float* __restrict__ test, const float* __restrict__ enroll, const float* __restrict__ einv, int nt, int ns,
     int dim, float* __restrict__ out, long long total_units) {
   __shared__ __attribute__((aligned(16))) float bs[2][CT_BN * CT_LD];
-  cosine_tiled_body<HOIST>(test, enroll, einv, nt, ns, dim, out, total_units, bs);
+  __shared__ __attribute__((aligned(16))) float stage[4 * 32 * CT_SLD];
+  cosine_tiled_body<HOIST>(test, enroll, einv, nt, ns, dim, out, total_units, bs, stage);
 }
 
 __global__ __launch_bounds__(256) void l2_dist_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,

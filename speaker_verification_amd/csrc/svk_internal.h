@@ -17,6 +17,8 @@ struct svk_ctx {
   void* scratch = nullptr;  // 256 bytes of device memory for tiny reductions (svk_log_power)
   void* work = nullptr;     // grow-only device workspace owned by the handle (row norms of svk_cosine_scores)
   size_t work_bytes = 0;
+  void* comm = nullptr;     // RCCL communicator (svk_comm_init), or NULL
+  int comm_ranks = 0, comm_rank = 0;
   char err[512] = {0};
 };
 

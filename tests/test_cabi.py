@@ -77,3 +77,60 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_host_sanitizer_build(tmp_path):
+    """`make asan`: the HOST side of every translation unit under AddressSanitizer + UBSan (the
+    device code is compiled as usual -- there is no GPU sanitizer on this pool).  A child interpreter with the
+    ASan runtime preloaded loads that build through the normal binding and walks the entry points that need no
+    GPU: version, the pure host helpers, every NULL / bad-argument early return, the no-device path."""
+    import subprocess
+    import sys
+    csrc = os.path.join(REPO, "speaker_verification_amd", "csrc")
+    so = os.path.join(REPO, "speaker_verification_amd", "libsvk_asan.so")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))] + \
+           [os.path.join(REPO, "include", "svk.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.run(["make", "-C", csrc, "asan"], check=True, stdout=subprocess.DEVNULL)
+    runtime = subprocess.run(["/opt/rocm/bin/hipcc", "--print-file-name=libclang_rt.asan-x86_64.so"],
+                             stdout=subprocess.PIPE, check=True).stdout.decode().strip()
+    assert os.path.exists(runtime)
+    script = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+from speaker_verification_amd import _lib
+_lib.LIB_PATH = %r
+lib = _lib.load()
+assert lib.svk_version() == _lib.VERSION
+cfg = _lib.FrontendCfg(320, 160, 512, 40, 13, 2, 1, 0, 1, 0.98, 1.0)
+assert lib.svk_frontend_num_frames(ctypes.byref(cfg), 48000) == 298
+assert lib.svk_frontend_num_frames(None, 48000) == 0 and lib.svk_frontend_num_cols(None) == 0
+assert lib.svk_frontend_num_cols(ctypes.byref(cfg)) == 13
+h = ctypes.c_void_p()
+rc = lib.svk_create(0, ctypes.byref(h))
+assert rc in (0, -4), rc                       # -4 = SVK_ERR_NO_DEVICE here; 0 on a GPU box
+assert lib.svk_create(0, None) == -1
+for fn, args in (("svk_sync", (None,)), ("svk_set_stream", (None, None)), ("svk_malloc", (None, 16, None)),
+                 ("svk_memset", (None, None, 0, 4)), ("svk_device_info", (None, None)),
+                 ("svk_comm_unique_id", (None, None)), ("svk_comm_init", (None, None, 1, 0)),
+                 ("svk_allgather_f32", (None, None, None, 4)), ("svk_comm_destroy", (None,)),
+                 ("svk_comm_info", (None, None)), ("svk_cmvn", (None, None, 1, 1, 1, None, 0)),
+                 ("svk_cosine_scores", (None, None, None, 1, 1, 1, None)), ("svk_l2_dist", (None, None, None, 1, 1, None)),
+                 ("svk_spectrum", (None, None, 1, 1, 512, 1, None)), ("svk_preemphasis", (None, None, 0, 1, 1, 0.5, None)),
+                 ("svk_frontend_plan_create", (None, None, None, None)),
+                 ("svk_roc_eer", (None, None, None, 1, None, 0, None))):
+    assert getattr(lib, fn)(*args) == -1, fn   # SVK_ERR_BAD_ARG, no crash, nothing for ASan / UBSan to report
+assert lib.svk_last_error(None) == b"null context"
+assert lib.svk_roc_workspace_bytes(1000) > 0
+lib.svk_destroy(None); lib.svk_frontend_plan_destroy(None)
+if rc == 0:
+    lib.svk_destroy(h)
+print("asan walk ok")
+''' % (REPO, so)
+    env = dict(os.environ, LD_PRELOAD=runtime, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    proc = subprocess.run([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=600)
+    assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+    assert b"asan walk ok" in proc.stdout
+    assert b"runtime error" not in proc.stderr and b"AddressSanitizer" not in proc.stderr

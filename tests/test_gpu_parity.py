@@ -1132,3 +1132,77 @@ def test_cmvnw_long_clips_and_windows(eng):
     for u in range(3):
         np.testing.assert_allclose(got[u, :nfr[u]], ref.cmvnw(batch[u, :nfr[u]], 301, True), rtol=2e-4, atol=2e-5)
         np.testing.assert_array_equal(got[u, nfr[u]:], batch[u, nfr[u]:])
+
+
+def test_rccl_wrappers_single_rank(eng):
+    """svk_comm_* (SURVEY 8b's table): RCCL bound at run time; with one rank the all-gather is the identity.
+    (N > 1 needs N GPUs: the driver's scaling run covers it through torch.distributed, and the sharding /
+    padding logic around the collective runs on two gloo ranks in tests/test_distributed_cpu.py.)"""
+    import ctypes as C
+    from speaker_verification_amd import _lib
+    lib = eng.lib
+    info = (C.c_int32 * 2)()
+    _lib.check(lib.svk_comm_info(eng.ctx, info), eng.ctx)
+    assert info[0] == 0
+    with pytest.raises(_lib.SvkError, match="svk_comm_init first"):
+        _lib.check(lib.svk_allgather_f32(eng.ctx, None, None, 4), eng.ctx)
+    uid = C.create_string_buffer(128)
+    _lib.check(lib.svk_comm_unique_id(eng.ctx, uid), eng.ctx)
+    assert any(uid.raw)
+    _lib.check(lib.svk_comm_init(eng.ctx, uid, 1, 0), eng.ctx)
+    try:
+        _lib.check(lib.svk_comm_info(eng.ctx, info), eng.ctx)
+        assert (info[0], info[1]) == (1, 0)
+        with pytest.raises(_lib.SvkError, match="already has a communicator"):
+            _lib.check(lib.svk_comm_init(eng.ctx, uid, 1, 0), eng.ctx)
+        send = torch.randn(18581, 128, device=eng.device)                    # one rank's shard of 148 642 / 8
+        recv = torch.zeros_like(send)
+        eng._stream()
+        _lib.check(lib.svk_allgather_f32(eng.ctx, eng._ptr(send), eng._ptr(recv), send.numel()), eng.ctx)
+        eng.synchronize()
+        assert torch.equal(send, recv)
+    finally:
+        _lib.check(lib.svk_comm_destroy(eng.ctx), eng.ctx)
+    _lib.check(lib.svk_comm_info(eng.ctx, info), eng.ctx)
+    assert info[0] == 0
+
+
+def test_siamese_train_step_on_rocm(eng):
+    """SURVEY 8f-4 / train_siamese.py:37-175: one contrastive step (embed both cubes of each pair, `Siamese.forward`
+    loss = contrastive + LAMBDA * sum of parameter norms, backward, SGD) on the GPU against the SAME step on
+    torch-CPU: loss, every gradient and every updated parameter.  (`Siamese.forward` needs CUDA in the reference,
+    so its loss is pinned to the restated formula of oracle/scoring_ref.py, "parity unpinned" -- see its header.)"""
+    import copy
+    from speaker_verification_amd.model import seeded_model
+    from speaker_verification_amd.train_siamese import make_criterion, siamese_train_step
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(6, 1, 20, 80, 40, generator=g), torch.randn(6, 1, 20, 80, 40, generator=g)
+    y = torch.tensor([1.0, 0.0, 1.0, 0.0, 0.0, 1.0])
+    cpu_model = seeded_model(5, n_labels=4)
+    gpu_model = copy.deepcopy(cpu_model).to(eng.device)
+    crit = make_criterion(0.001, 2.0)
+    opt_c = torch.optim.SGD(cpu_model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    opt_g = torch.optim.SGD(gpu_model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    for step in range(2):
+        lc = siamese_train_step(cpu_model, crit, opt_c, a, b, y)
+        lg = siamese_train_step(gpu_model, crit, opt_g, a.to(eng.device), b.to(eng.device), y.to(eng.device))
+        assert lg == pytest.approx(lc, rel=2e-4 if step == 0 else 1e-2)
+        if step > 0:             # the second step starts from weights that already differ by rounding: loss only
+            break
+        # (a conv bias in front of a training-mode BatchNorm has a mathematically ZERO gradient: both sides hold
+        # rounding noise there, so the absolute tolerance is set by the gradient scale of the whole model)
+        gscale = max(float(p.grad.abs().max()) for p in cpu_model.parameters())
+        for (name, pc), pg in zip(cpu_model.named_parameters(), gpu_model.parameters()):
+            scale = max(float(pc.grad.abs().max()), 1e-3 * gscale)
+            torch.testing.assert_close(pg.grad.cpu(), pc.grad, rtol=2e-3, atol=2e-3 * scale, msg=lambda m: name + ": " + m)
+            # the update is lr * (momentum-filtered) gradient: the gradient tolerance times the learning rate
+            torch.testing.assert_close(pg.detach().cpu(), pc.detach(), rtol=1e-4,
+                                       atol=1e-6 + 0.01 * 4e-3 * scale * (step + 1), msg=lambda m: name + ": " + m)
+    # the loss itself against the restated formula (siamese.py:14-25)
+    gpu_model.eval()
+    with torch.no_grad():
+        o1, o2 = gpu_model(a.to(eng.device), development=False), gpu_model(b.to(eng.device), development=False)
+        loss = float(crit(gpu_model, y.to(eng.device), o1, o2))
+    norms = [float(torch.norm(p.detach())) for p in gpu_model.parameters()]
+    want = scoring_ref.contrastive_loss(y.numpy(), o1.cpu().numpy(), o2.cpu().numpy(), norms, 0.001, 2.0)
+    assert loss == pytest.approx(want, rel=1e-4)

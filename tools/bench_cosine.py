@@ -17,8 +17,11 @@ def main():
     from speaker_verification_amd.engine import get_engine
     eng = get_engine(0)
     res = {}
-    for name, (nt, ns, d) in {"verif_4874x40": (4874, 40, 128), "dev_148642x1211": (148642, 1211, 128),
-                              "square_16384": (16384, 16384, 128)}.items():
+    shapes = {"verif_4874x40": (4874, 40, 128), "dev_148642x1211": (148642, 1211, 128),
+              "square_16384": (16384, 16384, 128)}
+    if os.environ.get("SVK_COS_SHAPES"):    # e.g. "148642x1216,148480x1211"
+        shapes = {sh: tuple(int(v) for v in sh.split("x")) + (128,) for sh in os.environ["SVK_COS_SHAPES"].split(",")}
+    for name, (nt, ns, d) in shapes.items():
         t = torch.randn(nt, d, device=eng.device)
         e = torch.randn(ns, d, device=eng.device)
         for _ in range(3):
