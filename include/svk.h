@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 101 /* 0.1.1 */
+#define SVK_VERSION 102 /* 0.1.2 */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -234,6 +234,27 @@ int svk_l2_dist(svk_ctx* ctx, const float* d_a, const float* d_b, int32_t n, int
 size_t svk_roc_workspace_bytes(int64_t n);
 int svk_roc_eer(svk_ctx* ctx, const float* d_scores, const uint8_t* d_labels, int64_t n, void* d_workspace,
                 size_t workspace_bytes, double* h_out);
+
+/* ---- the first block of the embedding network ----------------------------------------------------
+ * model.py:110-117 + :141-150 (C3D2): cube (utils.py:351-379) -> conv1_1 (1 -> 16, kernel (3,1,5)) -> BN -> PReLU
+ * -> conv1_2 (16 -> 16, kernel (3,9,1), stride (1,2,1)) -> BN -> PReLU -> MaxPool3d((1,1,2)), eval mode, as ONE
+ * kernel on v_mfma_f32_16x16x4_f32 (exact f32): conv1_1's output (3.3 MB per cube) lives only in LDS.  The host
+ * folds the BatchNorm statistics into weights / biases and lays the operands out:
+ *   d_w1frag [4][64]    float: lane l = (channel l & 15, kq = l >> 4), row k = 4 jj + kq of the 16 x 16 conv1_1
+ *                       GEMM: k < 15 -> weight of tap (kd = k / 5, kw = k % 5), k = 15 -> bias of the channel
+ *   d_w2frag [27][64][4] float: lane (co = l & 15, kk = l >> 4), element e = W2[co][ci = 4 kk + e][kd][kh] of
+ *                       tap t = 9 kd + kh;   d_bias2 [16];   d_slope1 / d_slope2 [16] PReLU slopes per channel
+ * d_feat [n_utt][max_frames][40], d_crop_idx [n_utt][20] as for svk_cube_gather (crop -1 -> zero cube).
+ * d_out: the activation after the pool, float32, channels last:
+ *   folded = 0: [n_utt][16 d][36 h][18 w][16 c]
+ *   folded = 1: [n_utt][16 d][18 h/2][18 w][2 (h & 1)][16 c]   (= a (n, 32, 16, 18, 18) channels-last tensor:
+ *               the row-parity-in-channels form model.FusedEmbedder feeds conv2_1 / conv2_2)
+ * Geometry other than the 20 x 80 x 40 cube -> SVK_ERR_UNSUPPORTED (run those layers on the host framework). */
+size_t svk_c3d2_stage1_lds_bytes(void);
+int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                    const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const float* d_w1frag,
+                    const float* d_slope1, const float* d_w2frag, const float* d_bias2, const float* d_slope2,
+                    int32_t folded, float* d_out);
 
 /* ---- multi-GPU: the one exchange step of the path ------------------------------------------------
  * Utterances shard over the GPUs of a node with no data-path exchange until scoring; then every rank needs

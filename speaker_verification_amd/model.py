@@ -203,9 +203,54 @@ class FusedEmbedder:
             x = x.contiguous(memory_format=torch.channels_last_3d)
         return self._run(x, first_done=False)
 
-    def _run(self, x, first_done):
-        fold = None
+    # ---- the first block (conv1_1 .. pool1) as one libsvk kernel ------------------------------------
+    def stage1_tables(self):
+        """Operand fragments of `svk_c3d2_stage1` (csrc/c3d2.hip) from the BN-folded weights of conv1_1 / conv1_2,
+        or None when the first block is not C3D2's (1 -> 16 k(3,1,5); 16 -> 16 k(3,9,1) stride (1,2,1); pool).
+          w1frag [4][64]   : lane (channel = l & 15, kq = l >> 4), GEMM row k = 4 jj + kq: tap (k // 5, k % 5) of
+                             conv1_1, row 15 = its bias
+          w2frag [27][64][4]: lane (co = l & 15, kk = l >> 4), element e = W2[co][4 kk + e][kd][kh], tap = 9 kd + kh"""
+        hit = getattr(self, "_stage1", False)
+        if hit is not False:
+            return hit
+        self._stage1 = None
+        (w1, b1, s1, st1, p1, _), (w2, b2, s2, st2, p2, _) = self.stages[0], self.stages[1]
+        if (tuple(w1.shape) != (16, 1, 3, 1, 5) or tuple(w2.shape) != (16, 16, 3, 9, 1) or tuple(st1) != (1, 1, 1)
+                or tuple(st2) != (1, 2, 1) or p1 or not p2):
+            return None
+        dev = w1.device
+        lane = torch.arange(64, device=dev)
+        ch, kq = lane & 15, lane >> 4
+        w1frag = torch.empty((4, 64), dtype=torch.float32, device=dev)
+        w1c = w1.contiguous().view(16, 15)                                  # [co][kd * 5 + kw]
+        for jj in range(4):
+            k = 4 * jj + kq
+            w1frag[jj] = torch.where(k < 15, w1c[ch, k.clamp(max=14)], b1[ch])
+        w2c = w2.contiguous()[:, :, :, :, 0]                                # [co][ci][kd][kh]
+        w2frag = torch.empty((27, 64, 4), dtype=torch.float32, device=dev)
+        for kd in range(3):
+            for kh in range(9):
+                for e in range(4):
+                    w2frag[9 * kd + kh, :, e] = w2c[ch, 4 * kq + e, kd, kh]
+        self._stage1 = (w1frag.contiguous(), s1.expand(16).contiguous() if s1.numel() == 1 else s1.contiguous(),
+                        w2frag.contiguous(), b2.contiguous(),
+                        s2.expand(16).contiguous() if s2.numel() == 1 else s2.contiguous())
+        return self._stage1
+
+    @torch.no_grad()
+    def from_stage1(self, y, n):
+        """Embeddings from the output of `svk_c3d2_stage1` -- the activation after pool1, in the row-folded
+        channels-last layout [n][16][18][18][2][16] when `self.row_fold` exists, plain [n][16][36][18][16] otherwise."""
+        if self.row_fold is not None:
+            x = y.view(n, 16, 18, 18, 32).permute(0, 4, 1, 2, 3)           # (n, 32, 16, 18, 18), channels_last_3d memory
+            return self._run(x, start=2, fold=self.row_fold)
+        x = y.view(n, 16, 36, 18, 16).permute(0, 4, 1, 2, 3)
+        return self._run(x, start=2)
+
+    def _run(self, x, first_done=False, start=0, fold=None):
         for li, (w, b, slope, stride, pool, pool_first) in enumerate(self.stages):
+            if li < start:
+                continue
             groups = 1
             if li == 1 and self.row_fold is not None:
                 # rows fold only when conv1_2's output has an even number of rows that the stride-4 form reproduces

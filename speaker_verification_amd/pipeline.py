@@ -39,6 +39,9 @@ class VerificationPipeline:
         # The switch is process-global in torch: it is set around this pipeline's own network
         # calls only (`_find_mode`), not left on for the rest of the process.
         self.miopen_find = bool(miopen_find)
+        import os
+        # SVK_C3D2_STAGE1=0: run the first block on PyTorch-ROCm too (A/B and parity tests)
+        self.stage1_kernel = os.environ.get("SVK_C3D2_STAGE1", "1") != "0"
         self.model = model.to(self.eng.device).eval()
         self.fused_model, self.channels_last = fused_model, channels_last
         self.refresh_model()
@@ -137,6 +140,15 @@ class VerificationPipeline:
         """features + crop starts -> embeddings.  With the fused embedder the cube is never materialised:
         svk_cube_gather_windows writes the first layer's patch matrix straight from the feature rows
         (FusedEmbedder.from_windows); otherwise cube -> network."""
+        import os
+        tables = self.embedder.stage1_tables() if (self.embedder is not None and self.stage1_kernel) else None
+        if tables is not None and feat.shape[2] == c.NUM_COEF and crop_idx.shape[1] == c.CUBE_CROPS:
+            # conv1_1 .. pool1 in one libsvk kernel (csrc/c3d2.hip): the cube and conv1_1's 3.3 MB-per-cube output
+            # never reach HBM; PyTorch-ROCm runs the remaining six convolutions and the FC layer
+            folded = self.embedder.row_fold is not None
+            y = self.eng.c3d2_stage1(feat, crop_idx, tables, folded=folded, crop_frames=c.CUBE_FRAMES)
+            with self._find_mode():
+                return self.embedder.from_stage1(y, feat.shape[0])
         geo = self.embedder.first_layer_windows(c.CUBE_CROPS, feat.shape[2]) if self.embedder is not None else None
         if geo is not None:
             kd, kw, G = geo
@@ -197,7 +209,9 @@ class VerificationPipeline:
                 idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo,
                                           self.bad_clips)
                 geo = self.embedder.first_layer_windows(c.CUBE_CROPS, feat.shape[2]) if self.embedder is not None else None
-                if geo is not None and geo[2] % 4 == 0 and (geo[1] + geo[2] - 1) % 4 == 0 and feat.shape[2] % 4 == 0:
+                if self.embedder is not None and self.stage1_kernel and self.embedder.stage1_tables() is not None:
+                    cube = ("features", (feat, idx), 0, 0)      # the first-block kernel reads the feature rows itself
+                elif geo is not None and geo[2] % 4 == 0 and (geo[1] + geo[2] - 1) % 4 == 0 and feat.shape[2] % 4 == 0:
                     cube = ("windows", self.eng.cube_windows(feat, idx, c.CUBE_FRAMES, *geo), feat.shape[0], feat.shape[2])
                 else:
                     cube = ("cube", self.cubes(feat, idx), 0, 0)
@@ -212,8 +226,11 @@ class VerificationPipeline:
                 nxt = stage(k + 1)
             main.wait_event(done)
             kind, data, n_rows, n_cols = cube
-            data.record_stream(main)               # allocated on the side stream, consumed on the main one
-            if kind == "windows":
+            for t in (data if isinstance(data, tuple) else (data,)):
+                t.record_stream(main)              # allocated on the side stream, consumed on the main one
+            if kind == "features":
+                emb[lo:hi] = self.embed_features(*data)
+            elif kind == "windows":
                 with self._find_mode():
                     emb[lo:hi] = self.embedder.from_windows(data, n_rows, c.CUBE_CROPS, c.CUBE_FRAMES, n_cols)
             else:

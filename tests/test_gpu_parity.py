@@ -1206,3 +1206,73 @@ def test_siamese_train_step_on_rocm(eng):
     norms = [float(torch.norm(p.detach())) for p in gpu_model.parameters()]
     want = scoring_ref.contrastive_loss(y.numpy(), o1.cpu().numpy(), o2.cpu().numpy(), norms, 0.001, 2.0)
     assert loss == pytest.approx(want, rel=1e-4)
+
+
+def test_c3d2_first_block_kernel(eng):
+    """svk_c3d2_stage1 (cube -> conv1_1 -> BN -> PReLU -> conv1_2 -> BN -> PReLU -> pool1 in one MFMA kernel,
+    model.py:110-117,141-150) against the same layers of the CPU oracle's network (torch-CPU f32, unfolded
+    BatchNorm), both output layouts, with a too-short clip (crop -1 -> zero cube) and per-channel slopes."""
+    import torch.nn.functional as F
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    model = seeded_model(41, n_labels=8)
+    model.load_state_dict(perturb_inference_state(model.state_dict(), 42))
+    emb = model.to(eng.device).eval().fused_inference(channels_last=True)
+    tables = emb.stage1_tables()
+    assert tables is not None
+    rng = np.random.default_rng(3)
+    n, T = 5, 131
+    feat = (rng.standard_normal((n, T, 40)) * 2.0 - 6.0).astype(np.float32)
+    crops = rng.integers(0, T - 80, size=(n, 20)).astype(np.int32)
+    crops[3] = -1
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cubes = np.stack([model_ref.feature_cube(feat[u], np.maximum(crops[u], 0))[0] for u in range(n)])[:, None]
+    cubes[3] = 0.0
+    x = torch.from_numpy(cubes)
+    with torch.no_grad():
+        for tag, stride in (("1_1", (1, 1, 1)), ("1_2", (1, 2, 1))):
+            x = F.conv3d(x, state[f"conv{tag}.weight"], state[f"conv{tag}.bias"], stride=stride)
+            x = F.batch_norm(x, state[f"batch_norm{tag}.running_mean"], state[f"batch_norm{tag}.running_var"],
+                             state[f"batch_norm{tag}.weight"], state[f"batch_norm{tag}.bias"], training=False, eps=1e-5)
+            x = F.prelu(x, state[f"PReLu{tag}.weight"])
+        want = F.max_pool3d(x, kernel_size=(1, 1, 2), stride=(1, 1, 2)).numpy()          # (n, 16, 16, 36, 18)
+    scale = np.abs(want).max()
+    plain = eng.c3d2_stage1(feat, crops, tables, folded=False).cpu().numpy()             # [n][d][h][w][c]
+    np.testing.assert_allclose(plain.transpose(0, 4, 1, 2, 3), want, rtol=1e-4, atol=2e-6 * scale)
+    folded = eng.c3d2_stage1(feat, crops, tables, folded=True).cpu().numpy()             # [n][d][h/2][w][h&1][c]
+    unfold = folded.transpose(0, 1, 2, 4, 3, 5).reshape(n, 16, 36, 18, 16)
+    np.testing.assert_array_equal(unfold, plain)
+    # a negative and a per-channel slope: PReLU before the max, as the reference orders them
+    w1frag, s1, w2frag, b2, s2 = tables
+    s2n = torch.linspace(-0.5, 0.4, 16, device=eng.device)
+    got = eng.c3d2_stage1(feat, crops, (w1frag, s1, w2frag, b2, s2n), folded=False).cpu().numpy()
+    with torch.no_grad():
+        x1 = F.prelu(F.batch_norm(F.conv3d(torch.from_numpy(cubes), state["conv1_1.weight"], state["conv1_1.bias"]),
+                                  state["batch_norm1_1.running_mean"], state["batch_norm1_1.running_var"],
+                                  state["batch_norm1_1.weight"], state["batch_norm1_1.bias"], training=False, eps=1e-5),
+                     state["PReLu1_1.weight"])
+        x2 = F.batch_norm(F.conv3d(x1, state["conv1_2.weight"], state["conv1_2.bias"], stride=(1, 2, 1)),
+                          state["batch_norm1_2.running_mean"], state["batch_norm1_2.running_var"],
+                          state["batch_norm1_2.weight"], state["batch_norm1_2.bias"], training=False, eps=1e-5)
+        want_n = F.max_pool3d(F.prelu(x2, s2n.cpu()), kernel_size=(1, 1, 2), stride=(1, 1, 2)).numpy()
+    np.testing.assert_allclose(got.transpose(0, 4, 1, 2, 3), want_n, rtol=1e-4, atol=2e-6 * scale)
+
+
+def test_embeddings_with_and_without_the_first_block_kernel(eng, monkeypatch):
+    """The whole embedding path with svk_c3d2_stage1 equals the PyTorch-ROCm-only path (and both the CPU oracle)."""
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    model = seeded_model(43, n_labels=8)
+    model.load_state_dict(perturb_inference_state(model.state_dict(), 44))
+    pcm, _ = synth.corpus(3, 3)
+    with_k = VerificationPipeline(model, crop_rng="device", crop_seed=9, normalize=True, preemph_cof=0.98)
+    assert with_k.stage1_kernel
+    a = with_k.embed(pcm).cpu().numpy()
+    monkeypatch.setenv("SVK_C3D2_STAGE1", "0")
+    without = VerificationPipeline(model, crop_rng="device", crop_seed=9, normalize=True, preemph_cof=0.98)
+    assert not without.stage1_kernel
+    b = without.embed(pcm).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-6 * np.abs(b).max())
+    _, inter = without.embed(pcm, return_intermediates=True)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref_emb = model_ref.c3d2_embed(state, inter[0]["cube"].cpu().numpy()).numpy()
+    np.testing.assert_allclose(a, ref_emb, rtol=1e-3, atol=2e-5 * np.abs(ref_emb).max())
