@@ -256,6 +256,18 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
                     const float* d_slope1, const float* d_w2frag, const float* d_bias2, const float* d_slope2,
                     int32_t folded, float* d_out);
 
+/* The second block, model.py:119-124 + :151-158: conv2_1 (16 -> 32, kernel (3,1,4)) -> BN -> PReLU -> conv2_2
+ * (32 -> 32, kernel (3,8,1), stride (1,2,1)) -> BN -> PReLU -> MaxPool3d((1,1,2)), two f32-MFMA kernels with the
+ * input region of a work item in LDS and the weights in registers; epilogues carry bias, PReLU and the pool.
+ *   d_in     [n_utt][16][36][18][16]  = svk_c3d2_stage1's output with folded = 0
+ *   d_w21frag [2 nt][12 taps][64][4]  : lane (co = 16 nt + (l & 15), kk = l >> 4), e: W21[co][4 kk + e][kd][kw], tap 4 kd + kw
+ *   d_w22frag [2 nt][24 taps][2][64][4]: W22[co][16 chunk + 4 kk + e][kd][kh], tap 8 kd + kh;  biases / slopes [32]
+ *   d_act2   [n_utt][14][36][15][32]  scratch the caller provides (conv2_1's output)
+ *   d_out    [n_utt][12][15][7][32]   the activation after pool2, channels last                                  */
+int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_w21frag, const float* d_bias21,
+                    const float* d_slope21, const float* d_w22frag, const float* d_bias22, const float* d_slope22,
+                    float* d_act2, float* d_out);
+
 /* ---- multi-GPU: the one exchange step of the path ------------------------------------------------
  * Utterances shard over the GPUs of a node with no data-path exchange until scoring; then every rank needs
  * the enrolled embeddings: ONE all-gather of the [rows_per_rank][dim] float32 shards over RCCL / xGMI

@@ -241,3 +241,203 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// The second block: conv2_1 (16 -> 32, kernel (3,1,4)) + BN + PReLU, conv2_2 (32 -> 32, kernel (3,8,1),
+// stride (1,2,1)) + BN + PReLU + MaxPool3d((1,1,2))  (/root/reference/model.py:119-124, :151-158), two
+// kernels of the same shape as the matrix phase above: the input region of a work item is staged in LDS
+// as padded 'pixels' (one pixel = the channel vector of one (d, h, w) position), the weights of the
+// wave's output-channel tile(s) sit in registers, and the A operand of every tap is one ds_read_b128
+// at a fixed offset from the M tile's base address.
+// =====================================================================================================
+namespace {
+
+constexpr int S2_D = 16, S2_H = 36, S2_W = 18;       // input of conv2_1 (after pool1), 16 channels
+constexpr int A2_D = 14, A2_W = 15;                  // conv2_1 output (32 channels), rows = S2_H
+constexpr int O2_D = 12, O2_H = 15, O2_W = 7;        // after conv2_2 + pool2 (32 channels)
+
+// ---- conv2_1: taps along w.  Item = (cube, block of 4 rows h): all 14 output depths x 4 rows x 15 columns ----
+constexpr int C21_TH = 4;
+constexpr int C21_PIX = S2_D * C21_TH * S2_W;        // 1152 pixels of 16 channels, stored at 16 p + 4 (p >> 2)
+constexpr int C21_LDS_FLOATS = 17 * (C21_PIX + 4);
+
+struct Conv21Params {
+  const float* in;      // [n][16][36][18][16]
+  const f32x4* wfrag;   // [2 nt][12 taps][64]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: W[co][4 kk + e][kd][kw], tap = 4 kd + kw
+  const float* bias;    // [32]
+  const float* slope;   // [32]
+  float* out;           // [n][14][36][15][32]
+  int32_t n_utt;
+};
+
+__global__ __launch_bounds__(256, 2) void c3d2_conv21_kernel(const Conv21Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_c21[];
+  float* reg = smem_c21;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  f32x4 w[2][12];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int t = 0; t < 12; ++t) w[nt][t] = p.wfrag[(nt * 12 + t) * 64 + lane];
+  float b[2], sl[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    b[nt] = p.bias[16 * nt + i];
+    sl[nt] = p.slope[16 * nt + i];
+  }
+  const int n_items = p.n_utt * (S2_H / C21_TH);
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int u = item / (S2_H / C21_TH), hb = (item - u * (S2_H / C21_TH)) * C21_TH;
+    // stage: [16 d][4 rows][18 w][16 c], a 16-byte piece per thread and trip
+    const float* src = p.in + (int64_t)u * (S2_D * S2_H * S2_W * 16);
+    for (int e = threadIdx.x; e < C21_PIX * 4; e += 256) {
+      const int pix = e >> 2, piece = e & 3;
+      const int d = pix / (C21_TH * S2_W), rem = pix - d * (C21_TH * S2_W);  // rem = hl * 18 + w
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((int64_t)(d * S2_H + hb) * S2_W + rem) * 16 + 4 * piece);
+      *reinterpret_cast<f32x4*>(reg + 16 * pix + 4 * (pix >> 2) + 4 * piece) = v;
+    }
+    __syncthreads();
+    // 56 M tiles = (output depth d', row hl): 16 pixels w' = 0 .. 15 (15 is a dummy), 14 per wave
+    for (int tile = wave; tile < A2_D * C21_TH; tile += 4) {
+      const int dp = tile / C21_TH, hl = tile - dp * C21_TH;
+      const int p0 = (dp * C21_TH + hl) * S2_W + i;
+      // pixel p0 + kw sits at 16 (p0 + kw) + 4 ((p0 + kw) >> 2); a depth step is 72 pixels = 18 groups of 4
+      const float* ab[4];
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw) ab[kw] = reg + 16 * (p0 + kw) + 4 * ((p0 + kw) >> 2) + 4 * kk;
+      f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(ab[kw] + kd * (17 * C21_TH * S2_W));
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w[nt][kd * 4 + kw][e], acc[nt], 0, 0, 0);
+        }
+      // rows 4 kk + r = output column w'; column i = channel 16 nt + i
+      float* o = p.out + (((int64_t)u * A2_D + dp) * S2_H + hb + hl) * (A2_W * 32) + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int wq = 4 * kk + r;
+        if (wq < A2_W) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) o[wq * 32 + 16 * nt] = prelu(acc[nt][r] + b[nt], sl[nt]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- conv2_2 + pool2: taps along h (stride 2).  Item = (cube, pooled column j, half q of the output depths) ----
+constexpr int C22_TD = 6;                                  // output depths per item
+constexpr int C22_PIX = (C22_TD + 2) * 2 * S2_H;           // [8 d][2 w][36 h] pixels of 32 channels at 32 p + 4 (p >> 1)
+constexpr int C22_LDS_FLOATS = 34 * (C22_PIX + 4);
+
+struct Conv22Params {
+  const float* in;      // [n][14][36][15][32]
+  const f32x4* wfrag;   // [2 nt][24 taps][2 chunks][64]: e: W[16 nt + (l & 15)][16 chunk + 4 (l >> 4) + e][kd][kh], tap = 8 kd + kh
+  const float* bias;    // [32]
+  const float* slope;   // [32]
+  float* out;           // [n][12][15][7][32]
+  int32_t n_utt;
+};
+
+__global__ __launch_bounds__(256, 2) void c3d2_conv22_kernel(const Conv22Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_c22[];
+  float* reg = smem_c22;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int nt = wave & 1, half = wave >> 1;   // output channels 16 nt .., output depths 3 half .. 3 half + 2 of the item
+  f32x4 w[24][2];
+#pragma unroll
+  for (int t = 0; t < 24; ++t)
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) w[t][ch] = p.wfrag[((nt * 24 + t) * 2 + ch) * 64 + lane];
+  const float b = p.bias[16 * nt + i], sl = p.slope[16 * nt + i];
+  const int n_items = p.n_utt * (O2_W * 2);
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int u = item / (O2_W * 2), rem = item - u * (O2_W * 2), q = rem / O2_W, j = rem - q * O2_W;
+    // stage [8 d][36 h][2 w][32 c] of the input as pixels p = (dl * 2 + w) * 36 + h (h fastest)
+    const float* src = p.in + ((int64_t)u * A2_D + C22_TD * q) * (S2_H * A2_W * 32) + 2 * j * 32;
+    for (int e = threadIdx.x; e < C22_PIX * 8; e += 256) {
+      const int piece = e & 7, wq = (e >> 3) & 1, dh = e >> 4;   // dh = dl * 36 + h
+      const int dl = dh / S2_H, h = dh - dl * S2_H;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)dh * (A2_W * 32) + wq * 32 + 4 * piece);
+      const int pix = (dl * 2 + wq) * S2_H + h;
+      *reinterpret_cast<f32x4*>(reg + 32 * pix + 4 * (pix >> 1) + 4 * piece) = v;
+    }
+    __syncthreads();
+    for (int s = 0; s < 3; ++s) {
+      const int dp = 3 * half + s;                           // output depth inside the item
+      const int p0 = dp * 2 * S2_H + 2 * i;                  // column 0 of the pair; column 1 is 36 pixels on
+      const float* a0 = reg + 32 * p0 + 4 * (p0 >> 1) + 4 * kk;
+      const float* a1 = a0 + 34 * S2_H;
+      f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 8; ++kh)
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) {
+            const int off = 34 * (2 * S2_H * kd) + 32 * kh + 4 * (kh >> 1) + 16 * ch;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(a0 + off);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(a1 + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], w[kd * 8 + kh][ch][e], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], w[kd * 8 + kh][ch][e], acc1, 0, 0, 0);
+            }
+          }
+      // rows 4 kk + r = output row h'; pool over the column pair, PReLU first (model.py:156-158)
+      float* o = p.out + ((((int64_t)u * O2_D + C22_TD * q + dp) * O2_H) * O2_W + j) * 32 + 16 * nt + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int hq = 4 * kk + r;
+        if (hq < O2_H) o[(int64_t)hq * (O2_W * 32)] = fmaxf(prelu(acc0[r] + b, sl), prelu(acc1[r] + b, sl));
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_w21frag,
+                               const float* d_bias21, const float* d_slope21, const float* d_w22frag,
+                               const float* d_bias22, const float* d_slope22, float* d_act2, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_utt >= 0, "n_utt negative");
+  if (n_utt == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_in && d_w21frag && d_bias21 && d_slope21 && d_w22frag && d_bias22 && d_slope22 && d_act2 && d_out,
+              "NULL buffer");
+  SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_act2) |
+                     reinterpret_cast<uintptr_t>(d_w21frag) | reinterpret_cast<uintptr_t>(d_w22frag)) & 15) == 0,
+              "buffers must be 16-byte aligned");
+  SVK_REQUIRE(ctx, (int64_t)n_utt * 14 < ((int64_t)1 << 31), "too many cubes for one launch");
+  {
+    Conv21Params p{d_in, reinterpret_cast<const f32x4*>(d_w21frag), d_bias21, d_slope21, d_act2, n_utt};
+    const size_t lds = sizeof(float) * (size_t)C21_LDS_FLOATS;
+    SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(c3d2_conv21_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t items = (int64_t)n_utt * (S2_H / C21_TH);
+    hipLaunchKernelGGL(c3d2_conv21_kernel, dim3((unsigned)std::min<int64_t>(items, 2 * ctx->num_cu)), dim3(256), lds,
+                       ctx->stream, p);
+    SVK_LAUNCH_CHECK(ctx);
+  }
+  {
+    Conv22Params p{d_act2, reinterpret_cast<const f32x4*>(d_w22frag), d_bias22, d_slope22, d_out, n_utt};
+    const size_t lds = sizeof(float) * (size_t)C22_LDS_FLOATS;
+    SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(c3d2_conv22_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t items = (int64_t)n_utt * (O2_W * 2);
+    hipLaunchKernelGGL(c3d2_conv22_kernel, dim3((unsigned)std::min<int64_t>(items, 2 * ctx->num_cu)), dim3(256), lds,
+                       ctx->stream, p);
+    SVK_LAUNCH_CHECK(ctx);
+  }
+  return SVK_OK;
+}

@@ -431,6 +431,20 @@ class Engine:
                                        self._ptr(slope2), int(bool(folded)), self._ptr(out)), self.ctx)
         return out
 
+    def c3d2_stage2(self, act1, tables):
+        """svk_c3d2_stage2: [n, 16, 36, 18, 16] (svk_c3d2_stage1, folded = 0) -> conv2_1 -> conv2_2 -> pool2 with
+        their BN + PReLU -> [n, 12, 15, 7, 32] f32 (channels last)."""
+        torch = _torch()
+        n = act1.shape[0]
+        w21, b21, s21, w22, b22, s22 = tables
+        act2 = torch.empty((n, 14, 36, 15, 32), dtype=torch.float32, device=self.device)
+        out = torch.empty((n, 12, 15, 7, 32), dtype=torch.float32, device=self.device)
+        self._stream()
+        check(self.lib.svk_c3d2_stage2(self.ctx, self._ptr(act1), n, self._ptr(w21), self._ptr(b21), self._ptr(s21),
+                                       self._ptr(w22), self._ptr(b22), self._ptr(s22), self._ptr(act2), self._ptr(out)),
+              self.ctx)
+        return out
+
     def cosine_scores(self, test, enroll):
         torch = _torch()
         t = self.to_device(test, torch.float32)

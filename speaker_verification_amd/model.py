@@ -237,6 +237,50 @@ class FusedEmbedder:
                         s2.expand(16).contiguous() if s2.numel() == 1 else s2.contiguous())
         return self._stage1
 
+    def stage2_tables(self):
+        """Operand fragments of `svk_c3d2_stage2` (conv2_1 16 -> 32 k(3,1,4); conv2_2 32 -> 32 k(3,8,1) stride
+        (1,2,1) + pool), BN folded, or None when the layers differ:
+          w21frag [2 nt][12][64][4]   : lane (co = 16 nt + (l & 15), kk = l >> 4): W[co][4 kk + e][kd][kw], tap 4 kd + kw
+          w22frag [2 nt][24][2][64][4]: W[co][16 chunk + 4 kk + e][kd][kh], tap 8 kd + kh"""
+        hit = getattr(self, "_stage2", False)
+        if hit is not False:
+            return hit
+        self._stage2 = None
+        (w1, b1, s1, st1, p1, _), (w2, b2, s2, st2, p2, _) = self.stages[2], self.stages[3]
+        if (tuple(w1.shape) != (32, 16, 3, 1, 4) or tuple(w2.shape) != (32, 32, 3, 8, 1) or tuple(st1) != (1, 1, 1)
+                or tuple(st2) != (1, 2, 1) or p1 or not p2):
+            return None
+        dev = w1.device
+        lane = torch.arange(64, device=dev)
+        ch, kq = lane & 15, lane >> 4
+        a = w1.contiguous()[:, :, :, 0, :]                                   # [co][ci][kd][kw]
+        f21 = torch.empty((2, 12, 64, 4), dtype=torch.float32, device=dev)
+        for nt in range(2):
+            for kd in range(3):
+                for kw in range(4):
+                    for e in range(4):
+                        f21[nt, 4 * kd + kw, :, e] = a[16 * nt + ch, 4 * kq + e, kd, kw]
+        bmat = w2.contiguous()[:, :, :, :, 0]                                # [co][ci][kd][kh]
+        f22 = torch.empty((2, 24, 2, 64, 4), dtype=torch.float32, device=dev)
+        for nt in range(2):
+            for kd in range(3):
+                for kh in range(8):
+                    for chunk in range(2):
+                        for e in range(4):
+                            f22[nt, 8 * kd + kh, chunk, :, e] = bmat[16 * nt + ch, 16 * chunk + 4 * kq + e, kd, kh]
+
+        def per_channel(t, n):
+            return t.expand(n).contiguous() if t.numel() == 1 else t.contiguous()
+        self._stage2 = (f21.contiguous(), b1.contiguous(), per_channel(s1, 32), f22.contiguous(), b2.contiguous(),
+                        per_channel(s2, 32))
+        return self._stage2
+
+    @torch.no_grad()
+    def from_stage2(self, z, n):
+        """Embeddings from the output of `svk_c3d2_stage2`: the activation after pool2, [n][12][15][7][32]."""
+        x = z.view(n, 12, 15, 7, 32).permute(0, 4, 1, 2, 3)                 # (n, 32, 12, 15, 7), channels_last_3d memory
+        return self._run(x, start=4)
+
     @torch.no_grad()
     def from_stage1(self, y, n):
         """Embeddings from the output of `svk_c3d2_stage1` -- the activation after pool1, in the row-folded

@@ -42,6 +42,7 @@ class VerificationPipeline:
         import os
         # SVK_C3D2_STAGE1=0: run the first block on PyTorch-ROCm too (A/B and parity tests)
         self.stage1_kernel = os.environ.get("SVK_C3D2_STAGE1", "1") != "0"
+        self.stage2_kernel = self.stage1_kernel and os.environ.get("SVK_C3D2_STAGE2", "1") != "0"
         self.model = model.to(self.eng.device).eval()
         self.fused_model, self.channels_last = fused_model, channels_last
         self.refresh_model()
@@ -145,6 +146,13 @@ class VerificationPipeline:
         if tables is not None and feat.shape[2] == c.NUM_COEF and crop_idx.shape[1] == c.CUBE_CROPS:
             # conv1_1 .. pool1 in one libsvk kernel (csrc/c3d2.hip): the cube and conv1_1's 3.3 MB-per-cube output
             # never reach HBM; PyTorch-ROCm runs the remaining six convolutions and the FC layer
+            tables2 = self.embedder.stage2_tables() if self.stage2_kernel else None
+            if tables2 is not None:
+                # ... and conv2_1, conv2_2, pool2 in two more: PyTorch-ROCm runs conv3_1 .. FC5
+                y = self.eng.c3d2_stage1(feat, crop_idx, tables, folded=False, crop_frames=c.CUBE_FRAMES)
+                z = self.eng.c3d2_stage2(y, tables2)
+                with self._find_mode():
+                    return self.embedder.from_stage2(z, feat.shape[0])
             folded = self.embedder.row_fold is not None
             y = self.eng.c3d2_stage1(feat, crop_idx, tables, folded=folded, crop_frames=c.CUBE_FRAMES)
             with self._find_mode():
