@@ -59,19 +59,31 @@ struct Stage1Params {
 
 __device__ __forceinline__ float prelu(float v, float slope) { return v > 0.f ? v : slope * v; }
 
-// the item's cube patch: patch[dd][h][ww] = feat[u][crop[u][8 q + dd] + h][2 j + ww]
-__device__ __forceinline__ void fetch_patch(const Stage1Params& p, int item, f32x2 (&regs)[P_VEC]) {
-  const int u = item / 36, rem = item - u * 36, q = rem / 18, j = rem - q * 18;
-  const float* base = p.feat + (int64_t)u * p.max_frames * NCOEF + 2 * j;
+// The item's cube patch: patch[dd][h][ww] = feat[u][crop[u][8 q + dd] + h][2 j + ww].  A thread's s-th piece always
+// belongs to the same depth dd of the patch, whatever the item: its crop starts are loaded one item ahead
+// (fetch_starts) so that the feature loads of fetch_patch never wait for them inside the matrix work.
+__device__ __forceinline__ void fetch_starts(const Stage1Params& p, int item, int (&starts)[P_VEC]) {
+  const int u = item / 36, rem = item - u * 36, q = rem / 18;
   const int32_t* cr = p.crop + (int64_t)u * NCROP + TD * q;
+#pragma unroll
+  for (int s = 0; s < P_VEC; ++s) {
+    const int e = threadIdx.x + 256 * s;
+    starts[s] = e < P_FLOATS / 2 ? cr[(e / 3) / NFRAME] : -1;
+  }
+}
+
+__device__ __forceinline__ void fetch_patch(const Stage1Params& p, int item, const int (&starts)[P_VEC],
+                                            f32x2 (&regs)[P_VEC]) {
+  const int u = item / 36, rem = item - u * 36, j = rem % 18;
+  const float* base = p.feat + (int64_t)u * p.max_frames * NCOEF + 2 * j;
 #pragma unroll
   for (int s = 0; s < P_VEC; ++s) {
     const int e = threadIdx.x + 256 * s;  // float2 index: row = e / 3 (dd * 80 + h), piece = e % 3
     f32x2 v = (f32x2){0.f, 0.f};
     if (e < P_FLOATS / 2) {
       const int row = e / 3, piece = e - row * 3;
-      const int dd = row / NFRAME, h = row - dd * NFRAME;
-      const int start = cr[dd];
+      const int h = row % NFRAME;
+      const int start = starts[s];
       if (start >= 0 && start + h < p.max_frames)
         v = *reinterpret_cast<const f32x2*>(base + (int64_t)(start + h) * NCOEF + 2 * piece);
     }
@@ -112,31 +124,53 @@ __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) 
   const int pix_lane = (i >> 1) * PW + (i & 1);  // patch offset of this lane's pixel inside a conv1_1 tile (8 rows x 2 columns)
 
   f32x2 pre[P_VEC];
+  int starts[P_VEC];
   int item = blockIdx.x;
   if (item < n_items) {
-    fetch_patch(p, item, pre);
+    fetch_starts(p, item, starts);
+    fetch_patch(p, item, starts, pre);
     park_patch(patch, pre);
+    if (item + (int)gridDim.x < n_items) fetch_starts(p, item + gridDim.x, starts);
   }
   __syncthreads();
   for (; item < n_items; item += gridDim.x) {
     const int next = item + gridDim.x;
-    if (next < n_items) fetch_patch(p, next, pre);  // in flight during the matrix work below
+    if (next < n_items) {
+      fetch_patch(p, next, starts, pre);                                        // in flight during the matrix work below
+      if (next + (int)gridDim.x < n_items) fetch_starts(p, next + gridDim.x, starts);  // ... and the starts of the one after
+    }
+    __builtin_amdgcn_sched_barrier(0);  // all of those loads are ISSUED here, not trickled into the MFMA stream
 
-    // ---- conv1_1 + PReLU: 100 tiles of 16 pixels (8 rows x 2 columns of one depth), 25 per wave ----
-    for (int tt = wave; tt < DIN * 10; tt += 4) {
-      const int din = tt / 10, hb = (tt - din * 10) * 8;
-      const float* pp = patch + din * (NFRAME * PW) + hb * PW + pix_lane;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ---- conv1_1 + PReLU: 100 tiles of 16 pixels (8 rows x 2 columns of one depth), 25 per wave, five at a
+    // time: 20 gather reads in flight, then 20 MFMAs on five independent accumulators (a tile on its own is 4
+    // DEPENDENT MFMAs behind one LDS round trip) ----
+    for (int t0 = wave; t0 < DIN * 10; t0 += 20) {
+      float av[5][4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        float a = pp[tapoff[jj]];
-        if (jj == 3) a = bias_lane ? 1.0f : a;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w1[jj], acc, 0, 0, 0);
+      for (int q5 = 0; q5 < 5; ++q5) {
+        const int tt = t0 + 4 * q5;
+        const int din = tt / 10, hb = (tt - din * 10) * 8;
+        const float* pp = patch + din * (NFRAME * PW) + hb * PW + pix_lane;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) av[q5][jj] = pp[tapoff[jj]];
+        av[q5][3] = bias_lane ? 1.0f : av[q5][3];
       }
-      // rows 4 kk + r of the tile = pixels p0 + 4 kk + r, column i = channel; p0 = (din * 80 + hb) * 2 (a multiple of 16)
-      float* ap = act + 17 * ((din * NFRAME + hb) * 2) + 68 * kk + i;
+      f32x4 acc1[5];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ap[16 * r] = prelu(acc[r], sl1);
+      for (int q5 = 0; q5 < 5; ++q5) acc1[q5] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int q5 = 0; q5 < 5; ++q5) acc1[q5] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q5][jj], w1[jj], acc1[q5], 0, 0, 0);
+#pragma unroll
+      for (int q5 = 0; q5 < 5; ++q5) {
+        const int tt = t0 + 4 * q5;
+        const int din = tt / 10, hb = (tt - din * 10) * 8;
+        // rows 4 kk + r of the tile = pixels p0 + 4 kk + r, column i = channel; p0 = (din * 80 + hb) * 2 (a multiple of 16)
+        float* ap = act + 17 * ((din * NFRAME + hb) * 2) + 68 * kk + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ap[16 * r] = prelu(acc1[q5][r], sl1);
+      }
     }
     __syncthreads();  // act1 is complete; the patch buffer is free
 
@@ -155,17 +189,30 @@ __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) 
         ab[s] = act + 16 * pix + 4 * (din0 * 40 + 4 * hg + hl) + 4 * kk;
         acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
+      // tap t's fragments are read while tap t - 1's twelve MFMAs run (the scheduler, left alone, issues the reads
+      // two MFMAs before their first use: an LDS round trip exposed per tap)
+      f32x4 a[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) a[s] = *reinterpret_cast<const f32x4*>(ab[s]);
 #pragma unroll
       for (int t = 0; t < N_TAPS; ++t) {
-        const int kd = t / 9, kh = t - kd * 9;
-        const int off = 2720 * kd + 32 * kh + 4 * (kh >> 1);  // 16 dp + 4 d(p >> 2) for dp = 160 kd + 2 kh pixels
-        f32x4 a[3];
+        f32x4 an[3];
+        if (t + 1 < N_TAPS) {
+          const int kd = (t + 1) / 9, kh = (t + 1) - kd * 9;
+          const int off = 2720 * kd + 32 * kh + 4 * (kh >> 1);  // 16 dp + 4 d(p >> 2) for dp = 160 kd + 2 kh pixels
 #pragma unroll
-        for (int s = 0; s < 3; ++s) a[s] = *reinterpret_cast<const f32x4*>(ab[s] + off);
+          for (int s = 0; s < 3; ++s) an[s] = *reinterpret_cast<const f32x4*>(ab[s] + off);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the next tap's three LDS reads stay in front of this tap's MFMAs
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int s = 0; s < 3; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][e], w2[t][e], acc[s], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < N_TAPS) {
+#pragma unroll
+          for (int s = 0; s < 3; ++s) a[s] = an[s];
+        }
       }
       // rows 4 kk + r: depth dl' = kk >> 1, row hl' = 2 (kk & 1) + (r >> 1), column r & 1: pool = max over r pairs
 #pragma unroll
