@@ -16,8 +16,11 @@ and --gpus N > 1 this process only starts N fresh rank processes of itself (RANK
 WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), relays rank 0's JSON line and exits with the worst code.
 
 The JSON line also carries
-  roofline      -- the fused front-end kernel (the dominant HAND-WRITTEN kernel): algorithmic HBM bytes
-                   of the launches it actually ran (VAD-shortened clips) over their HIP-event durations;
+  roofline      -- the dominant kernel, hand-written: c3d2_stage1_kernel (cube + conv1_1 + conv1_2 + pool1 on f32
+                   MFMA, ~40 % of the step): algorithmic FLOPs per launch over the HIP-event duration of each launch
+                   in the timed region, against the 157.3 TFLOP/s f32 matrix peak;  roofline_stage2: conv2_1 + conv2_2;
+  roofline_frontend -- the fused front-end kernel (HBM roof): algorithmic HBM bytes of the launches it actually
+                   ran (VAD-shortened clips) over their HIP-event durations;
   roofline_e2e  -- the whole step against the f32 matrix peak: value x 0.6766 GFLOP (the C3D2 forward is
                    95 % of the step) / 157.3 TFLOP/s -- the ceiling SURVEY 8(d) names (232 k utt/s/GPU);
   ranks_seen / backend / allgather_us -- what torch.distributed reports and the HIP-event time of the
@@ -44,6 +47,8 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA peak
 C3D2_GFLOP_PER_UTT = 0.6766      # 338.3 M multiply-adds per cube
+STAGE1_GFLOP_PER_UTT = 2 * (12.4416 + 143.327232) / 1e3   # conv1_1 12.44 M + conv1_2 143.33 M multiply-adds
+STAGE2_GFLOP_PER_UTT = 2 * (46.44864 + 66.3552) / 1e3     # conv2_1 46.45 M + conv2_2 66.36 M
 N_CORPUS = 148642                # VoxCeleb1 dev utterances (README.md:5-7) = BASELINE configs[4]
 N_TEST, N_TEST_SPK = 4874, 40    # VoxCeleb1 verification split (README.md:4-7)
 UTTS_PER_SPK = 123
@@ -582,6 +587,7 @@ def main():
 
     def one_step(record):
         # timed region: everything from resident PCM to the score matrix
+        pipe.kernel_events = [] if record and pipe.kernel_events is None else pipe.kernel_events
         local = torch.empty((n_local, 128), dtype=torch.float32, device=dev)
         for lo, hi in spans:
             chunk = pcm[lo:hi]
@@ -647,11 +653,46 @@ def main():
         avg_launch_s = float(fe_ms.mean()) * 1e-3
         gbs = bytes_per_launch / avg_launch_s / 1e9
         traffic, traffic_src = pmc_traffic("frontend_kernel<int16,nfft1024>")
+        kernel_events, pipe.kernel_events = pipe.kernel_events, None   # stop recording: the rest is outside the timed region
         labels = (spk_all[:n_test, None] == ids[None, :]).astype(np.float64)
         sc = scores.cpu().numpy().astype(np.float64)
         eer, auc, _, _ = evaluation.get_eer_auc(labels.flatten(), sc.flatten())
         eer_dev, auc_dev = evaluation.get_eer_auc_device(labels, scores)       # svk_roc_eer on the same matrix
         e2e_tflops = value * C3D2_GFLOP_PER_UTT / 1e3
+        frontend_roofline = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                             "traffic_note": "PMC pass ran this kernel on 1 024 FULL 3 s clips per launch "
+                                             "(algorithmic 146 964 480 B); `achieved` uses the VAD-shortened bytes of "
+                                             "the launches timed here",
+                             "kernel": "frontend_kernel<int16,nfft1024>", "avg_launch_ms": avg_launch_s * 1e3,
+                             "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+                             "full_clip_bytes_per_utt": 48000 * 2 + 297 * 40 * 4,
+                             "share_of_step": float(fe_ms.sum()) / args.steps / ms_per_step}
+        main_roofline = frontend_roofline
+        stage2_roofline = None
+        if kernel_events:
+            # the dominant hand-written kernel is now the network's first block (csrc/c3d2.hip): MFMA-bound.
+            # achieved = SURVEY 8(a)'s multiply-adds of conv1_1 + conv1_2 per cube x cubes per launch x 2 / the
+            # HIP-event duration of each launch inside the timed region (events on the launch stream)
+            s1_ms = np.array([ev[0].elapsed_time(ev[1]) for ev, _ in kernel_events])
+            s2_ms = np.array([ev[1].elapsed_time(ev[2]) for ev, _ in kernel_events])
+            cubes = np.array([n for _, n in kernel_events], dtype=np.float64)
+            tf1 = float((cubes * STAGE1_GFLOP_PER_UTT).sum() / s1_ms.sum())          # GFLOP / ms = TFLOP/s
+            tf2 = float((cubes * STAGE2_GFLOP_PER_UTT).sum() / s2_ms.sum())
+            main_roofline = {"bound": "mfma", "achieved": tf1, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf1 / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                             "kernel": "c3d2_stage1_kernel (cube + conv1_1 + conv1_2 + pool1, v_mfma_f32_16x16x4_f32)",
+                             "avg_launch_ms": float(s1_ms.mean()), "cubes_per_launch": float(cubes.mean()),
+                             "algorithmic_gflop_per_cube": STAGE1_GFLOP_PER_UTT,
+                             "issued_over_algorithmic": (143.327232 + 12.4416 * 1.25 * 16 / 15) / (143.327232 + 12.4416),
+                             "share_of_step": float(s1_ms.sum()) / args.steps / ms_per_step,
+                             "note": "f32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md); the kernel also issues 1.25 x "
+                                     "16/15 of conv1_1's products (depth halo recomputed per item, K padded 15 -> 16)"}
+            stage2_roofline = {"bound": "mfma", "achieved": tf2, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf2 / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "c3d2_conv21_kernel + c3d2_conv22_kernel (conv2_1, conv2_2 + pool2)",
+                               "avg_launch_ms": float(s2_ms.mean()), "algorithmic_gflop_per_cube": STAGE2_GFLOP_PER_UTT,
+                               "share_of_step": float(s2_ms.sum()) / args.steps / ms_per_step}
         result = {
             "metric": "utterances/sec (MFCC->embed->cosine)", "value": value, "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -667,21 +708,16 @@ def main():
             "backend": ("rccl (torch 'nccl')" if args.backend == "nccl" else "gloo") if use_dist else None,
             "allgather_us": float(np.median([a.elapsed_time(b) for a, b in ag_events])) * 1e3 if use_dist else None,
             "allgather_bytes_per_rank": svdist.shard_rows(n_total, world) * 128 * 4,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_note": "PMC pass ran this kernel on 1 024 FULL 3 s clips per launch "
-                                         "(algorithmic 146 964 480 B); `achieved` uses the VAD-shortened bytes of "
-                                         "the launches timed here",
-                         "kernel": "frontend_kernel<int16,nfft1024>", "avg_launch_ms": avg_launch_s * 1e3,
-                         "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "full_clip_bytes_per_utt": 48000 * 2 + 297 * 40 * 4,
-                         "frontend_share_of_step": float(fe_ms.sum()) / args.steps / ms_per_step},
+            "roofline": main_roofline,
+            "roofline_frontend": frontend_roofline,
+            "roofline_stage2": stage2_roofline,
             "roofline_e2e": {"bound": "mfma", "achieved": e2e_tflops, "peak": F32_MATRIX_PEAK_TFLOPS * world,
                              "unit": "TFLOP/s", "frac": e2e_tflops / (F32_MATRIX_PEAK_TFLOPS * world),
                              "gflop_per_utt": C3D2_GFLOP_PER_UTT,
                              "note": "whole step vs the dense f32 matrix peak of the N GPUs: the C3D2 forward "
-                                     "(676.6 MFLOP per utterance, PyTorch-ROCm / MIOpen) is ~95 % of the step; "
-                                     "SURVEY 8(d) ceiling = 232 k utt/s per GPU"},
+                                     "(676.6 MFLOP per utterance: conv1_1 .. pool2 in libsvk MFMA kernels, conv3_1 .. FC5 "
+                                     "on PyTorch-ROCm / MIOpen) is ~95 % of the step; SURVEY 8(d) ceiling = 232 k utt/s "
+                                     "per GPU"},
             "eer": {"eer": eer, "auc": auc, "eer_device": eer_dev, "auc_device": auc_dev, "pairs": int(labels.size),
                     "short_clips": bad},
         }

@@ -354,17 +354,20 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21_kernel(const Conv21Params 
 #pragma unroll
       for (int kw = 0; kw < 4; ++kw) ab[kw] = reg + 16 * (p0 + kw) + 4 * ((p0 + kw) >> 2) + 4 * kk;
       f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+      // tap t + 1's fragment is read in front of tap t's eight MFMAs (fenced: see the stage-1 tap loop)
+      f32x4 a = *reinterpret_cast<const f32x4*>(ab[0]);
 #pragma unroll
-      for (int kd = 0; kd < 3; ++kd)
+      for (int t = 0; t < 12; ++t) {
+        f32x4 an;
+        if (t + 1 < 12) an = *reinterpret_cast<const f32x4*>(ab[(t + 1) & 3] + ((t + 1) >> 2) * (17 * C21_TH * S2_W));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kw = 0; kw < 4; ++kw) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(ab[kw] + kd * (17 * C21_TH * S2_W));
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w[nt][kd * 4 + kw][e], acc[nt], 0, 0, 0);
-        }
+          for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w[nt][t][e], acc[nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < 12) a = an;
+      }
       // rows 4 kk + r = output column w'; column i = channel 16 nt + i
       float* o = p.out + (((int64_t)u * A2_D + dp) * S2_H + hb + hl) * (A2_W * 32) + i;
 #pragma unroll
@@ -425,21 +428,29 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22_kernel(const Conv22Params 
       const float* a0 = reg + 32 * p0 + 4 * (p0 >> 1) + 4 * kk;
       const float* a1 = a0 + 34 * S2_H;
       f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      // step = (tap, 16-channel chunk): the next step's two fragments are read in front of this step's eight MFMAs
+      f32x4 x0 = *reinterpret_cast<const f32x4*>(a0), x1 = *reinterpret_cast<const f32x4*>(a1);
 #pragma unroll
-      for (int kd = 0; kd < 3; ++kd)
+      for (int st = 0; st < 48; ++st) {
+        f32x4 n0, n1;
+        if (st + 1 < 48) {
+          const int t = (st + 1) >> 1, ch = (st + 1) & 1, kd = t >> 3, kh = t & 7;
+          const int off = 34 * (2 * S2_H * kd) + 32 * kh + 4 * (kh >> 1) + 16 * ch;
+          n0 = *reinterpret_cast<const f32x4*>(a0 + off);
+          n1 = *reinterpret_cast<const f32x4*>(a1 + off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kh = 0; kh < 8; ++kh)
-#pragma unroll
-          for (int ch = 0; ch < 2; ++ch) {
-            const int off = 34 * (2 * S2_H * kd) + 32 * kh + 4 * (kh >> 1) + 16 * ch;
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(a0 + off);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(a1 + off);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], w[kd * 8 + kh][ch][e], acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], w[kd * 8 + kh][ch][e], acc1, 0, 0, 0);
-            }
-          }
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], w[st >> 1][st & 1][e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], w[st >> 1][st & 1][e], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < 48) {
+          x0 = n0;
+          x1 = n1;
+        }
+      }
       // rows 4 kk + r = output row h'; pool over the column pair, PReLU first (model.py:156-158)
       float* o = p.out + ((((int64_t)u * O2_D + C22_TD * q + dp) * O2_H) * O2_W + j) * 32 + 16 * nt + i;
 #pragma unroll

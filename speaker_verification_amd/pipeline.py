@@ -43,6 +43,8 @@ class VerificationPipeline:
         # SVK_C3D2_STAGE1=0: run the first block on PyTorch-ROCm too (A/B and parity tests)
         self.stage1_kernel = os.environ.get("SVK_C3D2_STAGE1", "1") != "0"
         self.stage2_kernel = self.stage1_kernel and os.environ.get("SVK_C3D2_STAGE2", "1") != "0"
+        # bench.py sets this to a list: HIP events (on the launch stream) around the first- and second-block kernels
+        self.kernel_events = None
         self.model = model.to(self.eng.device).eval()
         self.fused_model, self.channels_last = fused_model, channels_last
         self.refresh_model()
@@ -149,8 +151,17 @@ class VerificationPipeline:
             tables2 = self.embedder.stage2_tables() if self.stage2_kernel else None
             if tables2 is not None:
                 # ... and conv2_1, conv2_2, pool2 in two more: PyTorch-ROCm runs conv3_1 .. FC5
+                rec = self.kernel_events is not None
+                if rec:
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    ev[0].record()
                 y = self.eng.c3d2_stage1(feat, crop_idx, tables, folded=False, crop_frames=c.CUBE_FRAMES)
+                if rec:
+                    ev[1].record()
                 z = self.eng.c3d2_stage2(y, tables2)
+                if rec:
+                    ev[2].record()
+                    self.kernel_events.append((ev, feat.shape[0]))
                 with self._find_mode():
                     return self.embedder.from_stage2(z, feat.shape[0])
             folded = self.embedder.row_fold is not None
