@@ -69,6 +69,8 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel side benches (profiling runs)")
     ap.add_argument("--frontend-only", action="store_true", help="time BASELINE config 2 only (for rocprof)")
     ap.add_argument("--stages-only", action="store_true", help="time the stage-level kernels only (for rocprof)")
+    ap.add_argument("--c3d2-only", action="store_true",
+                    help="features of 1 024 clips once, then the network (libsvk blocks 1-2 + PyTorch rest) K times (for rocprof --pmc)")
     ap.add_argument("--backend", default=os.environ.get("SVK_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="gloo: rehearse N ranks on ONE GPU (RCCL refuses two ranks on a device)")
     ap.add_argument("--selftest", action="store_true",
@@ -561,6 +563,17 @@ def main():
                           "cosine_mfma": cosine_mfma_bench(eng, torch)}))
         return 0
 
+    if args.c3d2_only:
+        pcm, _ = synth.corpus_device(1024, dev, first_clip=0, utts_per_speaker=UTTS_PER_SPK)
+        pipe = VerificationPipeline(seeded_model(2024, n_labels=1211), use_vad=not args.no_vad, normalize=not args.no_cmvn,
+                                    preemph_cof=None if args.no_preemph else 0.98, crop_rng="device", micro_batch=1024)
+        voiced, vlen = pipe.voiced(pcm)
+        feat, n_frames = pipe.features(voiced, vlen)
+        idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, 0, pipe.bad_clips)
+        ms = _median_ms(torch, lambda: pipe.embed_features(feat, idx), max(args.steps, 5))
+        print(json.dumps({"workload": "1024 cubes: svk_c3d2_stage1 + svk_c3d2_stage2 + conv3_1 .. FC5 (PyTorch-ROCm)",
+                          "ms": ms, "utt_per_s": 1024 / ms * 1e3, "tflops": 1024 * C3D2_GFLOP_PER_UTT / ms}))
+        return 0
     n_total = args.corpus
     lo_r, hi_r = svdist.shard_bounds(n_total, world, rank)
     n_local = hi_r - lo_r

@@ -303,8 +303,9 @@ constexpr int S2_D = 16, S2_H = 36, S2_W = 18;       // input of conv2_1 (after 
 constexpr int A2_D = 14, A2_W = 15;                  // conv2_1 output (32 channels), rows = S2_H
 constexpr int O2_D = 12, O2_H = 15, O2_W = 7;        // after conv2_2 + pool2 (32 channels)
 
-// ---- conv2_1: taps along w.  Item = (cube, block of 4 rows h): all 14 output depths x 4 rows x 15 columns ----
-constexpr int C21_TH = 4;
+// ---- conv2_1: taps along w.  Item = (cube, block of C21_TH rows h): all 14 output depths x C21_TH rows x 15 columns
+// (2 rows: 39 KB of LDS per workgroup, three workgroups per CU cover each other's staging; 4 rows / two per CU: 7 % slower) ----
+constexpr int C21_TH = 2;
 constexpr int C21_PIX = S2_D * C21_TH * S2_W;        // 1152 pixels of 16 channels, stored at 16 p + 4 (p >> 2)
 constexpr int C21_LDS_FLOATS = 17 * (C21_PIX + 4);
 
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21_kernel(const Conv21Params 
       *reinterpret_cast<f32x4*>(reg + 16 * pix + 4 * (pix >> 2) + 4 * piece) = v;
     }
     __syncthreads();
-    // 56 M tiles = (output depth d', row hl): 16 pixels w' = 0 .. 15 (15 is a dummy), 14 per wave
+    // M tiles = (output depth d', row hl): 16 pixels w' = 0 .. 15 (15 is a dummy), 14 x C21_TH / 4 per wave
     for (int tile = wave; tile < A2_D * C21_TH; tile += 4) {
       const int dp = tile / C21_TH, hl = tile - dp * C21_TH;
       const int p0 = (dp * C21_TH + hl) * S2_W + i;
@@ -483,8 +484,12 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(c3d2_conv21_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t items = (int64_t)n_utt * (S2_H / C21_TH);
-    hipLaunchKernelGGL(c3d2_conv21_kernel, dim3((unsigned)std::min<int64_t>(items, 2 * ctx->num_cu)), dim3(256), lds,
-                       ctx->stream, p);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(c3d2_conv21_kernel), 256, lds) !=
+            hipSuccess || per_cu < 1)
+      per_cu = 2;
+    hipLaunchKernelGGL(c3d2_conv21_kernel, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(256),
+                       lds, ctx->stream, p);
     SVK_LAUNCH_CHECK(ctx);
   }
   {
@@ -493,8 +498,12 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(c3d2_conv22_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t items = (int64_t)n_utt * (O2_W * 2);
-    hipLaunchKernelGGL(c3d2_conv22_kernel, dim3((unsigned)std::min<int64_t>(items, 2 * ctx->num_cu)), dim3(256), lds,
-                       ctx->stream, p);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(c3d2_conv22_kernel), 256, lds) !=
+            hipSuccess || per_cu < 1)
+      per_cu = 2;
+    hipLaunchKernelGGL(c3d2_conv22_kernel, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(256),
+                       lds, ctx->stream, p);
     SVK_LAUNCH_CHECK(ctx);
   }
   return SVK_OK;

@@ -8,16 +8,23 @@ set -e
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-echo "[1/5] kernel trace + stats of the end-to-end bench"
+echo "[1/6] kernel trace + stats of the end-to-end bench"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bench -- python3 $root/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
-echo "[2/5] HBM read / write counters"
+echo "[2/6] HBM read / write counters"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --frontend-only > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py --frontend-only > $out/pmc_write.log 2>&1
-echo "[3/5] SQ counters"
+echo "[3/6] SQ counters"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_sq -- python3 $root/bench.py --frontend-only > $out/pmc_sq.log 2>&1
-echo "[4/5] stall composition"
+echo "[4/6] stall composition"
 bash $root/tools/pmc_stalls.sh final
 cd /tmp
-echo "[5/5] the bench itself"
+echo "[5/6] the network kernels (libsvk blocks 1-2): HBM counters + stall composition over bench.py --c3d2-only"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_c3d2 -- python3 $root/bench.py --c3d2-only > $out/pmc_fetch_c3d2.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_c3d2 -- python3 $root/bench.py --c3d2-only > $out/pmc_write_c3d2.log 2>&1
+bash $root/tools/pmc_stalls.sh c3d2 bench.py --c3d2-only
+cd /tmp
+echo "[6/6] the bench itself + the stage-level kernels"
 python3 $root/bench.py --steps 3 --warmup 1 > $out/bench_final.json 2> $out/bench_final.err
+python3 $root/bench.py --stages-only > $out/stages_final.json 2> $out/stages_final.err
+python3 $root/tools/prune_prof.py $out      # per-dispatch traces and other libraries' counter rows do not travel back
 echo done

@@ -19,7 +19,9 @@ from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OURS = ("frontend_kernel", "cmvn_kernel", "vad_kernel", "cube_gather_kernel", "cosine_kernel", "cosine_tiled_kernel",
-        "inv_norm_kernel", "draw_crops_kernel", "cube_windows_kernel", "cube_windows_c3d2_kernel", "decimate_kernel", "resample_kernel")
+        "inv_norm_kernel", "draw_crops_kernel", "cube_windows_kernel", "cube_windows_c3d2_kernel", "decimate_kernel", "resample_kernel",
+        "c3d2_stage1_kernel", "c3d2_conv21_kernel", "c3d2_conv22_kernel", "cmvnw_kernel", "spectrum_pow2_kernel",
+        "spectrum_dft_kernel", "spectrum_fft_kernel", "mel_features_kernel")
 
 
 def short(name):
@@ -50,7 +52,7 @@ def main():
         print("wrote", f"profiles/{tag}_bench_kernel_stats.csv", len(keep) - 1, "kernels")
     summary = defaultdict(lambda: defaultdict(list))
     meta = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_c3d2", "pmc_write_c3d2", "pmc_sq_c3d2"):
         paths = sorted(glob.glob(os.path.join(REPO, "gpurun_out", sub, "**", "*_counter_collection.csv"),
                                  recursive=True), key=os.path.getmtime)
         for path in paths[-1:]:                             # newest run only
@@ -59,7 +61,7 @@ def main():
                 if not k:
                     continue
                 summary[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-                summary[k].setdefault("duration_ns_" + sub, []).append(
+                summary[k].setdefault("duration_ns_" + sub.replace("_c3d2", ""), []).append(
                     int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
                 meta[k] = {"grid_size": int(row["Grid_Size"]), "workgroup_size": int(row["Workgroup_Size"]),
                            "vgpr": int(row["VGPR_Count"]), "accum_vgpr": int(row["Accum_VGPR_Count"]),
@@ -81,8 +83,8 @@ def main():
         result[k] = rec
     if result:
         result["_note"] = ("per-launch averages from separate rocprofv3 --pmc passes over `bench.py --frontend-only` "
-                           "(1024 x 3 s clips per launch); FETCH_SIZE/WRITE_SIZE in KiB, read side doubled per the "
-                           "gfx950 correction")
+                           "(1024 x 3 s clips per launch) and, for the c3d2_* kernels, `bench.py --c3d2-only` (1024 cubes "
+                           "per launch); FETCH_SIZE/WRITE_SIZE in KiB, read side doubled per the gfx950 correction")
         with open(os.path.join(out_dir, f"{tag}_frontend_pmc.json"), "w") as fh:
             json.dump(result, fh, indent=1, sort_keys=True)
         print(json.dumps(result, indent=1, sort_keys=True))
@@ -102,6 +104,17 @@ def main():
                      "# rocprofv3 --pmc passes (tools/pmc_stalls.sh).  *_CYCLES of waves are in units of 4 clocks\n"
                      "# (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*); SQ_VALU_MFMA_BUSY_CYCLES is in clocks.\n" + table)
         print("wrote", f"{tag}_frontend_stalls.txt")
+    if glob.glob(os.path.join(REPO, "gpurun_out", "c3d2_1", "**", "*_counter_collection.csv"), recursive=True):
+        table = subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_table.py"), "c3d2", "c3d2_"],
+                               capture_output=True, text=True).stdout
+        with open(os.path.join(out_dir, f"{tag}_c3d2_stalls.txt"), "w") as fh:
+            fh.write("# per-launch averages, bench.py --c3d2-only (1 024 cubes per launch), three separate rocprofv3 --pmc\n"
+                     "# passes (tools/pmc_stalls.sh c3d2 bench.py --c3d2-only).  SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* are\n"
+                     "# in units of 4 clocks; SQ_VALU_MFMA_BUSY_CYCLES in clocks (32 per v_mfma_f32_16x16x4_f32).\n" + table)
+        print("wrote", f"{tag}_c3d2_stalls.txt")
+    path = os.path.join(REPO, "gpurun_out", "stages_final.json")
+    if os.path.exists(path) and os.path.getsize(path) > 0:
+        shutil.copyfile(path, os.path.join(out_dir, f"{tag}_stage_kernels.json"))
 
 
 if __name__ == "__main__":
