@@ -241,7 +241,7 @@ int svk_roc_eer(svk_ctx* ctx, const float* d_scores, const uint8_t* d_labels, in
  * kernel on v_mfma_f32_16x16x4_f32 (exact f32): conv1_1's output (3.3 MB per cube) lives only in LDS.  The host
  * folds the BatchNorm statistics into weights / biases and lays the operands out:
  *   d_w1frag [4][64]    float: lane l = (channel l & 15, kq = l >> 4), row k = 4 jj + kq of the 16 x 16 conv1_1
- *                       GEMM: k < 15 -> weight of tap (kd = k / 5, kw = k % 5), k = 15 -> bias of the channel
+ *                       GEMM: k < 15 -> weight of tap (kd = k / 5, kw = k % 5), k = 15 -> 0;   d_bias1 [16]
  *   d_w2frag [27][64][4] float: lane (co = l & 15, kk = l >> 4), element e = W2[co][ci = 4 kk + e][kd][kh] of
  *                       tap t = 9 kd + kh;   d_bias2 [16];   d_slope1 / d_slope2 [16] PReLU slopes per channel
  * d_feat [n_utt][max_frames][40], d_crop_idx [n_utt][20] as for svk_cube_gather (crop -1 -> zero cube).
@@ -253,8 +253,8 @@ int svk_roc_eer(svk_ctx* ctx, const float* d_scores, const uint8_t* d_labels, in
 size_t svk_c3d2_stage1_lds_bytes(void);
 int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const float* d_w1frag,
-                    const float* d_slope1, const float* d_w2frag, const float* d_bias2, const float* d_slope2,
-                    int32_t folded, float* d_out);
+                    const float* d_bias1, const float* d_slope1, const float* d_w2frag, const float* d_bias2,
+                    const float* d_slope2, int32_t folded, float* d_out);
 
 /* The second block, model.py:119-124 + :151-158: conv2_1 (16 -> 32, kernel (3,1,4)) -> BN -> PReLU -> conv2_2
  * (32 -> 32, kernel (3,8,1), stride (1,2,1)) -> BN -> PReLU -> MaxPool3d((1,1,2)), two f32-MFMA kernels with the

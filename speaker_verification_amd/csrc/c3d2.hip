@@ -42,13 +42,13 @@ constexpr int OD = 16, OH = 36, OWP = 18;            // output: depths, rows, po
 constexpr int ACT_FLOATS = 17 * DIN * NFRAME * 2;    // 16 p + 4 (p >> 2), p < DIN * 80 * 2
 constexpr int P_FLOATS = PD * NFRAME * PW;
 constexpr int N_TAPS = 27;                           // conv1_2: 3 depths x 9 rows
-constexpr int P_VEC = (P_FLOATS / 2 + 255) / 256;    // float2 loads per thread for a patch
 
 struct Stage1Params {
   const float* feat;
   const int32_t* crop;
   int32_t n_utt, max_frames;
-  const float* w1frag;   // [4][64]: B operand of the conv1_1 GEMM, k = 4 jj + (lane >> 4): tap (k / 5, k % 5), k = 15: bias
+  const float* w1frag;   // [4][64]: B operand of the conv1_1 GEMM, k = 4 jj + (lane >> 4): tap (k / 5, k % 5), k = 15: zero
+  const float* bias1;    // [16]
   const float* slope1;   // [16]
   const f32x4* w2frag;   // [27][64]: lane (co = l & 15, kk = l >> 4), element e = W[co][4 kk + e][kd][kh], tap = 9 kd + kh
   const float* bias2;    // [16]
@@ -59,43 +59,36 @@ struct Stage1Params {
 
 __device__ __forceinline__ float prelu(float v, float slope) { return v > 0.f ? v : slope * v; }
 
-// The item's cube patch: patch[dd][h][ww] = feat[u][crop[u][8 q + dd] + h][2 j + ww].  A thread's s-th piece always
-// belongs to the same depth dd of the patch, whatever the item: its crop starts are loaded one item ahead
-// (fetch_starts) so that the feature loads of fetch_patch never wait for them inside the matrix work.
-__device__ __forceinline__ void fetch_starts(const Stage1Params& p, int item, int (&starts)[P_VEC]) {
+// The item's cube patch: patch[dd][h][ww] = feat[u][crop[u][8 q + dd] + h][2 j + ww].  Thread t < 240 owns the float2
+// (row h = t / 3, piece t % 3) of EVERY depth dd: nothing to decode per item, the depth's crop start is wave-uniform
+// (scalar loads, one item ahead so that no feature load waits for it inside the matrix work), and the LDS address is
+// a per-thread constant plus an immediate.
+__device__ __forceinline__ void fetch_starts(const Stage1Params& p, int item, int (&starts)[PD]) {
   const int u = item / 36, rem = item - u * 36, q = rem / 18;
   const int32_t* cr = p.crop + (int64_t)u * NCROP + TD * q;
 #pragma unroll
-  for (int s = 0; s < P_VEC; ++s) {
-    const int e = threadIdx.x + 256 * s;
-    starts[s] = e < P_FLOATS / 2 ? cr[(e / 3) / NFRAME] : -1;
-  }
+  for (int dd = 0; dd < PD; ++dd) starts[dd] = cr[dd];   // uniform address: s_load
 }
 
-__device__ __forceinline__ void fetch_patch(const Stage1Params& p, int item, const int (&starts)[P_VEC],
-                                            f32x2 (&regs)[P_VEC]) {
+__device__ __forceinline__ void fetch_patch(const Stage1Params& p, int item, const int (&starts)[PD], int h, int piece,
+                                            f32x2 (&regs)[PD]) {
   const int u = item / 36, rem = item - u * 36, j = rem % 18;
-  const float* base = p.feat + (int64_t)u * p.max_frames * NCOEF + 2 * j;
+  const float* base = p.feat + (int64_t)u * p.max_frames * NCOEF + 2 * j + 2 * piece;
 #pragma unroll
-  for (int s = 0; s < P_VEC; ++s) {
-    const int e = threadIdx.x + 256 * s;  // float2 index: row = e / 3 (dd * 80 + h), piece = e % 3
+  for (int dd = 0; dd < PD; ++dd) {
     f32x2 v = (f32x2){0.f, 0.f};
-    if (e < P_FLOATS / 2) {
-      const int row = e / 3, piece = e - row * 3;
-      const int h = row % NFRAME;
-      const int start = starts[s];
-      if (start >= 0 && start + h < p.max_frames)
-        v = *reinterpret_cast<const f32x2*>(base + (int64_t)(start + h) * NCOEF + 2 * piece);
-    }
-    regs[s] = v;
+    const int start = starts[dd];
+    if (h < NFRAME && start >= 0 && start + h < p.max_frames)
+      v = *reinterpret_cast<const f32x2*>(base + (start + h) * NCOEF);  // < 2^31 floats per clip
+    regs[dd] = v;
   }
 }
 
-__device__ __forceinline__ void park_patch(float* patch, const f32x2 (&regs)[P_VEC]) {
+__device__ __forceinline__ void park_patch(float* patch, int h, int piece, const f32x2 (&regs)[PD]) {
+  if (h < NFRAME) {
+    float* dst = patch + h * PW + 2 * piece;
 #pragma unroll
-  for (int s = 0; s < P_VEC; ++s) {
-    const int e = threadIdx.x + 256 * s;
-    if (e < P_FLOATS / 2) *reinterpret_cast<f32x2*>(patch + 2 * e) = regs[s];
+    for (int dd = 0; dd < PD; ++dd) *reinterpret_cast<f32x2*>(dst + dd * (NFRAME * PW)) = regs[dd];
   }
 }
 
@@ -119,24 +112,26 @@ __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) 
     const int k = 4 * jj + kk;
     tapoff[jj] = k < 15 ? (k / 5) * (NFRAME * PW) + (k % 5) : 0;
   }
-  const bool bias_lane = kk == 3;  // k = 15 (jj = 3, kk = 3): the A operand is the constant 1 (bias row of w1frag)
-  const float sl1 = p.slope1[i], b2 = p.bias2[i], sl2 = p.slope2[i];
+  // (GEMM row k = 15 is padding: its weight is 0 and its A operand whatever patch[.. + 0] holds; the bias of
+  // conv1_1 enters through the accumulators)
+  const float sl1 = p.slope1[i], b1 = p.bias1[i], b2 = p.bias2[i], sl2 = p.slope2[i];
   const int pix_lane = (i >> 1) * PW + (i & 1);  // patch offset of this lane's pixel inside a conv1_1 tile (8 rows x 2 columns)
 
-  f32x2 pre[P_VEC];
-  int starts[P_VEC];
+  f32x2 pre[PD];
+  int starts[PD];
+  const int ph = threadIdx.x / 3, ppiece = threadIdx.x - 3 * ph;   // this thread's patch row (>= 80: idle) and float2 piece
   int item = blockIdx.x;
   if (item < n_items) {
     fetch_starts(p, item, starts);
-    fetch_patch(p, item, starts, pre);
-    park_patch(patch, pre);
+    fetch_patch(p, item, starts, ph, ppiece, pre);
+    park_patch(patch, ph, ppiece, pre);
     if (item + (int)gridDim.x < n_items) fetch_starts(p, item + gridDim.x, starts);
   }
   __syncthreads();
   for (; item < n_items; item += gridDim.x) {
     const int next = item + gridDim.x;
     if (next < n_items) {
-      fetch_patch(p, next, starts, pre);                                        // in flight during the matrix work below
+      fetch_patch(p, next, starts, ph, ppiece, pre);                            // in flight during the matrix work below
       if (next + (int)gridDim.x < n_items) fetch_starts(p, next + gridDim.x, starts);  // ... and the starts of the one after
     }
     __builtin_amdgcn_sched_barrier(0);  // all of those loads are ISSUED here, not trickled into the MFMA stream
@@ -144,32 +139,38 @@ __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) 
     // ---- conv1_1 + PReLU: 100 tiles of 16 pixels (8 rows x 2 columns of one depth), 25 per wave, five at a
     // time: 20 gather reads in flight, then 20 MFMAs on five independent accumulators (a tile on its own is 4
     // DEPENDENT MFMAs behind one LDS round trip) ----
-    for (int t0 = wave; t0 < DIN * 10; t0 += 20) {
-      float av[5][4];
+    // Tile tt covers pixels 16 tt .. 16 tt + 15: its patch offset (480 (tt / 10) + 48 (tt % 10) = 48 tt) and its act1
+    // offset (17 x 16 tt) are LINEAR in tt, so with tt = wave + 4 m the per-lane addresses are computed once and every
+    // tile is an immediate offset from them (the / 10 form cost ~25 VALU instructions per tile: issued with no MFMA
+    // to hide behind, they were a tenth of the kernel).
+    {
+      const float* pl[4];
 #pragma unroll
-      for (int q5 = 0; q5 < 5; ++q5) {
-        const int tt = t0 + 4 * q5;
-        const int din = tt / 10, hb = (tt - din * 10) * 8;
-        const float* pp = patch + din * (NFRAME * PW) + hb * PW + pix_lane;
+      for (int jj = 0; jj < 4; ++jj) pl[jj] = patch + 48 * wave + pix_lane + tapoff[jj];
+      float* const al = act + 272 * wave + 68 * kk + i;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) av[q5][jj] = pp[tapoff[jj]];
-        av[q5][3] = bias_lane ? 1.0f : av[q5][3];
-      }
-      f32x4 acc1[5];
+      for (int g5 = 0; g5 < 5; ++g5) {
+        float av[5][4];
 #pragma unroll
-      for (int q5 = 0; q5 < 5; ++q5) acc1[q5] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q5 = 0; q5 < 5; ++q5) {
+          const int m = 5 * g5 + q5;  // tile tt = wave + 4 m
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
+          for (int jj = 0; jj < 4; ++jj) av[q5][jj] = pl[jj][192 * m];
+        }
+        f32x4 acc1[5];  // column i of the tile = channel i: the accumulators start at its (BN-folded) bias
 #pragma unroll
-        for (int q5 = 0; q5 < 5; ++q5) acc1[q5] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q5][jj], w1[jj], acc1[q5], 0, 0, 0);
+        for (int q5 = 0; q5 < 5; ++q5) acc1[q5] = (f32x4){b1, b1, b1, b1};
 #pragma unroll
-      for (int q5 = 0; q5 < 5; ++q5) {
-        const int tt = t0 + 4 * q5;
-        const int din = tt / 10, hb = (tt - din * 10) * 8;
-        // rows 4 kk + r of the tile = pixels p0 + 4 kk + r, column i = channel; p0 = (din * 80 + hb) * 2 (a multiple of 16)
-        float* ap = act + 17 * ((din * NFRAME + hb) * 2) + 68 * kk + i;
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ap[16 * r] = prelu(acc1[q5][r], sl1);
+          for (int q5 = 0; q5 < 5; ++q5) acc1[q5] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q5][jj], w1[jj], acc1[q5], 0, 0, 0);
+#pragma unroll
+        for (int q5 = 0; q5 < 5; ++q5) {
+          // rows 4 kk + r of the tile = pixels 16 tt + 4 kk + r, column i = channel: float 17 x 16 tt + 68 kk + 16 r + i
+          float* ap = al + 1088 * (5 * g5 + q5);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ap[16 * r] = prelu(acc1[q5][r], sl1);
+        }
       }
     }
     __syncthreads();  // act1 is complete; the patch buffer is free
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) 
         o[p.s_par] = v1;
       }
     }
-    if (next < n_items) park_patch(patch, pre);
+    if (next < n_items) park_patch(patch, ph, ppiece, pre);
     __syncthreads();  // the next patch is in place; act1 may be overwritten
   }
 }
@@ -238,8 +239,8 @@ size_t svk_c3d2_stage1_lds_bytes(void) { return sizeof(float) * (size_t)(ACT_FLO
 
 int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const float* d_w1frag,
-                    const float* d_slope1, const float* d_w2frag, const float* d_bias2, const float* d_slope2,
-                    int32_t folded, float* d_out) {
+                    const float* d_bias1, const float* d_slope1, const float* d_w2frag, const float* d_bias2,
+                    const float* d_slope2, int32_t folded, float* d_out) {
   if (!ctx) return SVK_ERR_BAD_ARG;
   SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 1, "shape");
   if (n_cols != NCOEF || n_crops != NCROP || crop_frames != NFRAME)
@@ -247,7 +248,8 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
                     "svk_c3d2_stage1 is built for the 20 x 80 x 40 cube of utils.py:20-21 (got %d x %d x %d)", n_crops,
                     crop_frames, n_cols);
   if (n_utt == 0) return SVK_OK;
-  SVK_REQUIRE(ctx, d_feat && d_crop_idx && d_w1frag && d_slope1 && d_w2frag && d_bias2 && d_slope2 && d_out, "NULL buffer");
+  SVK_REQUIRE(ctx, d_feat && d_crop_idx && d_w1frag && d_bias1 && d_slope1 && d_w2frag && d_bias2 && d_slope2 && d_out,
+              "NULL buffer");
   SVK_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_feat) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_w2frag) & 15) == 0,
               "d_feat must be 8-byte and d_w2frag 16-byte aligned");
   SVK_REQUIRE(ctx, (int64_t)n_utt * 36 < ((int64_t)1 << 31), "too many cubes for one launch");
@@ -257,6 +259,7 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
   p.n_utt = n_utt;
   p.max_frames = max_frames;
   p.w1frag = d_w1frag;
+  p.bias1 = d_bias1;
   p.slope1 = d_slope1;
   p.w2frag = reinterpret_cast<const f32x4*>(d_w2frag);
   p.bias2 = d_bias2;

@@ -422,12 +422,12 @@ class Engine:
         feat = self.to_device(feat, torch.float32)
         idx = self.to_device(crop_idx, torch.int32)
         n, T, Cc = feat.shape
-        w1frag, slope1, w2frag, bias2, slope2 = tables
+        w1frag, bias1, slope1, w2frag, bias2, slope2 = tables
         out = torch.empty((n, 16, 18, 18, 2, 16) if folded else (n, 16, 36, 18, 16), dtype=torch.float32,
                           device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_stage1(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), idx.shape[1], crop_frames,
-                                       self._ptr(w1frag), self._ptr(slope1), self._ptr(w2frag), self._ptr(bias2),
+                                       self._ptr(w1frag), self._ptr(bias1), self._ptr(slope1), self._ptr(w2frag), self._ptr(bias2),
                                        self._ptr(slope2), int(bool(folded)), self._ptr(out)), self.ctx)
         return out
 

@@ -208,7 +208,7 @@ class FusedEmbedder:
         """Operand fragments of `svk_c3d2_stage1` (csrc/c3d2.hip) from the BN-folded weights of conv1_1 / conv1_2,
         or None when the first block is not C3D2's (1 -> 16 k(3,1,5); 16 -> 16 k(3,9,1) stride (1,2,1); pool).
           w1frag [4][64]   : lane (channel = l & 15, kq = l >> 4), GEMM row k = 4 jj + kq: tap (k // 5, k % 5) of
-                             conv1_1, row 15 = its bias
+                             conv1_1, row 15 = 0 (padding); its bias goes separately
           w2frag [27][64][4]: lane (co = l & 15, kk = l >> 4), element e = W2[co][4 kk + e][kd][kh], tap = 9 kd + kh"""
         hit = getattr(self, "_stage1", False)
         if hit is not False:
@@ -225,14 +225,15 @@ class FusedEmbedder:
         w1c = w1.contiguous().view(16, 15)                                  # [co][kd * 5 + kw]
         for jj in range(4):
             k = 4 * jj + kq
-            w1frag[jj] = torch.where(k < 15, w1c[ch, k.clamp(max=14)], b1[ch])
+            w1frag[jj] = torch.where(k < 15, w1c[ch, k.clamp(max=14)], torch.zeros_like(b1[ch]))
         w2c = w2.contiguous()[:, :, :, :, 0]                                # [co][ci][kd][kh]
         w2frag = torch.empty((27, 64, 4), dtype=torch.float32, device=dev)
         for kd in range(3):
             for kh in range(9):
                 for e in range(4):
                     w2frag[9 * kd + kh, :, e] = w2c[ch, 4 * kq + e, kd, kh]
-        self._stage1 = (w1frag.contiguous(), s1.expand(16).contiguous() if s1.numel() == 1 else s1.contiguous(),
+        self._stage1 = (w1frag.contiguous(), b1.contiguous(),
+                        s1.expand(16).contiguous() if s1.numel() == 1 else s1.contiguous(),
                         w2frag.contiguous(), b2.contiguous(),
                         s2.expand(16).contiguous() if s2.numel() == 1 else s2.contiguous())
         return self._stage1
