@@ -60,7 +60,8 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--corpus", type=int, default=N_CORPUS, help="clips in the whole job (all ranks), per step")
-    ap.add_argument("--micro-batch", type=int, default=1024)
+    ap.add_argument("--micro-batch", type=int, default=4096,
+                    help="clips per launch sequence (4 096: +2.4 % over 1 024: fewer persistent-kernel tails and launch gaps)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="clips of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--no-vad", action="store_true")
     ap.add_argument("--no-cmvn", action="store_true")

@@ -1302,3 +1302,35 @@ def test_c3d2_second_block_kernels(eng):
         want = F.max_pool3d(x, kernel_size=(1, 1, 2), stride=(1, 1, 2)).numpy()          # (n, 32, 12, 15, 7)
     got = eng.c3d2_stage2(eng.to_device(act1), tables).cpu().numpy()                      # [n][12][15][7][32]
     np.testing.assert_allclose(got.transpose(0, 4, 1, 2, 3), want, rtol=1e-4, atol=2e-6 * np.abs(want).max())
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """The N > 1 path on the device: `bench.py --gpus 2 --backend gloo` starts two rank processes on this one GPU
+    (RCCL refuses two ranks on a device, so the all-gather goes through gloo / host memory; everything else is the
+    code the 8-GPU run executes): contiguous shards, padded gather, every rank scores, rank 0 reports.  The sharded
+    run must report two ranks and give the SAME scores-derived numbers as the one-rank run."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    common = ["--corpus", "5001", "--micro-batch", "1024", "--steps", "1", "--warmup", "1", "--no-extras"]
+    out = {}
+    for n in (2, 1):
+        extra = ["--gpus", "2", "--backend", "gloo"] if n == 2 else []
+        proc = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + extra + common, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert proc.returncode == 0, proc.stderr.decode()[-2000:]
+        lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
+        assert len(lines) == 1, lines
+        out[n] = json.loads(lines[0])
+    two, one = out[2], out[1]
+    assert two["ranks_seen"] == 2 and two["n_gpus"] == 2 and two["backend"] == "gloo" and two["scaling"] == "strong"
+    assert two["config"]["corpus_clips"] == one["config"]["corpus_clips"] == 5001
+    assert two["config"]["clips_per_rank"] == 2501 and one["config"]["clips_per_rank"] == 5001
+    assert two["allgather_us"] > 0 and one["allgather_us"] is None
+    # the two shards are embedded with other micro-batch shapes than the single shard (MIOpen may pick other
+    # kernels for conv3_1 .. conv4_2): equal to rounding, and the same EER to 1e-3
+    assert two["eer"]["eer"] == pytest.approx(one["eer"]["eer"], abs=2e-3)
+    assert two["eer"]["pairs"] == one["eer"]["pairs"] == 4874 * 40
+    assert two["eer"]["eer"] == pytest.approx(two["eer"]["eer_device"], abs=1e-9)
