@@ -1334,3 +1334,32 @@ def test_bench_two_ranks_share_one_gpu():
     assert two["eer"]["eer"] == pytest.approx(one["eer"]["eer"], abs=2e-3)
     assert two["eer"]["pairs"] == one["eer"]["pairs"] == 4874 * 40
     assert two["eer"]["eer"] == pytest.approx(two["eer"]["eer_device"], abs=1e-9)
+
+
+def test_network_block_error_paths(eng):
+    """The libsvk network blocks refuse what they were not built for, loudly (no silent fallback inside the library;
+    the pipeline routes such models to PyTorch-ROCm by checking `stage1_tables()` / `stage2_tables()` first)."""
+    import ctypes as C
+    from speaker_verification_amd import _lib
+    from speaker_verification_amd.model import C3D2, seeded_model
+    emb = seeded_model(5, n_labels=4).to(eng.device).eval().fused_inference(channels_last=True)
+    tables = emb.stage1_tables()
+    feat = torch.zeros((2, 100, 39), device=eng.device)                      # 39 coefficients: not the 20 x 80 x 40 cube
+    with pytest.raises(_lib.SvkError, match="20 x 80 x 40"):
+        eng.c3d2_stage1(feat, torch.zeros((2, 20), dtype=torch.int32, device=eng.device), tables)
+    feat = torch.zeros((2, 100, 40), device=eng.device)
+    with pytest.raises(_lib.SvkError, match="20 x 80 x 40"):
+        eng.c3d2_stage1(feat, torch.zeros((2, 19), dtype=torch.int32, device=eng.device), tables)
+    assert eng.lib.svk_c3d2_stage1(eng.ctx, None, 1, 100, 40, None, 20, 80, None, None, None, None, None, None, 0, None) == -1
+    assert eng.lib.svk_c3d2_stage2(eng.ctx, None, 1, None, None, None, None, None, None, None, None) == -1
+    assert eng.lib.svk_c3d2_stage1_lds_bytes() <= eng.lds_per_cu
+    # empty batch: nothing launched, nothing touched
+    assert eng.lib.svk_c3d2_stage1(eng.ctx, None, 0, 100, 40, None, 20, 80, None, None, None, None, None, None, 0, None) == 0
+    # a model whose first block is not C3D2's: no tables, the pipeline keeps it on PyTorch-ROCm
+    other = C3D2(4, 1)
+    other.conv1_1 = torch.nn.Conv3d(1, 16, kernel_size=(3, 1, 3))
+    assert other.to(eng.device).eval().fused_inference(channels_last=True).stage1_tables() is None
+    # all-(-1) crops (every clip too short): an all-bias activation, finite, identical for every cube
+    y = eng.c3d2_stage1(torch.randn((3, 90, 40), device=eng.device), torch.full((3, 20), -1, dtype=torch.int32,
+                                                                              device=eng.device), tables, folded=False)
+    assert bool(torch.isfinite(y).all()) and torch.equal(y[0], y[1]) and torch.equal(y[1], y[2])
