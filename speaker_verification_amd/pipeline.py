@@ -143,7 +143,6 @@ class VerificationPipeline:
         """features + crop starts -> embeddings.  With the fused embedder the cube is never materialised:
         svk_cube_gather_windows writes the first layer's patch matrix straight from the feature rows
         (FusedEmbedder.from_windows); otherwise cube -> network."""
-        import os
         tables = self.embedder.stage1_tables() if (self.embedder is not None and self.stage1_kernel) else None
         if tables is not None and feat.shape[2] == c.NUM_COEF and crop_idx.shape[1] == c.CUBE_CROPS:
             # conv1_1 .. pool1 in one libsvk kernel (csrc/c3d2.hip): the cube and conv1_1's 3.3 MB-per-cube output
