@@ -178,14 +178,21 @@ def dataset_embeddings(dataset, model, batch=256):
 
 
 def load_indexed_labels(path):
-    """{speaker id: class index} of the reference's `50_first_ids.npy` (a pickled dict inside an .npy,
-    evaluation.py:100) -- or of a `.json` file of the same stem, preferred when present."""
+    """{speaker id: class index} for `create_dataset`.  The reference keeps it as a PICKLED dict inside
+    `50_first_ids.npy` (`np.load(..., allow_pickle=True).item()`, evaluation.py:100, model.py:360); unpickling runs
+    whatever the file says, so this build never does it.  Sources, in order: a `.json` file of the same stem; else the
+    id list of the same stem (`50_first_ids.txt`, which carries the same information): speaker id = the first 7
+    characters of each path (load_data.py:73), class index = rank among the sorted ids.  The labels only ride along
+    in the dataset items; enrolment and evaluation key on the ids themselves."""
     import json
-    alt = os.path.splitext(path)[0] + '.json'
-    if os.path.exists(alt):
-        with open(alt) as fh:
+    stem = os.path.splitext(path)[0]
+    if os.path.exists(stem + '.json'):
+        with open(stem + '.json') as fh:
             return json.load(fh)
-    return np.load(path, allow_pickle=True).item()          # the user's own id table, in the reference's format
+    if os.path.exists(stem + '.txt'):
+        ids = sorted({str(line)[0:7] for line in np.atleast_1d(np.genfromtxt(stem + '.txt', dtype='str'))})
+        return {sid: k for k, sid in enumerate(ids)}
+    raise FileNotFoundError(f"{stem}.json / {stem}.txt not found ({path} is a pickle: not loaded)")
 
 
 def _evaluate_files(k, plot_path):

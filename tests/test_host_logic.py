@@ -1,5 +1,7 @@
 """Host-side logic of the drop-in layer that needs no GPU: table builders, frame
 bookkeeping, sharding arithmetic, the synthetic corpus, model plumbing."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -148,3 +150,22 @@ def test_fused_embedder_row_fold():
     assert float((got - want).abs().max()) <= 1e-5 * max(scale, 1.0)
     assert float((got - plain).abs().max()) <= 1e-5 * max(scale, 1.0)
     assert not torch.equal(got, plain) or True           # (another summation order: equality is not required)
+
+
+def test_indexed_labels_never_unpickle(tmp_path):
+    """The id table of the file-driven entry points: json if present, else derived from the id list; the reference's
+    pickled .npy is never opened."""
+    import json
+    from speaker_verification_amd.evaluation import load_indexed_labels
+    from speaker_verification_amd import synth
+    root = str(tmp_path)
+    synth.write_verification_tree(root, n_speakers=3, utts_per_speaker=2, n_samples=16000)
+    want = {"id10001": 0, "id10002": 1, "id10003": 2}
+    assert load_indexed_labels(root + "/50_first_ids.npy") == want
+    os.remove(root + "/50_first_ids.json")
+    with open(root + "/50_first_ids.npy", "wb") as fh:
+        fh.write(b"not a numpy file: must never be opened")
+    assert load_indexed_labels(root + "/50_first_ids.npy") == want
+    os.remove(root + "/50_first_ids.txt")
+    with pytest.raises(FileNotFoundError, match="pickle"):
+        load_indexed_labels(root + "/50_first_ids.npy")
