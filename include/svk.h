@@ -268,6 +268,12 @@ int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float*
                     const float* d_slope21, const float* d_w22frag, const float* d_bias22, const float* d_slope22,
                     float* d_act2, float* d_out);
 
+/* What follows each of conv3_1 .. conv4_2 (model.py:159-167; those convolutions run on the host framework): + bias
+ * (BatchNorm folded), PReLU -- one in-place pass over channels-last activations d_x [n_rows][n_channels]
+ * (n_channels a multiple of 4): x <- prelu(x + bias[c], slope[c]).                                            */
+int svk_bias_prelu(svk_ctx* ctx, float* d_x, int64_t n_rows, int32_t n_channels, const float* d_bias,
+                   const float* d_slope);
+
 /* ---- multi-GPU: the one exchange step of the path ------------------------------------------------
  * Utterances shard over the GPUs of a node with no data-path exchange until scoring; then every rank needs
  * the enrolled embeddings: ONE all-gather of the [rows_per_rank][dim] float32 shards over RCCL / xGMI

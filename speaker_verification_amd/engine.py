@@ -445,6 +445,19 @@ class Engine:
               self.ctx)
         return out
 
+    def bias_prelu_(self, x, bias, slope):
+        """svk_bias_prelu, in place on a channels-last activation: x (n, C, D, H, W) with channels_last_3d memory (or
+        any [rows, C] contiguous tensor): x <- prelu(x + bias[c], slope[c])."""
+        torch = _torch()
+        channels = x.shape[1] if x.dim() == 5 else x.shape[-1]
+        ok = x.is_contiguous(memory_format=torch.channels_last_3d) if x.dim() == 5 else x.is_contiguous()
+        if not ok or x.dtype != torch.float32:
+            raise ValueError("bias_prelu_ wants a float32 tensor with channels-last memory")
+        self._stream()
+        check(self.lib.svk_bias_prelu(self.ctx, self._ptr(x), x.numel() // channels, channels, self._ptr(bias),
+                                      self._ptr(slope)), self.ctx)
+        return x
+
     def cosine_scores(self, test, enroll):
         torch = _torch()
         t = self.to_device(test, torch.float32)

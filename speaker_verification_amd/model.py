@@ -108,6 +108,14 @@ class FusedEmbedder:
                 self.stages.append((w, b, act.weight.detach().clone(), stride, pool, pool_first))
             self.fc_w = model.FC5.weight.detach().clone()
             self.fc_b = model.FC5.bias.detach().clone()
+            self.fc_w_cl = None
+            # engine for svk_bias_prelu after conv3_1 .. conv4_2 (GPU + channels-last only; SVK_C3D2_TAIL=0 disables)
+            self.fused_tail = None
+            if channels_last and self.fc_w.is_cuda:
+                import os
+                if os.environ.get("SVK_C3D2_TAIL", "1") != "0":
+                    from .engine import get_engine
+                    self.fused_tail = get_engine(self.fc_w.device.index)
             # First layer as patch-matrix x weight GEMM.  MIOpen has no direct kernel for a 1-channel
             # Conv3d and falls back to im2col + per-group GEMM + layout transposes (6.5 ms per 978
             # cubes).  Here ONE strided copy gathers, for every group of G adjacent output columns, the
@@ -326,6 +334,13 @@ class FusedEmbedder:
                 windows = xs.as_strided((n, od, h, ow // G, kd, kw + G - 1), (d * h * wd, h * wd, wd, G, h * wd, 1))
                 x = torch.addmm(bt, windows.reshape(n * od * h * (ow // G), kd * (kw + G - 1)), wt)
                 x = x.view(n, od, h, ow, w.shape[0]).permute(0, 4, 1, 2, 3)     # NDHWC memory = channels_last_3d
+            elif (self.fused_tail is not None and not pool and groups == 1 and w.shape[0] % 4 == 0 and x.is_cuda
+                  and x.is_contiguous(memory_format=torch.channels_last_3d)):
+                # conv3_1 .. conv4_2: the framework's convolution WITHOUT bias, then bias + PReLU in one in-place
+                # libsvk pass (svk_bias_prelu) instead of a bias-add kernel and a PReLU kernel
+                y = F.conv3d(x, w, None, stride=stride).contiguous(memory_format=torch.channels_last_3d)
+                x = self.fused_tail.bias_prelu_(y, b, slope.expand(w.shape[0]).contiguous() if slope.numel() == 1 else slope)
+                continue
             else:
                 x = F.conv3d(x, w, b, stride=stride, groups=groups)
             if pool_first:
@@ -337,6 +352,13 @@ class FusedEmbedder:
                 x = F.prelu(x, slope)
                 if pool:
                     x = F.max_pool3d(x, kernel_size=(1, 1, 2), stride=(1, 1, 2))
+        if x.dim() == 5 and x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous():
+            # flatten in memory order (d, h, w, c) -- a view -- against FC5's columns permuted to match
+            # (model.py:168 flattens NCDHW: column c * 36 + (d, h, w))
+            if self.fc_w_cl is None:
+                cdhw = self.fc_w.view(self.fc_w.shape[0], x.shape[1], -1)                    # [out][c][dhw]
+                self.fc_w_cl = cdhw.permute(0, 2, 1).reshape(self.fc_w.shape[0], _FLAT).contiguous()
+            return F.linear(x.permute(0, 2, 3, 4, 1).reshape(x.shape[0], _FLAT), self.fc_w_cl, self.fc_b)
         return F.linear(x.reshape(x.shape[0], _FLAT), self.fc_w, self.fc_b)
 
 

@@ -1363,3 +1363,25 @@ def test_network_block_error_paths(eng):
     y = eng.c3d2_stage1(torch.randn((3, 90, 40), device=eng.device), torch.full((3, 20), -1, dtype=torch.int32,
                                                                               device=eng.device), tables, folded=False)
     assert bool(torch.isfinite(y).all()) and torch.equal(y[0], y[1]) and torch.equal(y[1], y[2])
+
+
+def test_bias_prelu_pass(eng):
+    """svk_bias_prelu (what follows conv3_1 .. conv4_2, model.py:159-167): in place on channels-last activations."""
+    import torch.nn.functional as F
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(2)
+    for shape in ((5, 64, 10, 15, 5), (3, 128, 4, 3, 3), (2, 12, 3, 3, 3)):
+        x = torch.randn(shape, device=eng.device, generator=g).contiguous(memory_format=torch.channels_last_3d)
+        b = torch.randn(shape[1], device=eng.device, generator=g)
+        s = torch.rand(shape[1], device=eng.device, generator=g) * 1.5 - 0.5
+        want = F.prelu(x + b.view(1, -1, 1, 1, 1), s)
+        got = eng.bias_prelu_(x.clone(memory_format=torch.preserve_format), b, s)
+        assert got.is_contiguous(memory_format=torch.channels_last_3d)
+        torch.testing.assert_close(got, want, rtol=0, atol=0)
+    rows = torch.randn((1000, 64), device=eng.device, generator=g)
+    torch.testing.assert_close(eng.bias_prelu_(rows.clone(), b[:64] if b.numel() >= 64 else torch.zeros(64, device=eng.device),
+                                               torch.full((64,), 0.25, device=eng.device)),
+                               F.prelu(rows + (b[:64] if b.numel() >= 64 else 0), torch.full((64,), 0.25, device=eng.device)),
+                               rtol=0, atol=0)
+    with pytest.raises(ValueError):
+        eng.bias_prelu_(torch.randn((2, 8, 3, 3, 3), device=eng.device), b[:8], s[:8])      # NCDHW memory: refused
