@@ -693,8 +693,14 @@ def main():
             cubes = np.array([n for _, n in kernel_events], dtype=np.float64)
             tf1 = float((cubes * STAGE1_GFLOP_PER_UTT).sum() / s1_ms.sum())          # GFLOP / ms = TFLOP/s
             tf2 = float((cubes * STAGE2_GFLOP_PER_UTT).sum() / s2_ms.sum())
+            # HBM bytes of this kernel from the committed PMC passes (bench.py --c3d2-only: 1 024 cubes per launch;
+            # FETCH_SIZE x 2 + WRITE_SIZE), scaled to the cubes per launch here: its traffic is linear in the cubes
+            t1, t1_src = pmc_traffic("c3d2_stage1_kernel")
             main_roofline = {"bound": "mfma", "achieved": tf1, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tf1 / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                             "frac": tf1 / F32_MATRIX_PEAK_TFLOPS,
+                             "traffic": None if t1 is None else t1 * float(cubes.mean()) / 1024.0, "traffic_source": t1_src,
+                             "traffic_note": "PMC pass: 1 024 cubes per launch, scaled by cubes_per_launch / 1024; algorithmic "
+                                             "bytes per cube: 47 520 (features, re-read 36 x from L2) + 663 552 written",
                              "kernel": "c3d2_stage1_kernel (cube + conv1_1 + conv1_2 + pool1, v_mfma_f32_16x16x4_f32)",
                              "avg_launch_ms": float(s1_ms.mean()), "cubes_per_launch": float(cubes.mean()),
                              "algorithmic_gflop_per_cube": STAGE1_GFLOP_PER_UTT,
