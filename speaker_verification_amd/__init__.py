@@ -4,7 +4,8 @@ Drop-in call surface of MingmChen/Speaker_Verification for ONE hot path
 (SURVEY.md section 8): `speechpy.{feature,processing,functions}`, `vad`,
 `model.C3D2`, `siamese.Siamese`, `evaluation`.  Compute runs in hand-written
 gfx950 HIP kernels behind the C-ABI of `include/svk.h` (`libsvk.so`, loaded by
-`_lib.py` through ctypes); only the C3D2 forward is PyTorch-ROCm.
+`_lib.py` through ctypes), the first two blocks of the C3D2 forward included; its last four
+convolutions and FC5 run on PyTorch-ROCm.
 
 Importing the package is cheap and needs no GPU; the first call into a device
 op loads `libsvk.so` and raises if it is missing -- there is no CPU fallback.

@@ -1,5 +1,7 @@
-"""C3D2 speaker-embedding network on PyTorch-ROCm (the one piece of the hot
-path that is NOT hand-written HIP, by the north-star's decree).
+"""C3D2 speaker-embedding network: the PyTorch module (what checkpoints load into, what training uses, the
+parity oracle of the libsvk kernels) and `FusedEmbedder`, the inference path: since round 2 its first two
+blocks (conv1_1 .. pool2) run in libsvk (`svk_c3d2_stage1`, `svk_c3d2_stage2`: csrc/c3d2.hip), conv3_1 ..
+FC5 on PyTorch-ROCm with `svk_bias_prelu` behind each convolution.
 
 Mirrors `/root/reference/model.py:104-191`: same constructor arguments, same
 sub-module names (so a reference-format checkpoint's `state_dict` loads

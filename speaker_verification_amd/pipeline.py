@@ -5,8 +5,8 @@ This is the batched, device-resident form of what the reference does one
 utterance at a time on the host:
   vad.py:135-168  ->  load_data.py:50-87  ->  utils.py:351-397  ->
   model.py:141-170  ->  evaluation.py:67-84.
-Every stage except the C3D2 forward (PyTorch-ROCm by the north-star's decree)
-is a libsvk.so kernel.
+Every stage is a libsvk.so kernel except the last four convolutions and FC5 of the C3D2
+forward (PyTorch-ROCm / MIOpen; the first two blocks are `svk_c3d2_stage1` / `svk_c3d2_stage2`).
 """
 import numpy as np
 import torch
@@ -140,9 +140,9 @@ class VerificationPipeline:
             return self.model(cubes, development=False)
 
     def embed_features(self, feat, crop_idx):
-        """features + crop starts -> embeddings.  With the fused embedder the cube is never materialised:
-        svk_cube_gather_windows writes the first layer's patch matrix straight from the feature rows
-        (FusedEmbedder.from_windows); otherwise cube -> network."""
+        """features + crop starts -> embeddings.  The cube is never materialised: `svk_c3d2_stage1` reads the
+        feature rows and crop starts itself (C3D2 geometry); for other first layers `svk_cube_gather_windows` writes
+        the first layer's patch matrix (FusedEmbedder.from_windows); otherwise cube -> network."""
         tables = self.embedder.stage1_tables() if (self.embedder is not None and self.stage1_kernel) else None
         if tables is not None and feat.shape[2] == c.NUM_COEF and crop_idx.shape[1] == c.CUBE_CROPS:
             # conv1_1 .. pool1 in one libsvk kernel (csrc/c3d2.hip): the cube and conv1_1's 3.3 MB-per-cube output
