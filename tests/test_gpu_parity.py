@@ -1334,6 +1334,17 @@ def test_bench_two_ranks_share_one_gpu():
     assert two["eer"]["eer"] == pytest.approx(one["eer"]["eer"], abs=2e-3)
     assert two["eer"]["pairs"] == one["eer"]["pairs"] == 4874 * 40
     assert two["eer"]["eer"] == pytest.approx(two["eer"]["eer_device"], abs=1e-9)
+    # the line's contract (task prompt / DESIGN section 6)
+    for rec in (one, two):
+        assert rec["metric"].startswith("utterances/sec") and rec["unit"] == "utterances/s" and rec["higher_is_better"] is True
+        assert rec["steps"] == 1 and rec["warmup"] == 1 and rec["vs_baseline"] is None and rec["dtype"] == "f32"
+        assert rec["value"] == pytest.approx(5001 / (rec["ms_per_step"] * 1e-3), rel=1e-6)
+        assert "synthetic" in rec["data"] and "5001-clip corpus" in rec["config"]["workload"]
+        roof = rec["roofline"]
+        assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
+        assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"]) and 0.2 < roof["frac"] < 1.0
+        assert "c3d2_stage1_kernel" in roof["kernel"] and roof["avg_launch_ms"] > 0
+        assert rec["roofline_frontend"]["bound"] == "hbm" and rec["roofline_e2e"]["bound"] == "mfma"
 
 
 def test_network_block_error_paths(eng):
