@@ -188,6 +188,50 @@ __device__ __forceinline__ void cosine_tiled_body(const float* __restrict__ test
     for (int r = 0; r < 4; ++r) rinv[rt][r] = 1.0f / __shfl(tn[rt], 4 * kk + r, 64);
   const bool rows_in = m0 + 32 <= nt;  // wave-uniform
 
+  // Epilogue of one 32 x 32 block, through LDS for every block, ragged ones included: scale by the two norms, park in
+  // this wave's staging tile, write whole 128-byte row segments.  One wave's DS instructions execute in order: fences only.
+  auto epilogue = [&](const f32x4 (&accv)[2][2], int st_e, const float (&sinv_e)[2]) __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stage[(16 * rt + 4 * kk + r) * CT_SLD + 16 * ct + i] = accv[rt][ct][r] * rinv[rt][r] * sinv_e[ct];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int c4 = 4 * (lane & 7);
+    float* const ob = out + (int64_t)m0 * ns + st_e * CT_BN + c4;
+    const bool cols_in = (st_e + 1) * CT_BN <= ns;  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (lane >> 3) + 8 * j;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * CT_SLD + c4);
+      if (rows_in || m0 + row < nt) {
+        float* const dst = ob + (int64_t)row * ns;
+        if (cols_in) {
+#ifdef SVK_COS_NOSTORE
+          if (v[0] == 123456.0f)
+#endif
+          *reinterpret_cast<f32x4_u*>(dst) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (st_e * CT_BN + c4 + e < ns) dst[e] = v[e];
+        }
+      }
+    }
+  };
+  // The epilogue of block st - 1 is issued in the MIDDLE of block st's 128 MFMAs (its ~60 VALU / LDS / store
+  // instructions fit the issue slots the matrix pipe leaves free) instead of after its own: the accumulators of
+  // the finished block wait in `pacc`.
+  f32x4 pacc[2][2];
+  float psinv[2] = {0.f, 0.f};
+  int pst = 0;
+  bool pending = false;
+
   f32x4 pre[4];
   fetch(st_begin, 0, pre);
   stash(bs[0], pre);
@@ -236,46 +280,27 @@ __device__ __forceinline__ void cosine_tiled_body(const float* __restrict__ test
             acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][3], bv[3], acc[rt][ct], 0, 0, 0);
           }
         }
+        if (u == 1 && kb == 0 && pending) {  // wave-uniform
+          epilogue(pacc, pst, psinv);
+          pending = false;
+        }
       }
       if (more) stash(bs[cur ^ 1], pre);
       __syncthreads();  // everyone is done with bs[cur]; bs[cur ^ 1] is complete
       cur ^= 1;
     }
-    // Epilogue through LDS for every block, ragged ones included (the per-element path this replaces ran only
-    // in the corpus's LAST row block -- all of it in the last workgroup, which then finished ~10 % after the
-    // others -- and in the last column block).  One wave's DS instructions execute in order: fences only.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          stage[(16 * rt + 4 * kk + r) * CT_SLD + 16 * ct + i] = acc[rt][ct][r] * rinv[rt][r] * sinv[ct];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int c4 = 4 * (lane & 7);
-    float* const ob = out + (int64_t)m0 * ns + st * CT_BN + c4;
-    const bool cols_in = (st + 1) * CT_BN <= ns;  // wave-uniform
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = (lane >> 3) + 8 * j;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * CT_SLD + c4);
-      if (rows_in || m0 + row < nt) {
-        float* const dst = ob + (int64_t)row * ns;
-        if (cols_in) {
-#ifdef SVK_COS_NOSTORE
-          if (v[0] == 123456.0f)
-#endif
-          *reinterpret_cast<f32x4_u*>(dst) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (st * CT_BN + c4 + e < ns) dst[e] = v[e];
-        }
-      }
-    }
+      for (int ct = 0; ct < 2; ++ct) pacc[rt][ct] = acc[rt][ct];
+    psinv[0] = sinv[0];
+    psinv[1] = sinv[1];
+    pst = st;
+    pending = true;
+  }
+  if (pending) {  // the segment's last block (the row block, and with it rinv / the output rows, changes next)
+    epilogue(pacc, pst, psinv);
+    pending = false;
   }
   }  // next segment of this workgroup's unit range (the st loop ended on a __syncthreads: bs[] is free)
 }
