@@ -213,6 +213,14 @@ class FusedEmbedder:
             x = x.contiguous(memory_format=torch.channels_last_3d)
         return self._run(x, first_done=False)
 
+    def _channel_slopes(self, li):
+        """PReLU slope of stage `li` as one value per output channel (nn.PReLU() holds a single one), cached."""
+        cache = self.__dict__.setdefault("_slopes", {})
+        if li not in cache:
+            w, _, slope = self.stages[li][:3]
+            cache[li] = slope.expand(w.shape[0]).contiguous() if slope.numel() == 1 else slope.contiguous()
+        return cache[li]
+
     # ---- the first block (conv1_1 .. pool1) as one libsvk kernel ------------------------------------
     def stage1_tables(self):
         """Operand fragments of `svk_c3d2_stage1` (csrc/c3d2.hip) from the BN-folded weights of conv1_1 / conv1_2,
@@ -341,7 +349,7 @@ class FusedEmbedder:
                 # conv3_1 .. conv4_2: the framework's convolution WITHOUT bias, then bias + PReLU in one in-place
                 # libsvk pass (svk_bias_prelu) instead of a bias-add kernel and a PReLU kernel
                 y = F.conv3d(x, w, None, stride=stride).contiguous(memory_format=torch.channels_last_3d)
-                x = self.fused_tail.bias_prelu_(y, b, slope.expand(w.shape[0]).contiguous() if slope.numel() == 1 else slope)
+                x = self.fused_tail.bias_prelu_(y, b, self._channel_slopes(li))
                 continue
             else:
                 x = F.conv3d(x, w, b, stride=stride, groups=groups)
