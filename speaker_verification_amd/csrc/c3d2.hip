@@ -26,6 +26,8 @@
 // floats per 4 pixels spread the 16 pixels of an M tile (strides of 2 rows = 4 pixels and of 1 depth = 160
 // pixels) over all 64 banks; unpadded they would share two 64-byte windows (8-way conflicts).
 #include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 #include "svk_internal.h"
 
@@ -55,29 +57,47 @@ struct Stage1Params {
   const float* slope2;   // [16]
   float* out;
   int64_t s_n, s_d, s_hp, s_par, s_w;  // output strides (floats): cube, depth, row pair, row parity, pooled column
+  unsigned long long* stamps;          // tuning builds only (-DSVK_TUNING): [grid][4 waves][6] summed phase cycles
 };
 
+// In-kernel phase stamps (s_memtime) for `make TUNING=1` builds; compiled out of the shipped library.
+#ifdef SVK_TUNING
+#define SVK_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define SVK_STAMP_ADD(slot, a, b) do { if (p.stamps && lane == 0) stamp_acc[slot] += (b) - (a); } while (0)
+#else
+#define SVK_STAMP(var) do { } while (0)
+#define SVK_STAMP_ADD(slot, a, b) do { } while (0)
+#endif
+
 __device__ __forceinline__ float prelu(float v, float slope) { return v > 0.f ? v : slope * v; }
+// 0 <= slope <= 1 (nn.PReLU starts at 0.25 and trained slopes stay there): prelu(v) = max(v, slope v), two
+// instructions instead of compare / multiply / select (+ a wait state); bit-identical for finite v.
+template <bool SLOPE01>
+__device__ __forceinline__ float prelu_t(float v, float slope) {
+  return SLOPE01 ? fmaxf(v, slope * v) : prelu(v, slope);
+}
 
 // The item's cube patch: patch[dd][h][ww] = feat[u][crop[u][8 q + dd] + h][2 j + ww].  Thread t < 240 owns the float2
 // (row h = t / 3, piece t % 3) of EVERY depth dd: nothing to decode per item, the depth's crop start is wave-uniform
 // (scalar loads, one item ahead so that no feature load waits for it inside the matrix work), and the LDS address is
 // a per-thread constant plus an immediate.
-__device__ __forceinline__ void fetch_starts(const Stage1Params& p, int item, int (&starts)[PD]) {
+// (a VECTOR load by lanes 0 .. 11, not twelve scalar loads: scalar loads return out of order, so while any is in
+// flight every LDS wait of the wave becomes lgkmcnt(0) -- the first gather read of the conv1_1 phase then stalled for
+// the crop table's whole L2 round trip, 2 500 cycles per item by the in-kernel stamps)
+__device__ __forceinline__ int fetch_starts(const Stage1Params& p, int item, int lane) {
   const int u = item / 36, rem = item - u * 36, q = rem / 18;
   const int32_t* cr = p.crop + (int64_t)u * NCROP + TD * q;
-#pragma unroll
-  for (int dd = 0; dd < PD; ++dd) starts[dd] = cr[dd];   // uniform address: s_load
+  return cr[lane < PD ? lane : 0];
 }
 
-__device__ __forceinline__ void fetch_patch(const Stage1Params& p, int item, const int (&starts)[PD], int h, int piece,
+__device__ __forceinline__ void fetch_patch(const Stage1Params& p, int item, int starts_v, int h, int piece,
                                             f32x2 (&regs)[PD]) {
   const int u = item / 36, rem = item - u * 36, j = rem % 18;
   const float* base = p.feat + (int64_t)u * p.max_frames * NCOEF + 2 * j + 2 * piece;
 #pragma unroll
   for (int dd = 0; dd < PD; ++dd) {
     f32x2 v = (f32x2){0.f, 0.f};
-    const int start = starts[dd];
+    const int start = __builtin_amdgcn_readlane(starts_v, dd);   // wave-uniform
     if (h < NFRAME && start >= 0 && start + h < p.max_frames)
       v = *reinterpret_cast<const f32x2*>(base + (start + h) * NCOEF);  // < 2^31 floats per clip
     regs[dd] = v;
@@ -92,6 +112,7 @@ __device__ __forceinline__ void park_patch(float* patch, int h, int piece, const
   }
 }
 
+template <bool SLOPE01>
 __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem_c3d2[];
   float* act = smem_c3d2;               // [ACT_FLOATS]
@@ -118,23 +139,28 @@ __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) 
   const int pix_lane = (i >> 1) * PW + (i & 1);  // patch offset of this lane's pixel inside a conv1_1 tile (8 rows x 2 columns)
 
   f32x2 pre[PD];
-  int starts[PD];
+  int starts = 0;  // lane dd < 12 holds the crop start of patch depth dd
   const int ph = threadIdx.x / 3, ppiece = threadIdx.x - 3 * ph;   // this thread's patch row (>= 80: idle) and float2 piece
   int item = blockIdx.x;
   if (item < n_items) {
-    fetch_starts(p, item, starts);
+    starts = fetch_starts(p, item, lane);
     fetch_patch(p, item, starts, ph, ppiece, pre);
     park_patch(patch, ph, ppiece, pre);
-    if (item + (int)gridDim.x < n_items) fetch_starts(p, item + gridDim.x, starts);
+    if (item + (int)gridDim.x < n_items) starts = fetch_starts(p, item + gridDim.x, lane);
   }
   __syncthreads();
+#ifdef SVK_TUNING
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
   for (; item < n_items; item += gridDim.x) {
+    SVK_STAMP(ts0);
     const int next = item + gridDim.x;
     if (next < n_items) {
       fetch_patch(p, next, starts, ph, ppiece, pre);                            // in flight during the matrix work below
-      if (next + (int)gridDim.x < n_items) fetch_starts(p, next + gridDim.x, starts);  // ... and the starts of the one after
+      if (next + (int)gridDim.x < n_items) starts = fetch_starts(p, next + gridDim.x, lane);  // ... and the starts of the one after
     }
     __builtin_amdgcn_sched_barrier(0);  // all of those loads are ISSUED here, not trickled into the MFMA stream
+    SVK_STAMP(ts1);
 
     // ---- conv1_1 + PReLU: 100 tiles of 16 pixels (8 rows x 2 columns of one depth), 25 per wave, five at a
     // time: 20 gather reads in flight, then 20 MFMAs on five independent accumulators (a tile on its own is 4
@@ -148,6 +174,10 @@ __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) 
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) pl[jj] = patch + 48 * wave + pix_lane + tapoff[jj];
       float* const al = act + 272 * wave + 68 * kk + i;
+      // (measured, in-kernel stamps: this phase takes 7 650 cycles per item for 3 200 cycles of MFMA work -- the rest is
+      // its 5 VALU per output value (accumulator read-back, PReLU as compare / multiply / select) and the LDS writes;
+      // issuing the next group's reads ahead and interleaving the previous group's PReLU + writes with the MFMAs by
+      // sched_group_barrier changed nothing: the VALU stream itself is the length of the phase)
 #pragma unroll
       for (int g5 = 0; g5 < 5; ++g5) {
         float av[5][4];
@@ -169,11 +199,13 @@ __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) 
           // rows 4 kk + r of the tile = pixels 16 tt + 4 kk + r, column i = channel: float 17 x 16 tt + 68 kk + 16 r + i
           float* ap = al + 1088 * (5 * g5 + q5);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ap[16 * r] = prelu(acc1[q5][r], sl1);
+          for (int r = 0; r < 4; ++r) ap[16 * r] = prelu_t<SLOPE01>(acc1[q5][r], sl1);
         }
       }
     }
+    SVK_STAMP(ts2);
     __syncthreads();  // act1 is complete; the patch buffer is free
+    SVK_STAMP(ts3);
 
     // ---- conv1_2 on MFMA: this wave owns the depth pair dp = wave (output depths 2 dp, 2 dp + 1 of the item) ----
     const int u = item / 36, rem = item - u * 36, q = rem / 18, j = rem - q * 18;
@@ -219,16 +251,29 @@ __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) 
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const int hp = 2 * (3 * g + s) + (kk & 1);  // output row pair: rows 4 hg + 2 (kk & 1) + {0, 1}
-        const float v0 = fmaxf(prelu(acc[s][0] + b2, sl2), prelu(acc[s][1] + b2, sl2));
-        const float v1 = fmaxf(prelu(acc[s][2] + b2, sl2), prelu(acc[s][3] + b2, sl2));
+        const float v0 = fmaxf(prelu_t<SLOPE01>(acc[s][0] + b2, sl2), prelu_t<SLOPE01>(acc[s][1] + b2, sl2));
+        const float v1 = fmaxf(prelu_t<SLOPE01>(acc[s][2] + b2, sl2), prelu_t<SLOPE01>(acc[s][3] + b2, sl2));
         float* o = obase + (int64_t)hp * p.s_hp;
         o[0] = v0;
         o[p.s_par] = v1;
       }
     }
+    SVK_STAMP(ts4);
     if (next < n_items) park_patch(patch, ph, ppiece, pre);
+    SVK_STAMP(ts5);
     __syncthreads();  // the next patch is in place; act1 may be overwritten
+    SVK_STAMP(ts6);
+    SVK_STAMP_ADD(0, ts0, ts1);  // issue of the next patch's loads
+    SVK_STAMP_ADD(1, ts1, ts2);  // conv1_1 phase
+    SVK_STAMP_ADD(2, ts2, ts3);  // barrier 1
+    SVK_STAMP_ADD(3, ts3, ts4);  // conv1_2 phase + epilogue
+    SVK_STAMP_ADD(4, ts4, ts5);  // park
+    SVK_STAMP_ADD(5, ts5, ts6);  // barrier 2
   }
+#ifdef SVK_TUNING
+  if (p.stamps && lane == 0)
+    for (int k = 0; k < 6; ++k) p.stamps[((size_t)blockIdx.x * 4 + wave) * 6 + k] = stamp_acc[k];
+#endif
 }
 
 }  // namespace
@@ -242,6 +287,10 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
                     const float* d_bias1, const float* d_slope1, const float* d_w2frag, const float* d_bias2,
                     const float* d_slope2, int32_t folded, float* d_out) {
   if (!ctx) return SVK_ERR_BAD_ARG;
+  // (the slopes live on the device: whether all 32 lie in [0, 1] -- the two-instruction PReLU -- is the caller's
+  // knowledge, passed in bit 1 of `folded`: 0 / 1 = layout with the general PReLU, 2 / 3 = the same with slopes in [0, 1])
+  const bool slope01 = (folded & 2) != 0;
+  folded &= 1;
   SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 1, "shape");
   if (n_cols != NCOEF || n_crops != NCROP || crop_frames != NFRAME)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED,
@@ -281,12 +330,40 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
   if (lds > (size_t)ctx->lds_per_cu)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage1 needs %zu bytes of LDS per workgroup (device: %d)", lds,
                     ctx->lds_per_cu);
-  SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(c3d2_stage1_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  void (*kern)(const Stage1Params) = slope01 ? c3d2_stage1_kernel<true> : c3d2_stage1_kernel<false>;
+  SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t items = (int64_t)n_utt * 36;
   const unsigned grid = (unsigned)std::min<int64_t>(items, ctx->num_cu);  // one persistent workgroup per CU
-  hipLaunchKernelGGL(c3d2_stage1_kernel, dim3(grid), dim3(256), lds, ctx->stream, p);
+  p.stamps = nullptr;
+#ifdef SVK_TUNING
+  const bool want_stamps = getenv("SVK_C3D2_STAMPS") != nullptr;
+  const size_t stamp_bytes = (size_t)grid * 4 * 6 * sizeof(unsigned long long);
+  if (want_stamps) {
+    const int rc = svk_ensure_work(ctx, stamp_bytes);
+    if (rc != SVK_OK) return rc;
+    p.stamps = reinterpret_cast<unsigned long long*>(ctx->work);
+  }
+#endif
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
+#ifdef SVK_TUNING
+  if (want_stamps) {  // phase cycles (s_memtime, 100 MHz-independent shader clock), averaged over workgroups, per wave
+    std::vector<unsigned long long> h((size_t)grid * 24);
+    SVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SVK_HIP(ctx, hipMemcpy(h.data(), p.stamps, stamp_bytes, hipMemcpyDeviceToHost));
+    const char* names[6] = {"issue next patch loads", "conv1_1 phase", "barrier 1", "conv1_2 phase + epilogue", "park", "barrier 2"};
+    const double per = (double)items / grid;
+    for (int w = 0; w < 4; ++w) {
+      fprintf(stderr, "stage1 stamps wave %d (cycles per item):", w);
+      for (int k = 0; k < 6; ++k) {
+        double sum = 0;
+        for (unsigned b = 0; b < grid; ++b) sum += (double)h[((size_t)b * 4 + w) * 6 + k];
+        fprintf(stderr, "  %s %.0f", names[k], sum / grid / per);
+      }
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   return SVK_OK;
 }
 

@@ -422,13 +422,14 @@ class Engine:
         feat = self.to_device(feat, torch.float32)
         idx = self.to_device(crop_idx, torch.int32)
         n, T, Cc = feat.shape
-        w1frag, bias1, slope1, w2frag, bias2, slope2 = tables
+        w1frag, bias1, slope1, w2frag, bias2, slope2 = tables[:6]
+        slope01 = bool(tables[6]) if len(tables) > 6 else False          # every slope in [0, 1]: the two-instruction PReLU
         out = torch.empty((n, 16, 18, 18, 2, 16) if folded else (n, 16, 36, 18, 16), dtype=torch.float32,
                           device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_stage1(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), idx.shape[1], crop_frames,
                                        self._ptr(w1frag), self._ptr(bias1), self._ptr(slope1), self._ptr(w2frag), self._ptr(bias2),
-                                       self._ptr(slope2), int(bool(folded)), self._ptr(out)), self.ctx)
+                                       self._ptr(slope2), int(bool(folded)) | (2 if slope01 else 0), self._ptr(out)), self.ctx)
         return out
 
     def c3d2_stage2(self, act1, tables):

@@ -250,10 +250,11 @@ class FusedEmbedder:
             for kh in range(9):
                 for e in range(4):
                     w2frag[9 * kd + kh, :, e] = w2c[ch, 4 * kq + e, kd, kh]
+        slope01 = bool(((s1 >= 0) & (s1 <= 1)).all() and ((s2 >= 0) & (s2 <= 1)).all())   # one host read per checkpoint
         self._stage1 = (w1frag.contiguous(), b1.contiguous(),
                         s1.expand(16).contiguous() if s1.numel() == 1 else s1.contiguous(),
                         w2frag.contiguous(), b2.contiguous(),
-                        s2.expand(16).contiguous() if s2.numel() == 1 else s2.contiguous())
+                        s2.expand(16).contiguous() if s2.numel() == 1 else s2.contiguous(), slope01)
         return self._stage1
 
     def stage2_tables(self):

@@ -1242,9 +1242,12 @@ def test_c3d2_first_block_kernel(eng):
     unfold = folded.transpose(0, 1, 2, 4, 3, 5).reshape(n, 16, 36, 18, 16)
     np.testing.assert_array_equal(unfold, plain)
     # a negative and a per-channel slope: PReLU before the max, as the reference orders them
-    w1frag, b1, s1, w2frag, b2, s2 = tables
+    w1frag, b1, s1, w2frag, b2, s2, slope01 = tables
+    assert slope01                                        # perturb_inference_state draws slopes in [0.1, 0.4]: the fast PReLU ran above
     s2n = torch.linspace(-0.5, 0.4, 16, device=eng.device)
-    got = eng.c3d2_stage1(feat, crops, (w1frag, b1, s1, w2frag, b2, s2n), folded=False).cpu().numpy()
+    got = eng.c3d2_stage1(feat, crops, (w1frag, b1, s1, w2frag, b2, s2n, False), folded=False).cpu().numpy()
+    same = eng.c3d2_stage1(feat, crops, (w1frag, b1, s1, w2frag, b2, s2, False), folded=False).cpu().numpy()
+    np.testing.assert_array_equal(same, plain)            # general and [0, 1] PReLU forms agree bit for bit
     with torch.no_grad():
         x1 = F.prelu(F.batch_norm(F.conv3d(torch.from_numpy(cubes), state["conv1_1.weight"], state["conv1_1.bias"]),
                                   state["batch_norm1_1.running_mean"], state["batch_norm1_1.running_var"],

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Phase timing of svk_c3d2_stage1 from in-kernel s_memtime stamps (a `-DSVK_TUNING` build of csrc/c3d2.hip:
+build_variants/libsvk_stamps.so; the shipped library has no stamps).  Prints cycles per item and wave."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+    from speaker_verification_amd import _lib
+    _lib.LIB_PATH = os.environ.get("SVK_TOOL_LIB", os.path.join(os.path.dirname(_lib.LIB_PATH), "..", "build_variants",
+                                                                 "libsvk_stamps.so"))
+    from speaker_verification_amd.engine import get_engine
+    from speaker_verification_amd.model import seeded_model
+    eng = get_engine(0)
+    emb = seeded_model(1, n_labels=4).to(eng.device).eval().fused_inference(channels_last=True)
+    t1 = emb.stage1_tables()
+    n = 1024
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(0)
+    feat = torch.randn((n, 297, 40), device=eng.device, generator=g) * 2 - 6
+    crops = torch.randint(0, 200, (n, 20), device=eng.device, dtype=torch.int32, generator=g)
+    for _ in range(20):
+        eng.c3d2_stage1(feat, crops, t1, folded=False)
+    torch.cuda.synchronize()
+    os.environ["SVK_C3D2_STAMPS"] = "1"
+    eng.c3d2_stage1(feat, crops, t1, folded=False)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()
