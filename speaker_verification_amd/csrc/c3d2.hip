@@ -419,11 +419,27 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21_kernel(const Conv21Params 
     const int u = item / (S2_H / C21_TH), hb = (item - u * (S2_H / C21_TH)) * C21_TH;
     // stage: [16 d][4 rows][18 w][16 c], a 16-byte piece per thread and trip
     const float* src = p.in + (int64_t)u * (S2_D * S2_H * S2_W * 16);
-    for (int e = threadIdx.x; e < C21_PIX * 4; e += 256) {
-      const int pix = e >> 2, piece = e & 3;
-      const int d = pix / (C21_TH * S2_W), rem = pix - d * (C21_TH * S2_W);  // rem = hl * 18 + w
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((int64_t)(d * S2_H + hb) * S2_W + rem) * 16 + 4 * piece);
-      *reinterpret_cast<f32x4*>(reg + 16 * pix + 4 * (pix >> 2) + 4 * piece) = v;
+    // all nine 16-byte loads of a thread first, then the LDS writes: written as a plain load-store loop the
+    // compiler waited for every load before issuing the next (nine memory round trips per item; conv2_2's 18
+    // were 24 k of its 97 k cycles per item by the in-kernel stamps)
+    constexpr int C21_NV = 3;  // loads in flight per thread and round (more would cost the third resident workgroup its registers)
+    static_assert(C21_PIX * 4 % (256 * C21_NV) == 0, "whole rounds");
+#pragma unroll 1
+    for (int base = threadIdx.x; base < C21_PIX * 4; base += 256 * C21_NV) {
+      f32x4 sv[C21_NV];
+#pragma unroll
+      for (int k = 0; k < C21_NV; ++k) {
+        const int e = base + 256 * k;
+        const int pix = e >> 2, piece = e & 3;
+        const int d = pix / (C21_TH * S2_W), rem = pix - d * (C21_TH * S2_W);  // rem = hl * 18 + w
+        sv[k] = *reinterpret_cast<const f32x4*>(src + ((int64_t)(d * S2_H + hb) * S2_W + rem) * 16 + 4 * piece);
+      }
+#pragma unroll
+      for (int k = 0; k < C21_NV; ++k) {
+        const int e = base + 256 * k;
+        const int pix = e >> 2, piece = e & 3;
+        *reinterpret_cast<f32x4*>(reg + 16 * pix + 4 * (pix >> 2) + 4 * piece) = sv[k];
+      }
     }
     __syncthreads();
     // M tiles = (output depth d', row hl): 16 pixels w' = 0 .. 15 (15 is a dummy), 14 x C21_TH / 4 per wave
@@ -476,6 +492,7 @@ struct Conv22Params {
   const float* slope;   // [32]
   float* out;           // [n][12][15][7][32]
   int32_t n_utt;
+  unsigned long long* stamps;   // tuning builds only: [grid][4 waves][4] summed phase cycles
 };
 
 __global__ __launch_bounds__(256, 2) void c3d2_conv22_kernel(const Conv22Params p) {
@@ -491,18 +508,40 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22_kernel(const Conv22Params 
     for (int ch = 0; ch < 2; ++ch) w[t][ch] = p.wfrag[((nt * 24 + t) * 2 + ch) * 64 + lane];
   const float b = p.bias[16 * nt + i], sl = p.slope[16 * nt + i];
   const int n_items = p.n_utt * (O2_W * 2);
+#ifdef SVK_TUNING
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    SVK_STAMP(ts0);
     const int u = item / (O2_W * 2), rem = item - u * (O2_W * 2), q = rem / O2_W, j = rem - q * O2_W;
     // stage [8 d][36 h][2 w][32 c] of the input as pixels p = (dl * 2 + w) * 36 + h (h fastest)
     const float* src = p.in + ((int64_t)u * A2_D + C22_TD * q) * (S2_H * A2_W * 32) + 2 * j * 32;
-    for (int e = threadIdx.x; e < C22_PIX * 8; e += 256) {
-      const int piece = e & 7, wq = (e >> 3) & 1, dh = e >> 4;   // dh = dl * 36 + h
-      const int dl = dh / S2_H, h = dh - dl * S2_H;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)dh * (A2_W * 32) + wq * 32 + 4 * piece);
-      const int pix = (dl * 2 + wq) * S2_H + h;
-      *reinterpret_cast<f32x4*>(reg + 32 * pix + 4 * (pix >> 1) + 4 * piece) = v;
+    // six rounds of three 16-byte loads in flight per thread (a plain load-store loop waited for every load: 18
+    // memory round trips, 24 k of the item's 97 k cycles by the in-kernel stamps; the 192 weight VGPRs leave room for
+    // three -- six in flight spilled)
+    constexpr int C22_NV = 3;
+    static_assert(C22_PIX * 8 % (256 * C22_NV) == 0, "whole rounds");
+#pragma unroll 1
+    for (int base = threadIdx.x; base < C22_PIX * 8; base += 256 * C22_NV) {
+      f32x4 sv[C22_NV];
+#pragma unroll
+      for (int k = 0; k < C22_NV; ++k) {
+        const int e = base + 256 * k;
+        const int piece = e & 7, wq = (e >> 3) & 1, dh = e >> 4;   // dh = dl * 36 + h
+        sv[k] = *reinterpret_cast<const f32x4*>(src + (int64_t)dh * (A2_W * 32) + wq * 32 + 4 * piece);
+      }
+#pragma unroll
+      for (int k = 0; k < C22_NV; ++k) {
+        const int e = base + 256 * k;
+        const int piece = e & 7, wq = (e >> 3) & 1, dh = e >> 4;
+        const int dl = dh / S2_H, h = dh - dl * S2_H;
+        const int pix = (dl * 2 + wq) * S2_H + h;
+        *reinterpret_cast<f32x4*>(reg + 32 * pix + 4 * (pix >> 1) + 4 * piece) = sv[k];
+      }
     }
+    SVK_STAMP(ts1);
     __syncthreads();
+    SVK_STAMP(ts2);
     for (int s = 0; s < 3; ++s) {
       const int dp = 3 * half + s;                           // output depth inside the item
       const int p0 = dp * 2 * S2_H + 2 * i;                  // column 0 of the pair; column 1 is 36 pixels on
@@ -540,9 +579,20 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22_kernel(const Conv22Params 
         if (hq < O2_H) o[(int64_t)hq * (O2_W * 32)] = fmaxf(prelu(acc0[r] + b, sl), prelu(acc1[r] + b, sl));
       }
     }
+    SVK_STAMP(ts3);
     __syncthreads();
+    SVK_STAMP(ts4);
+    SVK_STAMP_ADD(0, ts0, ts1);  // staging: global -> registers -> LDS
+    SVK_STAMP_ADD(1, ts1, ts2);  // barrier 1
+    SVK_STAMP_ADD(2, ts2, ts3);  // 3 x (48 steps of 8 MFMAs) + epilogues
+    SVK_STAMP_ADD(3, ts3, ts4);  // barrier 2
   }
+#ifdef SVK_TUNING
+  if (p.stamps && lane == 0)
+    for (int k = 0; k < 4; ++k) p.stamps[((size_t)blockIdx.x * 4 + wave) * 4 + k] = stamp_acc[k];
+#endif
 }
+
 
 }  // namespace
 
@@ -573,7 +623,7 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     SVK_LAUNCH_CHECK(ctx);
   }
   {
-    Conv22Params p{d_act2, reinterpret_cast<const f32x4*>(d_w22frag), d_bias22, d_slope22, d_out, n_utt};
+    Conv22Params p{d_act2, reinterpret_cast<const f32x4*>(d_w22frag), d_bias22, d_slope22, d_out, n_utt, nullptr};
     const size_t lds = sizeof(float) * (size_t)C22_LDS_FLOATS;
     SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(c3d2_conv22_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -582,9 +632,36 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(c3d2_conv22_kernel), 256, lds) !=
             hipSuccess || per_cu < 1)
       per_cu = 2;
-    hipLaunchKernelGGL(c3d2_conv22_kernel, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(256),
-                       lds, ctx->stream, p);
+    const unsigned grid = (unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu);
+#ifdef SVK_TUNING
+    const bool want_stamps = getenv("SVK_C3D2_STAMPS") != nullptr;
+    const size_t stamp_bytes = (size_t)grid * 4 * 4 * sizeof(unsigned long long);
+    if (want_stamps) {
+      const int rc = svk_ensure_work(ctx, stamp_bytes);
+      if (rc != SVK_OK) return rc;
+      p.stamps = reinterpret_cast<unsigned long long*>(ctx->work);
+    }
+#endif
+    hipLaunchKernelGGL(c3d2_conv22_kernel, dim3(grid), dim3(256), lds, ctx->stream, p);
     SVK_LAUNCH_CHECK(ctx);
+#ifdef SVK_TUNING
+    if (want_stamps) {
+      std::vector<unsigned long long> h((size_t)grid * 16);
+      SVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      SVK_HIP(ctx, hipMemcpy(h.data(), p.stamps, stamp_bytes, hipMemcpyDeviceToHost));
+      const char* names[4] = {"staging", "barrier 1", "MFMA phase + epilogues", "barrier 2"};
+      const double per = (double)items / grid;
+      for (int w = 0; w < 4; ++w) {
+        fprintf(stderr, "conv22 stamps wave %d (cycles per item, %d workgroups per CU):", w, per_cu);
+        for (int k = 0; k < 4; ++k) {
+          double sum = 0;
+          for (unsigned b = 0; b < grid; ++b) sum += (double)h[((size_t)b * 4 + w) * 4 + k];
+          fprintf(stderr, "  %s %.0f", names[k], sum / grid / per);
+        }
+        fprintf(stderr, "\n");
+      }
+    }
+#endif
   }
   return SVK_OK;
 }

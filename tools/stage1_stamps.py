@@ -25,8 +25,15 @@ def main():
     for _ in range(20):
         eng.c3d2_stage1(feat, crops, t1, folded=False)
     torch.cuda.synchronize()
+    t2 = emb.stage2_tables()
+    y = eng.c3d2_stage1(feat, crops, t1, folded=False)
+    for _ in range(10):
+        eng.c3d2_stage2(y, t2)
+    torch.cuda.synchronize()
     os.environ["SVK_C3D2_STAMPS"] = "1"
-    eng.c3d2_stage1(feat, crops, t1, folded=False)
+    y = eng.c3d2_stage1(feat, crops, t1, folded=False)
+    torch.cuda.synchronize()
+    eng.c3d2_stage2(y, t2)
     torch.cuda.synchronize()
 
 
