@@ -276,11 +276,225 @@ __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) 
 #endif
 }
 
+
+// -----------------------------------------------------------------------------------------------------
+// The same block with conv1_2 through Winograd's F(2, 3) ALONG DEPTH (every C3D2 kernel is 3 deep, stride 1):
+// for an output depth pair (2 P, 2 P + 1) and act1 depths x0 .. x3 = 2 P .. 2 P + 3,
+//     t0 = x0 - x2,  t1 = x1 + x2,  t2 = x2 - x1,  t3 = x1 - x3,
+//     G0 = g0,  G1 = (g0 + g1 + g2) / 2,  G2 = (g0 - g1 + g2) / 2,  G3 = g2      (g = the three depth taps of a row tap),
+//     a_k = sum over (row tap, channel) of t_k G_k,        y(2 P) = a0 + a1 + a2,   y(2 P + 1) = a1 - a2 - a3:
+// four MFMAs where the direct form issues six.  The transform of the A operand is VALU work per fragment (16 adds
+// per 16 MFMAs), and a wave does not overlap its own VALU with its own MFMAs on this chip (measured: every add between
+// two MFMAs of a single resident wave costs its full issue time and more) -- so this variant runs EIGHT waves per
+// workgroup, two per SIMD, each with its own M tiles: one wave's adds, LDS waits and epilogues run under the other's
+// MFMAs (the conv1_1 phase, VALU-bound in the four-wave kernel, gains the same way).
+//   * act1 pixel p at 16 p + 4 (p >> 2) + 16 (p >> 4): an M tile is 8 output rows x 2 columns of one depth, its 16
+//     pixels 4 apart; 4 hl + 16 ((hl + s) >> 2) + 16 wc (mod 64) are 16 different multiples of 4, one conflict-free
+//     ds_read_b128 per quarter wave.  The lane part depends on the row tap only through s = kh >> 1: five bases.
+//   * wave = (pair P = wave & 3, part = wave >> 2): part 0 owns the tiles at rows 0, 8, 16, part 1 those at 24 and 28
+//     (the last repeats rows 28 .. 31 and stores 32 .. 35): five tiles of 144 MFMAs per SIMD and item.
+//   * the weights G (36 fragments = 144 VGPRs) are derived in the prologue from the same 27 fragments the direct kernel
+//     takes: the C-ABI does not change.
+// -----------------------------------------------------------------------------------------------------
+constexpr int WPIXF = 18;                                  // average floats per act1 pixel in this layout
+constexpr int WACT_FLOATS = WPIXF * DIN * NFRAME * 2;
+constexpr int WPD = PD / 2;                                // patch depths per thread (512 threads: two halves)
+
+__device__ __forceinline__ void fetch_patch_w(const Stage1Params& p, int item, int starts_v, int h, int piece, int dhalf,
+                                              f32x2 (&regs)[WPD]) {
+  const int u = item / 36, rem = item - u * 36, j = rem % 18;
+  const float* base = p.feat + (int64_t)u * p.max_frames * NCOEF + 2 * j + 2 * piece;
+#pragma unroll
+  for (int dd = 0; dd < WPD; ++dd) {
+    f32x2 v = (f32x2){0.f, 0.f};
+    const int start = __builtin_amdgcn_readlane(starts_v, WPD * dhalf + dd);   // wave-uniform (dhalf = wave >> 2)
+    if (h < NFRAME && start >= 0 && start + h < p.max_frames)
+      v = *reinterpret_cast<const f32x2*>(base + (start + h) * NCOEF);
+    regs[dd] = v;
+  }
+}
+
+__device__ __forceinline__ void park_patch_w(float* patch, int h, int piece, int dhalf, const f32x2 (&regs)[WPD]) {
+  if (h < NFRAME) {
+    float* dst = patch + (WPD * dhalf) * (NFRAME * PW) + h * PW + 2 * piece;
+#pragma unroll
+    for (int dd = 0; dd < WPD; ++dd) *reinterpret_cast<f32x2*>(dst + dd * (NFRAME * PW)) = regs[dd];
+  }
+}
+
+template <bool SLOPE01>
+__global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_c3d2[];
+  float* act = smem_c3d2;               // [WACT_FLOATS]
+  float* patch = act + WACT_FLOATS;     // [P_FLOATS]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int pair = wave & 3, part = wave >> 2;
+  const int n_items = p.n_utt * 36;
+
+  f32x4 G[36];   // [k][kh]
+#pragma unroll
+  for (int kh = 0; kh < 9; ++kh) {
+    const f32x4 g0 = p.w2frag[kh * 64 + lane], g1 = p.w2frag[(9 + kh) * 64 + lane], g2 = p.w2frag[(18 + kh) * 64 + lane];
+    G[kh] = g0;
+    G[9 + kh] = 0.5f * ((g0 + g2) + g1);
+    G[18 + kh] = 0.5f * ((g0 + g2) - g1);
+    G[27 + kh] = g2;
+  }
+  float w1[4];
+  int tapoff[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    w1[jj] = p.w1frag[jj * 64 + lane];
+    const int k = 4 * jj + kk;
+    tapoff[jj] = k < 15 ? (k / 5) * (NFRAME * PW) + (k % 5) : 0;
+  }
+  const float sl1 = p.slope1[i], b1 = p.bias1[i], b2 = p.bias2[i], sl2 = p.slope2[i];
+  const int pix_lane = (i >> 1) * PW + (i & 1);
+
+  f32x2 pre[WPD];
+  int starts = 0;
+  const int tq = threadIdx.x & 255;
+  const int ph = tq / 3, ppiece = tq - 3 * ph;   // patch row (>= 80: idle) and float2 piece; depths 6 part .. 6 part + 5
+  int item = blockIdx.x;
+  if (item < n_items) {
+    starts = fetch_starts(p, item, lane);
+    fetch_patch_w(p, item, starts, ph, ppiece, part, pre);
+    park_patch_w(patch, ph, ppiece, part, pre);
+    if (item + (int)gridDim.x < n_items) starts = fetch_starts(p, item + gridDim.x, lane);
+  }
+  __syncthreads();
+#ifdef SVK_TUNING
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  for (; item < n_items; item += gridDim.x) {
+    SVK_STAMP(ts0);
+    const int next = item + gridDim.x;
+    if (next < n_items) {
+      fetch_patch_w(p, next, starts, ph, ppiece, part, pre);
+      if (next + (int)gridDim.x < n_items) starts = fetch_starts(p, next + gridDim.x, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SVK_STAMP(ts1);
+
+    // ---- conv1_1 + PReLU: 100 tiles of 16 pixels, tile tt = wave + 8 m: 13 for waves 0 .. 3, 12 for the others, four at
+    // a time (patch offset 48 tt and act1 offset 288 tt are linear in tt: per-lane bases + immediates) ----
+    {
+      const float* pl[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) pl[jj] = patch + 48 * wave + pix_lane + tapoff[jj];
+      float* const al = act + 16 * WPIXF * wave + 68 * kk + i;
+#pragma unroll
+      for (int g4 = 0; g4 < 3; ++g4) {
+        float av[4][4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) av[q4][jj] = pl[jj][384 * (4 * g4 + q4)];
+        f32x4 acc1[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) acc1[q4] = (f32x4){b1, b1, b1, b1};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) acc1[q4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q4][jj], w1[jj], acc1[q4], 0, 0, 0);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float* ap = al + 128 * WPIXF * (4 * g4 + q4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ap[16 * r] = prelu_t<SLOPE01>(acc1[q4][r], sl1);
+        }
+      }
+      if (part == 0) {   // tile 96 + wave
+        float av[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) av[jj] = pl[jj][384 * 12];
+        f32x4 acc1 = (f32x4){b1, b1, b1, b1};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], w1[jj], acc1, 0, 0, 0);
+        float* ap = al + 128 * WPIXF * 12;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ap[16 * r] = prelu_t<SLOPE01>(acc1[r], sl1);
+      }
+    }
+    SVK_STAMP(ts2);
+    __syncthreads();  // act1 is complete; the patch buffer is free
+    SVK_STAMP(ts3);
+
+    // ---- conv1_2, depth-transformed ----
+    {
+      const int u = item / 36, rem = item - u * 36, q = rem / 18, j = rem - q * 18;
+      const int hl = i >> 1, wc = i & 1;
+      const float* const wbase = act + 2 * (160 * WPIXF) * pair + 68 * hl + 16 * wc + 4 * kk;
+      float* const obase = p.out + (int64_t)u * p.s_n + (int64_t)(TD * q + 2 * pair) * p.s_d + (int64_t)j * p.s_w + i;
+      const int tl0 = part ? 3 : 0, tl1 = part ? 5 : 3;
+#pragma unroll 1
+      for (int tl = tl0; tl < tl1; ++tl) {
+        const int h0 = tl < 4 ? 8 * tl : 28;
+        const float* pb[5];
+#pragma unroll
+        for (int sft = 0; sft < 5; ++sft) pb[sft] = wbase + 72 * h0 + 16 * ((hl + sft) >> 2);
+        f32x4 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 x[4];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(pb[0] + 160 * WPIXF * dd);
+#pragma unroll
+        for (int kh = 0; kh < 9; ++kh) {
+          f32x4 t[4];
+          t[0] = x[0] - x[2];
+          t[1] = x[1] + x[2];
+          t[2] = x[2] - x[1];
+          t[3] = x[1] - x[3];
+          __builtin_amdgcn_sched_barrier(0);
+          if (kh + 1 < 9) {   // the next row tap's fragments: a whole tap of MFMAs ahead of their use
+            const int off = 32 * (kh + 1) + 4 * ((kh + 1) >> 1);
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(pb[(kh + 1) >> 1] + 160 * WPIXF * dd + off);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e], G[9 * k + kh][e], acc[k], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // rows 4 kk + r of the tile: output row h0 + 2 kk + (r >> 1), column r & 1: pool = max over r pairs
+        if (tl < 4 || kk >= 2) {
+          const f32x4 y0 = acc[0] + acc[1] + acc[2] + b2, y1 = acc[1] - acc[2] - acc[3] + b2;
+          float* o = obase + (int64_t)(h0 / 2 + kk) * p.s_hp;
+          o[0] = fmaxf(prelu_t<SLOPE01>(y0[0], sl2), prelu_t<SLOPE01>(y0[1], sl2));
+          o[p.s_par] = fmaxf(prelu_t<SLOPE01>(y0[2], sl2), prelu_t<SLOPE01>(y0[3], sl2));
+          o[p.s_d] = fmaxf(prelu_t<SLOPE01>(y1[0], sl2), prelu_t<SLOPE01>(y1[1], sl2));
+          o[p.s_d + p.s_par] = fmaxf(prelu_t<SLOPE01>(y1[2], sl2), prelu_t<SLOPE01>(y1[3], sl2));
+        }
+      }
+    }
+    SVK_STAMP(ts4);
+    if (next < n_items) park_patch_w(patch, ph, ppiece, part, pre);
+    SVK_STAMP(ts5);
+    __syncthreads();  // the next patch is in place; act1 may be overwritten
+    SVK_STAMP(ts6);
+    SVK_STAMP_ADD(0, ts0, ts1);
+    SVK_STAMP_ADD(1, ts1, ts2);
+    SVK_STAMP_ADD(2, ts2, ts3);
+    SVK_STAMP_ADD(3, ts3, ts4);
+    SVK_STAMP_ADD(4, ts4, ts5);
+    SVK_STAMP_ADD(5, ts5, ts6);
+  }
+#ifdef SVK_TUNING
+  if (p.stamps && lane == 0)
+    for (int k = 0; k < 6; ++k) p.stamps[((size_t)blockIdx.x * 8 + wave) * 6 + k] = stamp_acc[k];
+#endif
+}
+
 }  // namespace
 
 extern "C" {
 
-size_t svk_c3d2_stage1_lds_bytes(void) { return sizeof(float) * (size_t)(ACT_FLOATS + P_FLOATS); }
+// (of the larger variant, the depth-transformed one)
+size_t svk_c3d2_stage1_lds_bytes(void) { return sizeof(float) * (size_t)(WACT_FLOATS + P_FLOATS); }
 
 int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const float* d_w1frag,
@@ -289,7 +503,7 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
   if (!ctx) return SVK_ERR_BAD_ARG;
   // (the slopes live on the device: whether all 32 lie in [0, 1] -- the two-instruction PReLU -- is the caller's
   // knowledge, passed in bit 1 of `folded`: 0 / 1 = layout with the general PReLU, 2 / 3 = the same with slopes in [0, 1])
-  const bool slope01 = (folded & 2) != 0;
+  const bool slope01 = (folded & 2) != 0, wino = (folded & 4) != 0;
   folded &= 1;
   SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 1, "shape");
   if (n_cols != NCOEF || n_crops != NCROP || crop_frames != NFRAME)
@@ -326,38 +540,40 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
     p.s_d = (int64_t)OH * OWP * 16;
   }
   p.s_n = (int64_t)OD * OH * OWP * 16;
-  const size_t lds = svk_c3d2_stage1_lds_bytes();
+  const size_t lds = sizeof(float) * (size_t)((wino ? WACT_FLOATS : ACT_FLOATS) + P_FLOATS);
   if (lds > (size_t)ctx->lds_per_cu)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage1 needs %zu bytes of LDS per workgroup (device: %d)", lds,
                     ctx->lds_per_cu);
-  void (*kern)(const Stage1Params) = slope01 ? c3d2_stage1_kernel<true> : c3d2_stage1_kernel<false>;
+  void (*kern)(const Stage1Params) = wino ? (slope01 ? c3d2_stage1w_kernel<true> : c3d2_stage1w_kernel<false>)
+                                          : (slope01 ? c3d2_stage1_kernel<true> : c3d2_stage1_kernel<false>);
+  const int n_waves = wino ? 8 : 4;
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t items = (int64_t)n_utt * 36;
   const unsigned grid = (unsigned)std::min<int64_t>(items, ctx->num_cu);  // one persistent workgroup per CU
   p.stamps = nullptr;
 #ifdef SVK_TUNING
   const bool want_stamps = getenv("SVK_C3D2_STAMPS") != nullptr;
-  const size_t stamp_bytes = (size_t)grid * 4 * 6 * sizeof(unsigned long long);
+  const size_t stamp_bytes = (size_t)grid * n_waves * 6 * sizeof(unsigned long long);
   if (want_stamps) {
     const int rc = svk_ensure_work(ctx, stamp_bytes);
     if (rc != SVK_OK) return rc;
     p.stamps = reinterpret_cast<unsigned long long*>(ctx->work);
   }
 #endif
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * n_waves), lds, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
 #ifdef SVK_TUNING
   if (want_stamps) {  // phase cycles (s_memtime, 100 MHz-independent shader clock), averaged over workgroups, per wave
-    std::vector<unsigned long long> h((size_t)grid * 24);
+    std::vector<unsigned long long> h((size_t)grid * n_waves * 6);
     SVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SVK_HIP(ctx, hipMemcpy(h.data(), p.stamps, stamp_bytes, hipMemcpyDeviceToHost));
     const char* names[6] = {"issue next patch loads", "conv1_1 phase", "barrier 1", "conv1_2 phase + epilogue", "park", "barrier 2"};
     const double per = (double)items / grid;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < n_waves; ++w) {
       fprintf(stderr, "stage1 stamps wave %d (cycles per item):", w);
       for (int k = 0; k < 6; ++k) {
         double sum = 0;
-        for (unsigned b = 0; b < grid; ++b) sum += (double)h[((size_t)b * 4 + w) * 6 + k];
+        for (unsigned b = 0; b < grid; ++b) sum += (double)h[((size_t)b * n_waves + w) * 6 + k];
         fprintf(stderr, "  %s %.0f", names[k], sum / grid / per);
       }
       fprintf(stderr, "\n");

@@ -43,6 +43,8 @@ class VerificationPipeline:
         # SVK_C3D2_STAGE1=0: run the first block on PyTorch-ROCm too (A/B and parity tests)
         self.stage1_kernel = os.environ.get("SVK_C3D2_STAGE1", "1") != "0"
         self.stage2_kernel = self.stage1_kernel and os.environ.get("SVK_C3D2_STAGE2", "1") != "0"
+        # conv1_2 through Winograd's F(2, 3) along depth (2 / 3 of the multiply-adds); SVK_C3D2_DEPTH_TRANSFORM=0 = direct sums
+        self.depth_transform = os.environ.get("SVK_C3D2_DEPTH_TRANSFORM", "1") != "0"
         # bench.py sets this to a list: HIP events (on the launch stream) around the first- and second-block kernels
         self.kernel_events = None
         self.model = model.to(self.eng.device).eval()
@@ -154,7 +156,8 @@ class VerificationPipeline:
                 if rec:
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                     ev[0].record()
-                y = self.eng.c3d2_stage1(feat, crop_idx, tables, folded=False, crop_frames=c.CUBE_FRAMES)
+                y = self.eng.c3d2_stage1(feat, crop_idx, tables, folded=False, crop_frames=c.CUBE_FRAMES,
+                                         depth_transform=self.depth_transform)
                 if rec:
                     ev[1].record()
                 z = self.eng.c3d2_stage2(y, tables2)
@@ -164,7 +167,8 @@ class VerificationPipeline:
                 with self._find_mode():
                     return self.embedder.from_stage2(z, feat.shape[0])
             folded = self.embedder.row_fold is not None
-            y = self.eng.c3d2_stage1(feat, crop_idx, tables, folded=folded, crop_frames=c.CUBE_FRAMES)
+            y = self.eng.c3d2_stage1(feat, crop_idx, tables, folded=folded, crop_frames=c.CUBE_FRAMES,
+                                     depth_transform=self.depth_transform)
             with self._find_mode():
                 return self.embedder.from_stage1(y, feat.shape[0])
         geo = self.embedder.first_layer_windows(c.CUBE_CROPS, feat.shape[2]) if self.embedder is not None else None

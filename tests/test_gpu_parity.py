@@ -1241,6 +1241,13 @@ def test_c3d2_first_block_kernel(eng):
     folded = eng.c3d2_stage1(feat, crops, tables, folded=True).cpu().numpy()             # [n][d][h/2][w][h&1][c]
     unfold = folded.transpose(0, 1, 2, 4, 3, 5).reshape(n, 16, 36, 18, 16)
     np.testing.assert_array_equal(unfold, plain)
+    # conv1_2 through Winograd's F(2, 3) along depth: the same sums in another association
+    wino = eng.c3d2_stage1(feat, crops, tables, folded=False, depth_transform=True).cpu().numpy()
+    np.testing.assert_allclose(wino.transpose(0, 4, 1, 2, 3), want, rtol=1e-4, atol=4e-6 * scale)
+    wino_f = eng.c3d2_stage1(feat, crops, tables, folded=True, depth_transform=True).cpu().numpy()
+    np.testing.assert_array_equal(wino_f.transpose(0, 1, 2, 4, 3, 5).reshape(n, 16, 36, 18, 16), wino)
+    print("first block, max |diff| / scale: direct %.2e, depth-transformed %.2e"
+          % (np.abs(plain.transpose(0, 4, 1, 2, 3) - want).max() / scale, np.abs(wino.transpose(0, 4, 1, 2, 3) - want).max() / scale))
     # a negative and a per-channel slope: PReLU before the max, as the reference orders them
     w1frag, b1, s1, w2frag, b2, s2, slope01 = tables
     assert slope01                                        # perturb_inference_state draws slopes in [0.1, 0.4]: the fast PReLU ran above
@@ -1258,6 +1265,8 @@ def test_c3d2_first_block_kernel(eng):
                           state["batch_norm1_2.weight"], state["batch_norm1_2.bias"], training=False, eps=1e-5)
         want_n = F.max_pool3d(F.prelu(x2, s2n.cpu()), kernel_size=(1, 1, 2), stride=(1, 1, 2)).numpy()
     np.testing.assert_allclose(got.transpose(0, 4, 1, 2, 3), want_n, rtol=1e-4, atol=2e-6 * scale)
+    got_w = eng.c3d2_stage1(feat, crops, (w1frag, b1, s1, w2frag, b2, s2n, False), folded=False, depth_transform=True).cpu().numpy()
+    np.testing.assert_allclose(got_w.transpose(0, 4, 1, 2, 3), want_n, rtol=1e-4, atol=4e-6 * scale)
 
 
 def test_embeddings_with_and_without_the_first_block_kernel(eng, monkeypatch):

@@ -22,16 +22,24 @@ def main():
     g.manual_seed(0)
     feat = torch.randn((n, 297, 40), device=eng.device, generator=g) * 2 - 6
     crops = torch.randint(0, 200, (n, 20), device=eng.device, dtype=torch.int32, generator=g)
-    for _ in range(20):
-        eng.c3d2_stage1(feat, crops, t1, folded=False)
-    torch.cuda.synchronize()
+    dt = os.environ.get("SVK_C3D2_DEPTH_TRANSFORM", "1") != "0"
+    for mode in (False, True):
+        for _ in range(20):
+            eng.c3d2_stage1(feat, crops, t1, folded=False, depth_transform=mode)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            eng.c3d2_stage1(feat, crops, t1, folded=False, depth_transform=mode)
+        b.record()
+        torch.cuda.synchronize()
+        print("svk_c3d2_stage1, 1024 cubes, depth_transform=%s: %.3f ms" % (mode, a.elapsed_time(b) / 20), file=sys.stderr)
     t2 = emb.stage2_tables()
     y = eng.c3d2_stage1(feat, crops, t1, folded=False)
     for _ in range(10):
         eng.c3d2_stage2(y, t2)
     torch.cuda.synchronize()
     os.environ["SVK_C3D2_STAMPS"] = "1"
-    y = eng.c3d2_stage1(feat, crops, t1, folded=False)
+    y = eng.c3d2_stage1(feat, crops, t1, folded=False, depth_transform=dt)
     torch.cuda.synchronize()
     eng.c3d2_stage2(y, t2)
     torch.cuda.synchronize()
