@@ -63,7 +63,7 @@ struct Stage1Params {
 // In-kernel phase stamps (s_memtime) for `make TUNING=1` builds; compiled out of the shipped library.
 #ifdef SVK_TUNING
 #define SVK_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define SVK_STAMP_ADD(slot, a, b) do { if (p.stamps && lane == 0) stamp_acc[slot] += (b) - (a); } while (0)
+#define SVK_STAMP_ADD(slot, a, b) do { stamp_acc[slot] += (b) - (a); } while (0)   /* wave-uniform: scalar registers */
 #else
 #define SVK_STAMP(var) do { } while (0)
 #define SVK_STAMP_ADD(slot, a, b) do { } while (0)
@@ -322,6 +322,29 @@ __device__ __forceinline__ void park_patch_w(float* patch, int h, int piece, int
   }
 }
 
+// Input transform of the depth-Winograd form for one element pair (hf = 0: elements 0, 1; 1: elements 2, 3) of the four
+// depth fragments x: t0 = x0 - x2, t1 = x1 + x2, t2 = x2 - x1, t3 = x1 - x3, as four v_pk_add_f32 (written out: the
+// compiler emits the packed form now and then for sums and never for differences, which use the negate modifiers).
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ void wino_input_pair(const f32x4 (&x)[4], int hf, f32x2 (&t)[4][2]) {
+  f32x2 xh[4];
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) xh[dd] = hf ? __builtin_shufflevector(x[dd], x[dd], 2, 3) : __builtin_shufflevector(x[dd], x[dd], 0, 1);
+  t[0][hf] = pk_sub(xh[0], xh[2]);
+  t[1][hf] = pk_add(xh[1], xh[2]);
+  t[2][hf] = pk_sub(xh[2], xh[1]);
+  t[3][hf] = pk_sub(xh[1], xh[3]);
+}
+
 template <bool SLOPE01>
 __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem_c3d2[];
@@ -342,13 +365,8 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
     G[27 + kh] = g2;
   }
   float w1[4];
-  int tapoff[4];
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    w1[jj] = p.w1frag[jj * 64 + lane];
-    const int k = 4 * jj + kk;
-    tapoff[jj] = k < 15 ? (k / 5) * (NFRAME * PW) + (k % 5) : 0;
-  }
+  for (int jj = 0; jj < 4; ++jj) w1[jj] = p.w1frag[jj * 64 + lane];
   const float sl1 = p.slope1[i], b1 = p.bias1[i], b2 = p.bias2[i], sl2 = p.slope2[i];
   const int pix_lane = (i >> 1) * PW + (i & 1);
 
@@ -370,11 +388,6 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
   for (; item < n_items; item += gridDim.x) {
     SVK_STAMP(ts0);
     const int next = item + gridDim.x;
-    if (next < n_items) {
-      fetch_patch_w(p, next, starts, ph, ppiece, part, pre);
-      if (next + (int)gridDim.x < n_items) starts = fetch_starts(p, next + gridDim.x, lane);
-    }
-    __builtin_amdgcn_sched_barrier(0);
     SVK_STAMP(ts1);
 
     // ---- conv1_1 + PReLU: 100 tiles of 16 pixels, tile tt = wave + 8 m: 13 for waves 0 .. 3, 12 for the others, four at
@@ -382,7 +395,10 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
     {
       const float* pl[4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) pl[jj] = patch + 48 * wave + pix_lane + tapoff[jj];
+      for (int jj = 0; jj < 4; ++jj) {   // (recomputed per item: this kernel has no registers to spare)
+        const int k = 4 * jj + kk;
+        pl[jj] = patch + 48 * wave + pix_lane + (k < 15 ? (k / 5) * (NFRAME * PW) + (k % 5) : 0);
+      }
       float* const al = act + 16 * WPIXF * wave + 68 * kk + i;
 #pragma unroll
       for (int g4 = 0; g4 < 3; ++g4) {
@@ -428,8 +444,16 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       const float* const wbase = act + 2 * (160 * WPIXF) * pair + 68 * hl + 16 * wc + 4 * kk;
       float* const obase = p.out + (int64_t)u * p.s_n + (int64_t)(TD * q + 2 * pair) * p.s_d + (int64_t)j * p.s_w + i;
       const int tl0 = part ? 3 : 0, tl1 = part ? 5 : 3;
+      const int fetch_tl = part ? 4 : 0;
 #pragma unroll 1
       for (int tl = tl0; tl < tl1; ++tl) {
+        // the next item's patch: twelve scattered 8-byte loads per row take the CU's address path ~2 000 cycles to accept;
+        // the two waves of a SIMD issue their halves at different times, under each other's MFMAs (part 0 in front of
+        // its first tile, part 1 in front of its second), and park them after the last tile
+        if (tl == fetch_tl && next < n_items) {
+          fetch_patch_w(p, next, starts, ph, ppiece, part, pre);
+          if (next + (int)gridDim.x < n_items) starts = fetch_starts(p, next + gridDim.x, lane);
+        }
         const int h0 = tl < 4 ? 8 * tl : 28;
         const float* pb[5];
 #pragma unroll
@@ -438,26 +462,37 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 x[4];
+        f32x2 t[4][2];   // [k][element pair]
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(pb[0] + 160 * WPIXF * dd);
 #pragma unroll
-        for (int kh = 0; kh < 9; ++kh) {
-          f32x4 t[4];
-          t[0] = x[0] - x[2];
-          t[1] = x[1] + x[2];
-          t[2] = x[2] - x[1];
-          t[3] = x[1] - x[3];
-          __builtin_amdgcn_sched_barrier(0);
-          if (kh + 1 < 9) {   // the next row tap's fragments: a whole tap of MFMAs ahead of their use
-            const int off = 32 * (kh + 1) + 4 * ((kh + 1) >> 1);
+        for (int hf = 0; hf < 2; ++hf) wino_input_pair(x, hf, t);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(pb[(kh + 1) >> 1] + 160 * WPIXF * dd + off);
+        for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(pb[0] + 160 * WPIXF * dd + 32);
+        // Row tap kh: 16 MFMAs on t.  The NEXT tap's t is computed in place, an element pair at a time, right behind the
+        // eight MFMAs that consumed the pair (x = the next tap's fragments, read a tap earlier): four packed adds per
+        // eight MFMAs.  (f32 MFMA and f32 VALU share the SIMD's multipliers on this chip -- neither the same wave nor the
+        // SIMD's other wave overlaps the two, measured -- so every add is paid for: packed ones cost half.)
+#pragma unroll
+        for (int kh = 0; kh < 9; ++kh) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][hf][e], G[9 * k + kh][2 * hf + e], acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kh + 1 < 9) wino_input_pair(x, hf, t);
           }
           __builtin_amdgcn_sched_barrier(0);
+          if (kh + 2 < 9) {
+            const int off = 32 * (kh + 2) + 4 * ((kh + 2) >> 1);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e], G[9 * k + kh][e], acc[k], 0, 0, 0);
+            for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(pb[(kh + 2) >> 1] + 160 * WPIXF * dd + off);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         // rows 4 kk + r of the tile: output row h0 + 2 kk + (r >> 1), column r & 1: pool = max over r pairs
