@@ -695,19 +695,34 @@ def main():
             tf2 = float((cubes * STAGE2_GFLOP_PER_UTT).sum() / s2_ms.sum())
             # HBM bytes of this kernel from the committed PMC passes (bench.py --c3d2-only: 1 024 cubes per launch;
             # FETCH_SIZE x 2 + WRITE_SIZE), scaled to the cubes per launch here: its traffic is linear in the cubes
-            t1, t1_src = pmc_traffic("c3d2_stage1_kernel")
+            wino = bool(getattr(pipe, "depth_transform", False))
+            t1, t1_src = pmc_traffic("c3d2_stage1w_kernel" if wino else "c3d2_stage1_kernel")
+            # MFMA work the kernel really issues per cube, in direct-form GFLOP: conv1_1 recomputes the depth halo per item
+            # (1.25 x) with K padded 15 -> 16; conv1_2 direct issues its products once, depth-transformed 2/3 of them on
+            # 40 rows for every 36 (five 8-row tiles)
+            conv12_issued = 143.327232 * (2.0 / 3.0) * (40.0 / 36.0) if wino else 143.327232
             main_roofline = {"bound": "mfma", "achieved": tf1, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf1 / F32_MATRIX_PEAK_TFLOPS,
                              "traffic": None if t1 is None else t1 * float(cubes.mean()) / 1024.0, "traffic_source": t1_src,
                              "traffic_note": "PMC pass: 1 024 cubes per launch, scaled by cubes_per_launch / 1024; algorithmic "
                                              "bytes per cube: 47 520 (features, re-read 36 x from L2) + 663 552 written",
-                             "kernel": "c3d2_stage1_kernel (cube + conv1_1 + conv1_2 + pool1, v_mfma_f32_16x16x4_f32)",
+                             "kernel": ("c3d2_stage1w_kernel (cube + conv1_1 + conv1_2 via Winograd F(2,3) along depth + pool1, "
+                                        "v_mfma_f32_16x16x4_f32)") if wino else
+                                       "c3d2_stage1_kernel (cube + conv1_1 + conv1_2 + pool1, v_mfma_f32_16x16x4_f32)",
                              "avg_launch_ms": float(s1_ms.mean()), "cubes_per_launch": float(cubes.mean()),
                              "algorithmic_gflop_per_cube": STAGE1_GFLOP_PER_UTT,
-                             "issued_over_algorithmic": (143.327232 + 12.4416 * 1.25 * 16 / 15) / (143.327232 + 12.4416),
+                             "issued_over_algorithmic": (conv12_issued + 12.4416 * 1.25 * 16 / 15) / (143.327232 + 12.4416),
+                             "mfma_pipe_frac": tf1 / F32_MATRIX_PEAK_TFLOPS
+                                               * (conv12_issued + 12.4416 * 1.25 * 16 / 15) / (143.327232 + 12.4416),
                              "share_of_step": float(s1_ms.sum()) / args.steps / ms_per_step,
-                             "note": "f32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md); the kernel also issues 1.25 x "
-                                     "16/15 of conv1_1's products (depth halo recomputed per item, K padded 15 -> 16)"}
+                             "note": "achieved = SURVEY 8(d)'s direct-form multiply-adds (conv1_1 12.44 M + conv1_2 143.33 M per "
+                                     "cube) x 2 / launch time, against the f32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md). "
+                                     + ("conv1_2 runs as Winograd F(2,3) along depth: 4 MFMAs where the direct form issues 6, so "
+                                        "`frac` (algorithmic) exceeds the share of the matrix pipe's issue slots the kernel fills "
+                                        "(`mfma_pipe_frac` = frac x issued_over_algorithmic); SVK_C3D2_DEPTH_TRANSFORM=0 runs the "
+                                        "direct-form kernel" if wino else
+                                        "the kernel also issues 1.25 x 16/15 of conv1_1's products (depth halo recomputed per "
+                                        "item, K padded 15 -> 16)")}
             stage2_roofline = {"bound": "mfma", "achieved": tf2, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf2 / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
                                "kernel": "c3d2_conv21_kernel + c3d2_conv22_kernel (conv2_1, conv2_2 + pool2)",

@@ -443,8 +443,16 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       const int hl = i >> 1, wc = i & 1;
       const float* const wbase = act + 2 * (160 * WPIXF) * pair + 68 * hl + 16 * wc + 4 * kk;
       float* const obase = p.out + (int64_t)u * p.s_n + (int64_t)(TD * q + 2 * pair) * p.s_d + (int64_t)j * p.s_w + i;
-      const int tl0 = part ? 3 : 0, tl1 = part ? 5 : 3;
-      const int fetch_tl = part ? 4 : 0;
+#ifdef SVK_EXP_SWAP
+      const int tpart = part ^ 1;
+#else
+      const int tpart = part;
+#endif
+#ifdef SVK_EXP_PRIO
+      if (part) __builtin_amdgcn_s_setprio(3);
+#endif
+      const int tl0 = tpart ? 3 : 0, tl1 = tpart ? 5 : 3;
+      const int fetch_tl = tpart ? 4 : 0;
 #pragma unroll 1
       for (int tl = tl0; tl < tl1; ++tl) {
         // the next item's patch: twelve scattered 8-byte loads per row take the CU's address path ~2 000 cycles to accept;
@@ -506,6 +514,9 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
         }
       }
     }
+#ifdef SVK_EXP_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     SVK_STAMP(ts4);
     if (next < n_items) park_patch_w(patch, ph, ppiece, part, pre);
     SVK_STAMP(ts5);
