@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
   extern __shared__ __attribute__((aligned(16))) float smem_c3d2[];
   float* act = smem_c3d2;               // [WACT_FLOATS]
   float* patch = act + WACT_FLOATS;     // [P_FLOATS]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: a scalar
   const int i = lane & 15, kk = lane >> 4;
   const int pair = wave & 3, part = wave >> 2;
   const int n_items = p.n_utt * 36;
@@ -443,16 +443,11 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       const int hl = i >> 1, wc = i & 1;
       const float* const wbase = act + 2 * (160 * WPIXF) * pair + 68 * hl + 16 * wc + 4 * kk;
       float* const obase = p.out + (int64_t)u * p.s_n + (int64_t)(TD * q + 2 * pair) * p.s_d + (int64_t)j * p.s_w + i;
-#ifdef SVK_EXP_SWAP
-      const int tpart = part ^ 1;
-#else
-      const int tpart = part;
-#endif
-#ifdef SVK_EXP_PRIO
-      if (part) __builtin_amdgcn_s_setprio(3);
-#endif
-      const int tl0 = tpart ? 3 : 0, tl1 = tpart ? 5 : 3;
-      const int fetch_tl = tpart ? 4 : 0;
+      // (the SIMD's two waves do not share its issue slots evenly -- the older one, part 0, gets about two in three, and
+      // s_setprio changes nothing, measured -- but the younger one fills what the older leaves: the phase lasts the SUM
+      // of both waves' MFMA + VALU time whichever way the five tiles are split, so 3 + 2 it is)
+      const int tl0 = part ? 3 : 0, tl1 = part ? 5 : 3;
+      const int fetch_tl = part ? 4 : 0;
 #pragma unroll 1
       for (int tl = tl0; tl < tl1; ++tl) {
         // the next item's patch: twelve scattered 8-byte loads per row take the CU's address path ~2 000 cycles to accept;
@@ -478,22 +473,22 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(pb[0] + 160 * WPIXF * dd + 32);
-        // Row tap kh: 16 MFMAs on t.  The NEXT tap's t is computed in place, an element pair at a time, right behind the
-        // eight MFMAs that consumed the pair (x = the next tap's fragments, read a tap earlier): four packed adds per
-        // eight MFMAs.  (f32 MFMA and f32 VALU share the SIMD's multipliers on this chip -- neither the same wave nor the
-        // SIMD's other wave overlaps the two, measured -- so every add is paid for: packed ones cost half.)
+        // Row tap kh: 16 MFMAs on t, then the NEXT tap's t in place (x = the next tap's fragments, read a tap earlier):
+        // eight packed adds in ONE burst per tap.  (f32 MFMA and f32 VALU share the SIMD's multipliers on this chip --
+        // neither the same wave nor the SIMD's other wave overlaps the two, measured -- so every add is paid for, and
+        // every switch from MFMAs to adds and back costs ~10 cycles on top: packed adds, few bursts.)
 #pragma unroll
         for (int kh = 0; kh < 9; ++kh) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            __builtin_amdgcn_sched_barrier(0);
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+            for (int k = 0; k < 4; ++k)
+              acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e >> 1][e & 1], G[9 * k + kh][e], acc[k], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kh + 1 < 9) {
 #pragma unroll
-              for (int k = 0; k < 4; ++k)
-                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][hf][e], G[9 * k + kh][2 * hf + e], acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kh + 1 < 9) wino_input_pair(x, hf, t);
+            for (int hf = 0; hf < 2; ++hf) wino_input_pair(x, hf, t);
           }
           __builtin_amdgcn_sched_barrier(0);
           if (kh + 2 < 9) {
@@ -514,9 +509,6 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
         }
       }
     }
-#ifdef SVK_EXP_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     SVK_STAMP(ts4);
     if (next < n_items) park_patch_w(patch, ph, ppiece, part, pre);
     SVK_STAMP(ts5);
