@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 102 /* 0.1.2 */
+#define SVK_VERSION 103 /* 0.1.2 */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -264,11 +264,13 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
  *   d_in     [n_utt][16][36][18][16]  = svk_c3d2_stage1's output with folded = 0
  *   d_w21frag [2 nt][12 taps][64][4]  : lane (co = 16 nt + (l & 15), kk = l >> 4), e: W21[co][4 kk + e][kd][kw], tap 4 kd + kw
  *   d_w22frag [2 nt][24 taps][2][64][4]: W22[co][16 chunk + 4 kk + e][kd][kh], tap 8 kd + kh;  biases / slopes [32]
+ *   flags    bit 0: conv2_1 through Winograd's F(2, 3) along depth (2 / 3 of the multiply-adds; the same sums in
+ *            another association, ~1e-6 relative from the direct form), derived in the kernel from the same fragments
  *   d_act2   [n_utt][14][36][15][32]  scratch the caller provides (conv2_1's output)
  *   d_out    [n_utt][12][15][7][32]   the activation after pool2, channels last                                  */
 int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_w21frag, const float* d_bias21,
                     const float* d_slope21, const float* d_w22frag, const float* d_bias22, const float* d_slope22,
-                    float* d_act2, float* d_out);
+                    int32_t flags, float* d_act2, float* d_out);
 
 /* What follows each of conv3_1 .. conv4_2 (model.py:159-167; those convolutions run on the host framework): + bias
  * (BatchNorm folded), PReLU -- one in-place pass over channels-last activations d_x [n_rows][n_channels]

@@ -734,6 +734,121 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21_kernel(const Conv21Params 
   }
 }
 
+// ---- conv2_1 through Winograd's F(2, 3) along depth (see c3d2_stage1w_kernel): per output depth pair P and row, the
+// planes x0 .. x3 = depths 2 P .. 2 P + 3 give t0 .. t3, four accumulators per N tile, 128 MFMAs where the direct form
+// issues 192; a transformed fragment feeds 8 MFMAs (two N tiles), so the packed adds are 1 per 4 MFMAs.  Item = (cube,
+// block of 4 rows): 7 pairs x 4 rows = 28 M tiles, 7 per wave; 78 KB of LDS, two workgroups per CU; the transformed
+// weights (128 VGPRs) are derived from the direct fragments in the prologue. ----
+constexpr int C21W_TH = 4;
+constexpr int C21W_PIX = S2_D * C21W_TH * S2_W;      // 1152 pixels of 16 channels, stored at 16 p + 4 (p >> 2)
+constexpr int C21W_LDS_FLOATS = 17 * (C21W_PIX + 4);
+constexpr int C21W_DSTEP = 17 * C21W_TH * S2_W;      // floats per depth plane (72 pixels = 18 groups of 4)
+
+__global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_c21w[];
+  float* reg = smem_c21w;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  f32x4 G[2][4][4];   // [nt][k][kw]
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw) {
+      const f32x4 g0 = p.wfrag[(nt * 12 + kw) * 64 + lane], g1 = p.wfrag[(nt * 12 + 4 + kw) * 64 + lane],
+                  g2 = p.wfrag[(nt * 12 + 8 + kw) * 64 + lane];
+      G[nt][0][kw] = g0;
+      G[nt][1][kw] = 0.5f * ((g0 + g2) + g1);
+      G[nt][2][kw] = 0.5f * ((g0 + g2) - g1);
+      G[nt][3][kw] = g2;
+    }
+  float b[2], sl[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    b[nt] = p.bias[16 * nt + i];
+    sl[nt] = p.slope[16 * nt + i];
+  }
+  constexpr int BLOCKS = S2_H / C21W_TH;   // 9 row blocks per cube
+  const int n_items = p.n_utt * BLOCKS;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int u = item / BLOCKS, hb = (item - u * BLOCKS) * C21W_TH;
+    // stage [16 d][4 rows][18 w][16 c]: 18 16-byte pieces per thread, six in flight at a time
+    const float* src = p.in + (int64_t)u * (S2_D * S2_H * S2_W * 16);
+    constexpr int NV = 6;
+    static_assert(C21W_PIX * 4 % (256 * NV) == 0, "whole rounds");
+#pragma unroll 1
+    for (int base = threadIdx.x; base < C21W_PIX * 4; base += 256 * NV) {
+      f32x4 sv[NV];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int e = base + 256 * k;
+        const int pix = e >> 2, piece = e & 3;
+        const int d = pix / (C21W_TH * S2_W), rem = pix - d * (C21W_TH * S2_W);  // rem = hl * 18 + w
+        sv[k] = *reinterpret_cast<const f32x4*>(src + ((int64_t)(d * S2_H + hb) * S2_W + rem) * 16 + 4 * piece);
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int e = base + 256 * k;
+        const int pix = e >> 2, piece = e & 3;
+        *reinterpret_cast<f32x4*>(reg + 16 * pix + 4 * (pix >> 2) + 4 * piece) = sv[k];
+      }
+    }
+    __syncthreads();
+    // M tiles = (pair P, row hl): 16 pixels w' = 0 .. 15 (15 is a dummy), tile = 4 P + hl
+#pragma unroll 1
+    for (int tile = wave; tile < 7 * C21W_TH; tile += 4) {
+      const int P = tile >> 2, hl = tile & 3;
+      const int p0 = (2 * P * C21W_TH + hl) * S2_W + i;
+      const float* ab[4];
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw) ab[kw] = reg + 16 * (p0 + kw) + 4 * ((p0 + kw) >> 2) + 4 * kk;
+      f32x4 acc[2][4];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[nt][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 x[4];
+      f32x2 t[4][2];
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ab[0] + C21W_DSTEP * dd);
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw) {
+        // this tap's transformed fragments (8 packed adds, one burst), the next tap's reads, 32 MFMAs
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) wino_input_pair(x, hf, t);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kw + 1 < 4) {
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ab[kw + 1] + C21W_DSTEP * dd);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              acc[nt][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e >> 1][e & 1], G[nt][k][kw][e], acc[nt][k], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // rows 4 kk + r = output column w'; column i = channel 16 nt + i; depths 2 P and 2 P + 1
+      float* o = p.out + (((int64_t)u * A2_D + 2 * P) * S2_H + hb + hl) * (A2_W * 32) + i;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 y0 = acc[nt][0] + acc[nt][1] + acc[nt][2] + b[nt], y1 = acc[nt][1] - acc[nt][2] - acc[nt][3] + b[nt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int wq = 4 * kk + r;
+          if (wq < A2_W) {
+            o[wq * 32 + 16 * nt] = prelu(y0[r], sl[nt]);
+            o[(int64_t)S2_H * (A2_W * 32) + wq * 32 + 16 * nt] = prelu(y1[r], sl[nt]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- conv2_2 + pool2: taps along h (stride 2).  Item = (cube, pooled column j, half q of the output depths) ----
 constexpr int C22_TD = 6;                                  // output depths per item
 constexpr int C22_PIX = (C22_TD + 2) * 2 * S2_H;           // [8 d][2 w][36 h] pixels of 32 channels at 32 p + 4 (p >> 1)
@@ -852,7 +967,7 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22_kernel(const Conv22Params 
 
 extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_w21frag,
                                const float* d_bias21, const float* d_slope21, const float* d_w22frag,
-                               const float* d_bias22, const float* d_slope22, float* d_act2, float* d_out) {
+                               const float* d_bias22, const float* d_slope22, int32_t flags, float* d_act2, float* d_out) {
   if (!ctx) return SVK_ERR_BAD_ARG;
   SVK_REQUIRE(ctx, n_utt >= 0, "n_utt negative");
   if (n_utt == 0) return SVK_OK;
@@ -864,16 +979,17 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   SVK_REQUIRE(ctx, (int64_t)n_utt * 14 < ((int64_t)1 << 31), "too many cubes for one launch");
   {
     Conv21Params p{d_in, reinterpret_cast<const f32x4*>(d_w21frag), d_bias21, d_slope21, d_act2, n_utt};
-    const size_t lds = sizeof(float) * (size_t)C21_LDS_FLOATS;
-    SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(c3d2_conv21_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t items = (int64_t)n_utt * (S2_H / C21_TH);
+    const bool wino = (flags & 1) != 0;   // conv2_1 through the depth transform
+    void (*kern)(const Conv21Params) = wino ? c3d2_conv21w_kernel : c3d2_conv21_kernel;
+    const size_t lds = sizeof(float) * (size_t)(wino ? C21W_LDS_FLOATS : C21_LDS_FLOATS);
+    SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t items = (int64_t)n_utt * (S2_H / (wino ? C21W_TH : C21_TH));
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(c3d2_conv21_kernel), 256, lds) !=
-            hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess ||
+        per_cu < 1)
       per_cu = 2;
-    hipLaunchKernelGGL(c3d2_conv21_kernel, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(256),
-                       lds, ctx->stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(256), lds,
+                       ctx->stream, p);
     SVK_LAUNCH_CHECK(ctx);
   }
   {

@@ -435,9 +435,10 @@ class Engine:
               self.ctx)
         return out
 
-    def c3d2_stage2(self, act1, tables):
+    def c3d2_stage2(self, act1, tables, depth_transform=False):
         """svk_c3d2_stage2: [n, 16, 36, 18, 16] (svk_c3d2_stage1, folded = 0) -> conv2_1 -> conv2_2 -> pool2 with
-        their BN + PReLU -> [n, 12, 15, 7, 32] f32 (channels last)."""
+        their BN + PReLU -> [n, 12, 15, 7, 32] f32 (channels last).  `depth_transform`: conv2_1 through Winograd's
+        F(2, 3) along depth."""
         torch = _torch()
         n = act1.shape[0]
         w21, b21, s21, w22, b22, s22 = tables
@@ -445,8 +446,8 @@ class Engine:
         out = torch.empty((n, 12, 15, 7, 32), dtype=torch.float32, device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_stage2(self.ctx, self._ptr(act1), n, self._ptr(w21), self._ptr(b21), self._ptr(s21),
-                                       self._ptr(w22), self._ptr(b22), self._ptr(s22), self._ptr(act2), self._ptr(out)),
-              self.ctx)
+                                       self._ptr(w22), self._ptr(b22), self._ptr(s22), 1 if depth_transform else 0,
+                                       self._ptr(act2), self._ptr(out)), self.ctx)
         return out
 
     def bias_prelu_(self, x, bias, slope):

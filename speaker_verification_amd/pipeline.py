@@ -43,7 +43,8 @@ class VerificationPipeline:
         # SVK_C3D2_STAGE1=0: run the first block on PyTorch-ROCm too (A/B and parity tests)
         self.stage1_kernel = os.environ.get("SVK_C3D2_STAGE1", "1") != "0"
         self.stage2_kernel = self.stage1_kernel and os.environ.get("SVK_C3D2_STAGE2", "1") != "0"
-        # conv1_2 through Winograd's F(2, 3) along depth (2 / 3 of the multiply-adds); SVK_C3D2_DEPTH_TRANSFORM=0 = direct sums
+        # conv1_2 and conv2_1 through Winograd's F(2, 3) along depth (2 / 3 of the multiply-adds);
+        # SVK_C3D2_DEPTH_TRANSFORM=0 = direct sums
         self.depth_transform = os.environ.get("SVK_C3D2_DEPTH_TRANSFORM", "1") != "0"
         # bench.py sets this to a list: HIP events (on the launch stream) around the first- and second-block kernels
         self.kernel_events = None
@@ -160,7 +161,7 @@ class VerificationPipeline:
                                          depth_transform=self.depth_transform)
                 if rec:
                     ev[1].record()
-                z = self.eng.c3d2_stage2(y, tables2)
+                z = self.eng.c3d2_stage2(y, tables2, depth_transform=self.depth_transform)
                 if rec:
                     ev[2].record()
                     self.kernel_events.append((ev, feat.shape[0]))

@@ -1314,6 +1314,12 @@ def test_c3d2_second_block_kernels(eng):
         want = F.max_pool3d(x, kernel_size=(1, 1, 2), stride=(1, 1, 2)).numpy()          # (n, 32, 12, 15, 7)
     got = eng.c3d2_stage2(eng.to_device(act1), tables).cpu().numpy()                      # [n][12][15][7][32]
     np.testing.assert_allclose(got.transpose(0, 4, 1, 2, 3), want, rtol=1e-4, atol=2e-6 * np.abs(want).max())
+    # conv2_1 through Winograd's F(2, 3) along depth: the same sums in another association
+    got_w = eng.c3d2_stage2(eng.to_device(act1), tables, depth_transform=True).cpu().numpy()
+    np.testing.assert_allclose(got_w.transpose(0, 4, 1, 2, 3), want, rtol=1e-4, atol=4e-6 * np.abs(want).max())
+    print("second block, max |diff| / scale: direct %.2e, conv2_1 depth-transformed %.2e"
+          % (np.abs(got.transpose(0, 4, 1, 2, 3) - want).max() / np.abs(want).max(),
+             np.abs(got_w.transpose(0, 4, 1, 2, 3) - want).max() / np.abs(want).max()))
 
 
 def test_bench_two_ranks_share_one_gpu():
@@ -1374,7 +1380,7 @@ def test_network_block_error_paths(eng):
     with pytest.raises(_lib.SvkError, match="20 x 80 x 40"):
         eng.c3d2_stage1(feat, torch.zeros((2, 19), dtype=torch.int32, device=eng.device), tables)
     assert eng.lib.svk_c3d2_stage1(eng.ctx, None, 1, 100, 40, None, 20, 80, None, None, None, None, None, None, 0, None) == -1
-    assert eng.lib.svk_c3d2_stage2(eng.ctx, None, 1, None, None, None, None, None, None, None, None) == -1
+    assert eng.lib.svk_c3d2_stage2(eng.ctx, None, 1, None, None, None, None, None, None, 0, None, None) == -1
     assert eng.lib.svk_c3d2_stage1_lds_bytes() <= eng.lds_per_cu
     # empty batch: nothing launched, nothing touched
     assert eng.lib.svk_c3d2_stage1(eng.ctx, None, 0, 100, 40, None, 20, 80, None, None, None, None, None, None, 0, None) == 0

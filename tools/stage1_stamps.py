@@ -35,13 +35,20 @@ def main():
         print("svk_c3d2_stage1, 1024 cubes, depth_transform=%s: %.3f ms" % (mode, a.elapsed_time(b) / 20), file=sys.stderr)
     t2 = emb.stage2_tables()
     y = eng.c3d2_stage1(feat, crops, t1, folded=False)
-    for _ in range(10):
-        eng.c3d2_stage2(y, t2)
-    torch.cuda.synchronize()
+    for mode in (False, True):
+        for _ in range(10):
+            eng.c3d2_stage2(y, t2, depth_transform=mode)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            eng.c3d2_stage2(y, t2, depth_transform=mode)
+        b.record()
+        torch.cuda.synchronize()
+        print("svk_c3d2_stage2, 1024 cubes, depth_transform=%s: %.3f ms" % (mode, a.elapsed_time(b) / 20), file=sys.stderr)
     os.environ["SVK_C3D2_STAMPS"] = "1"
     y = eng.c3d2_stage1(feat, crops, t1, folded=False, depth_transform=dt)
     torch.cuda.synchronize()
-    eng.c3d2_stage2(y, t2)
+    eng.c3d2_stage2(y, t2, depth_transform=dt)
     torch.cuda.synchronize()
 
 
