@@ -744,6 +744,7 @@ constexpr int C21W_PIX = S2_D * C21W_TH * S2_W;      // 1152 pixels of 16 channe
 constexpr int C21W_LDS_FLOATS = 17 * (C21W_PIX + 4);
 constexpr int C21W_DSTEP = 17 * C21W_TH * S2_W;      // floats per depth plane (72 pixels = 18 groups of 4)
 
+template <bool SLOPE01>
 __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem_c21w[];
   float* reg = smem_c21w;
@@ -801,11 +802,12 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
       const float* ab[4];
 #pragma unroll
       for (int kw = 0; kw < 4; ++kw) ab[kw] = reg + 16 * (p0 + kw) + 4 * ((p0 + kw) >> 2) + 4 * kk;
+      // (a1 enters both outputs with a plus sign: the bias rides in its accumulator)
       f32x4 acc[2][4];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[nt][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 4; ++k) acc[nt][k] = k == 1 ? (f32x4){b[nt], b[nt], b[nt], b[nt]} : (f32x4){0.f, 0.f, 0.f, 0.f};
       f32x4 x[4];
       f32x2 t[4][2];
 #pragma unroll
@@ -834,13 +836,23 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
       float* o = p.out + (((int64_t)u * A2_D + 2 * P) * S2_H + hb + hl) * (A2_W * 32) + i;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const f32x4 y0 = acc[nt][0] + acc[nt][1] + acc[nt][2] + b[nt], y1 = acc[nt][1] - acc[nt][2] - acc[nt][3] + b[nt];
+        // y0 = (a0 + a1) + a2, y1 = (a1 - a2) - a3 as packed adds (every VALU instruction here is paid in MFMA slots)
+        f32x2 y0[2], y1[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f32x2 a0 = hf ? __builtin_shufflevector(acc[nt][0], acc[nt][0], 2, 3) : __builtin_shufflevector(acc[nt][0], acc[nt][0], 0, 1);
+          const f32x2 a1 = hf ? __builtin_shufflevector(acc[nt][1], acc[nt][1], 2, 3) : __builtin_shufflevector(acc[nt][1], acc[nt][1], 0, 1);
+          const f32x2 a2 = hf ? __builtin_shufflevector(acc[nt][2], acc[nt][2], 2, 3) : __builtin_shufflevector(acc[nt][2], acc[nt][2], 0, 1);
+          const f32x2 a3 = hf ? __builtin_shufflevector(acc[nt][3], acc[nt][3], 2, 3) : __builtin_shufflevector(acc[nt][3], acc[nt][3], 0, 1);
+          y0[hf] = pk_add(pk_add(a0, a1), a2);
+          y1[hf] = pk_sub(pk_sub(a1, a2), a3);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int wq = 4 * kk + r;
           if (wq < A2_W) {
-            o[wq * 32 + 16 * nt] = prelu(y0[r], sl[nt]);
-            o[(int64_t)S2_H * (A2_W * 32) + wq * 32 + 16 * nt] = prelu(y1[r], sl[nt]);
+            o[wq * 32 + 16 * nt] = prelu_t<SLOPE01>(y0[r >> 1][r & 1], sl[nt]);
+            o[(int64_t)S2_H * (A2_W * 32) + wq * 32 + 16 * nt] = prelu_t<SLOPE01>(y1[r >> 1][r & 1], sl[nt]);
           }
         }
       }
@@ -980,7 +992,8 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   {
     Conv21Params p{d_in, reinterpret_cast<const f32x4*>(d_w21frag), d_bias21, d_slope21, d_act2, n_utt};
     const bool wino = (flags & 1) != 0;   // conv2_1 through the depth transform
-    void (*kern)(const Conv21Params) = wino ? c3d2_conv21w_kernel : c3d2_conv21_kernel;
+    void (*kern)(const Conv21Params) = !wino ? c3d2_conv21_kernel
+                                       : (flags & 2) ? c3d2_conv21w_kernel<true> : c3d2_conv21w_kernel<false>;
     const size_t lds = sizeof(float) * (size_t)(wino ? C21W_LDS_FLOATS : C21_LDS_FLOATS);
     SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t items = (int64_t)n_utt * (S2_H / (wino ? C21W_TH : C21_TH));

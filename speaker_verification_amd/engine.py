@@ -441,12 +441,14 @@ class Engine:
         F(2, 3) along depth."""
         torch = _torch()
         n = act1.shape[0]
-        w21, b21, s21, w22, b22, s22 = tables
+        w21, b21, s21, w22, b22, s22 = tables[:6]
+        slope01 = bool(tables[6]) if len(tables) > 6 else False          # every slope in [0, 1]: the two-instruction PReLU
         act2 = torch.empty((n, 14, 36, 15, 32), dtype=torch.float32, device=self.device)
         out = torch.empty((n, 12, 15, 7, 32), dtype=torch.float32, device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_stage2(self.ctx, self._ptr(act1), n, self._ptr(w21), self._ptr(b21), self._ptr(s21),
-                                       self._ptr(w22), self._ptr(b22), self._ptr(s22), 1 if depth_transform else 0,
+                                       self._ptr(w22), self._ptr(b22), self._ptr(s22),
+                                       (1 if depth_transform else 0) | (2 if slope01 else 0),
                                        self._ptr(act2), self._ptr(out)), self.ctx)
         return out
 

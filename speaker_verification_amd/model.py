@@ -291,8 +291,9 @@ class FusedEmbedder:
 
         def per_channel(t, n):
             return t.expand(n).contiguous() if t.numel() == 1 else t.contiguous()
+        slope01 = bool(((s1 >= 0) & (s1 <= 1)).all() and ((s2 >= 0) & (s2 <= 1)).all())   # one host read per checkpoint
         self._stage2 = (f21.contiguous(), b1.contiguous(), per_channel(s1, 32), f22.contiguous(), b2.contiguous(),
-                        per_channel(s2, 32))
+                        per_channel(s2, 32), slope01)
         return self._stage2
 
     @torch.no_grad()

@@ -1317,6 +1317,9 @@ def test_c3d2_second_block_kernels(eng):
     # conv2_1 through Winograd's F(2, 3) along depth: the same sums in another association
     got_w = eng.c3d2_stage2(eng.to_device(act1), tables, depth_transform=True).cpu().numpy()
     np.testing.assert_allclose(got_w.transpose(0, 4, 1, 2, 3), want, rtol=1e-4, atol=4e-6 * np.abs(want).max())
+    assert tables[6]                                       # slopes in [0.1, 0.4]: the two-instruction PReLU ran above
+    got_g = eng.c3d2_stage2(eng.to_device(act1), tables[:6] + (False,), depth_transform=True).cpu().numpy()
+    np.testing.assert_array_equal(got_g, got_w)            # general and [0, 1] PReLU forms agree bit for bit
     print("second block, max |diff| / scale: direct %.2e, conv2_1 depth-transformed %.2e"
           % (np.abs(got.transpose(0, 4, 1, 2, 3) - want).max() / np.abs(want).max(),
              np.abs(got_w.transpose(0, 4, 1, 2, 3) - want).max() / np.abs(want).max()))
