@@ -267,6 +267,7 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
  *   flags    bit 0: conv2_1 through Winograd's F(2, 3) along depth (2 / 3 of the multiply-adds; the same sums in
  *            another association, ~1e-6 relative from the direct form), derived in the kernel from the same fragments;
  *            bit 1: the caller asserts every PReLU slope lies in [0, 1] (as `folded` bit 1 of svk_c3d2_stage1)
+ *            bit 2: conv2_2 through the same transform
  *   d_act2   [n_utt][14][36][15][32]  scratch the caller provides (conv2_1's output)
  *   d_out    [n_utt][12][15][7][32]   the activation after pool2, channels last                                  */
 int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_w21frag, const float* d_bias21,

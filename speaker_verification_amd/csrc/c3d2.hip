@@ -974,6 +974,141 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22_kernel(const Conv22Params 
 #endif
 }
 
+// ---- conv2_2 + pool2 through the depth transform.  Its transformed weights are 4 x 8 x 32 x 32 floats = 512 VGPRs
+// x 64 lanes: exactly the registers of four waves at two workgroups per CU, so every weight lives in ONE wave and each
+// wave = (N tile nt, 16-channel K chunk ch) holds 32 fragments and produces PARTIAL sums over its half of K.  Item =
+// (cube, pooled column j, third q of the output depths): two depth pairs x two columns = four M tiles (16 output rows,
+// 15 real) of 8 row taps x 16 MFMAs per wave.  The two waves of an N tile swap partial sums through LDS: each writes the
+// output-transformed sums of the pair it does not finish, keeps those of the pair it does (ch finishes pair ch), and
+// after the barrier adds its partner's, then bias (carried by chunk 0's accumulator), PReLU, max over the column pair. ----
+constexpr int C22W_TD = 4;                                   // output depths per item
+constexpr int C22W_PIX = (C22W_TD + 2) * 2 * S2_H;           // [6 d][2 w][36 h] pixels of 32 channels at 32 p + 4 (p >> 1)
+constexpr int C22W_IN_FLOATS = 34 * (C22W_PIX + 4);
+constexpr int C22W_XCH_FLOATS = 2 * 2 * 2 * 2 * 64 * 4;      // [nt][pair][column][y][lane] f32x4
+constexpr int C22W_LDS_FLOATS = C22W_IN_FLOATS + C22W_XCH_FLOATS;
+constexpr int C22W_PLANE = 34 * 2 * S2_H, C22W_COL = 34 * S2_H;   // floats per depth plane / per column inside it
+
+template <bool SLOPE01>
+__global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_c22w[];
+  float* reg = smem_c22w;
+  float* exch = reg + C22W_IN_FLOATS;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  const int nt = wave & 1, ch = wave >> 1;
+  f32x4 G[4][8];   // [k][kh], this wave's N tile and K chunk
+#pragma unroll
+  for (int kh = 0; kh < 8; ++kh) {
+    const f32x4 g0 = p.wfrag[((nt * 24 + kh) * 2 + ch) * 64 + lane], g1 = p.wfrag[((nt * 24 + 8 + kh) * 2 + ch) * 64 + lane],
+                g2 = p.wfrag[((nt * 24 + 16 + kh) * 2 + ch) * 64 + lane];
+    G[0][kh] = g0;
+    G[1][kh] = 0.5f * ((g0 + g2) + g1);
+    G[2][kh] = 0.5f * ((g0 + g2) - g1);
+    G[3][kh] = g2;
+  }
+  const float b = ch == 0 ? p.bias[16 * nt + i] : 0.f, sl = p.slope[16 * nt + i];
+  const float* const a0 = reg + 68 * i + 4 * kk + 16 * ch;   // row 2 i of column 0 of plane 0, this lane's K piece
+  constexpr int PER_CUBE = O2_W * (O2_D / C22W_TD);           // 7 x 3 items
+  const int n_items = p.n_utt * PER_CUBE;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int u = item / PER_CUBE, rem = item - u * PER_CUBE, q = rem / O2_W, j = rem - q * O2_W;
+    // stage [6 d][36 h][2 w][32 c] of the input as pixels p = (dl * 2 + w) * 36 + h (h fastest): 13.5 16-byte pieces per
+    // thread, seven in flight at a time
+    const float* src = p.in + ((int64_t)u * A2_D + C22W_TD * q) * (S2_H * A2_W * 32) + 2 * j * 32;
+    constexpr int NV = 7;
+#pragma unroll 1
+    for (int base = threadIdx.x; base < C22W_PIX * 8; base += 256 * NV) {
+      f32x4 sv[NV];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int e = base + 256 * k;
+        const int piece = e & 7, wq = (e >> 3) & 1, dh = e >> 4;   // dh = dl * 36 + h
+        if (e < C22W_PIX * 8) sv[k] = *reinterpret_cast<const f32x4*>(src + (int64_t)dh * (A2_W * 32) + wq * 32 + 4 * piece);
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int e = base + 256 * k;
+        const int piece = e & 7, wq = (e >> 3) & 1, dh = e >> 4;
+        const int dl = dh / S2_H, h = dh - dl * S2_H;
+        const int pix = (dl * 2 + wq) * S2_H + h;
+        if (e < C22W_PIX * 8) *reinterpret_cast<f32x4*>(reg + 32 * pix + 4 * (pix >> 1) + 4 * piece) = sv[k];
+      }
+    }
+    __syncthreads();
+    f32x4 own[2][2];   // [column][y]: the partial sums of the pair this wave finishes
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const int P = pass ? ch : 1 - ch;   // the partner's pair first
+#pragma unroll
+      for (int wq = 0; wq < 2; ++wq) {
+        const float* ap = a0 + 2 * C22W_PLANE * P + C22W_COL * wq;
+        f32x4 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = k == 1 ? (f32x4){b, b, b, b} : (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 x[4];
+        f32x2 t[4][2];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C22W_PLANE * dd);
+#pragma unroll
+        for (int kh = 0; kh < 8; ++kh) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) wino_input_pair(x, hf, t);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kh + 1 < 8) {
+            const int off = 32 * (kh + 1) + 4 * ((kh + 1) >> 1);
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C22W_PLANE * dd + off);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e >> 1][e & 1], G[k][kh][e], acc[k], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 y0, y1;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f32x2 c0 = hf ? __builtin_shufflevector(acc[0], acc[0], 2, 3) : __builtin_shufflevector(acc[0], acc[0], 0, 1);
+          const f32x2 c1 = hf ? __builtin_shufflevector(acc[1], acc[1], 2, 3) : __builtin_shufflevector(acc[1], acc[1], 0, 1);
+          const f32x2 c2 = hf ? __builtin_shufflevector(acc[2], acc[2], 2, 3) : __builtin_shufflevector(acc[2], acc[2], 0, 1);
+          const f32x2 c3 = hf ? __builtin_shufflevector(acc[3], acc[3], 2, 3) : __builtin_shufflevector(acc[3], acc[3], 0, 1);
+          const f32x2 s0 = pk_add(pk_add(c0, c1), c2), s1 = pk_sub(pk_sub(c1, c2), c3);
+          y0[2 * hf] = s0[0];
+          y0[2 * hf + 1] = s0[1];
+          y1[2 * hf] = s1[0];
+          y1[2 * hf + 1] = s1[1];
+        }
+        if (pass == 0) {
+          float* xo = exch + ((((nt * 2 + P) * 2 + wq) * 2) * 64 + lane) * 4;
+          *reinterpret_cast<f32x4*>(xo) = y0;
+          *reinterpret_cast<f32x4*>(xo + 256) = y1;
+        } else {
+          own[wq][0] = y0;
+          own[wq][1] = y1;
+        }
+      }
+    }
+    __syncthreads();   // the partner's partial sums are in LDS; nobody reads the input region any more
+    {
+      const float* xi = exch + ((((nt * 2 + ch) * 2) * 2) * 64 + lane) * 4;   // pair ch, written by wave (nt, 1 - ch)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        const f32x4 v0 = own[0][y] + *reinterpret_cast<const f32x4*>(xi + 256 * y);
+        const f32x4 v1 = own[1][y] + *reinterpret_cast<const f32x4*>(xi + 512 + 256 * y);
+        // rows 4 kk + r = output row h'; pool over the column pair, PReLU first (model.py:156-158)
+        float* o = p.out + ((((int64_t)u * O2_D + C22W_TD * q + 2 * ch + y) * O2_H) * O2_W + j) * 32 + 16 * nt + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int hq = 4 * kk + r;
+          if (hq < O2_H) o[(int64_t)hq * (O2_W * 32)] = fmaxf(prelu_t<SLOPE01>(v0[r], sl), prelu_t<SLOPE01>(v1[r], sl));
+        }
+      }
+    }
+  }
+}
+
 
 }  // namespace
 
@@ -988,7 +1123,7 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_act2) |
                      reinterpret_cast<uintptr_t>(d_w21frag) | reinterpret_cast<uintptr_t>(d_w22frag)) & 15) == 0,
               "buffers must be 16-byte aligned");
-  SVK_REQUIRE(ctx, (int64_t)n_utt * 14 < ((int64_t)1 << 31), "too many cubes for one launch");
+  SVK_REQUIRE(ctx, (int64_t)n_utt * 21 < ((int64_t)1 << 31), "too many cubes for one launch");
   {
     Conv21Params p{d_in, reinterpret_cast<const f32x4*>(d_w21frag), d_bias21, d_slope21, d_act2, n_utt};
     const bool wino = (flags & 1) != 0;   // conv2_1 through the depth transform
@@ -1007,6 +1142,20 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   }
   {
     Conv22Params p{d_act2, reinterpret_cast<const f32x4*>(d_w22frag), d_bias22, d_slope22, d_out, n_utt, nullptr};
+    if (flags & 4) {   // conv2_2 through the depth transform
+      void (*kern)(const Conv22Params) = (flags & 2) ? c3d2_conv22w_kernel<true> : c3d2_conv22w_kernel<false>;
+      const size_t lds = sizeof(float) * (size_t)C22W_LDS_FLOATS;
+      SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const int64_t items = (int64_t)n_utt * (O2_W * (O2_D / C22W_TD));
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess ||
+          per_cu < 1)
+        per_cu = 2;
+      hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(256), lds,
+                         ctx->stream, p);
+      SVK_LAUNCH_CHECK(ctx);
+      return SVK_OK;
+    }
     const size_t lds = sizeof(float) * (size_t)C22_LDS_FLOATS;
     SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(c3d2_conv22_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

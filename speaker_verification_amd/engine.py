@@ -437,8 +437,8 @@ class Engine:
 
     def c3d2_stage2(self, act1, tables, depth_transform=False):
         """svk_c3d2_stage2: [n, 16, 36, 18, 16] (svk_c3d2_stage1, folded = 0) -> conv2_1 -> conv2_2 -> pool2 with
-        their BN + PReLU -> [n, 12, 15, 7, 32] f32 (channels last).  `depth_transform`: conv2_1 through Winograd's
-        F(2, 3) along depth."""
+        their BN + PReLU -> [n, 12, 15, 7, 32] f32 (channels last).  `depth_transform`: both convolutions through
+        Winograd's F(2, 3) along depth (True), or the flag bits of include/svk.h: 1 = conv2_1 only, 4 = conv2_2 only."""
         torch = _torch()
         n = act1.shape[0]
         w21, b21, s21, w22, b22, s22 = tables[:6]
@@ -448,7 +448,8 @@ class Engine:
         self._stream()
         check(self.lib.svk_c3d2_stage2(self.ctx, self._ptr(act1), n, self._ptr(w21), self._ptr(b21), self._ptr(s21),
                                        self._ptr(w22), self._ptr(b22), self._ptr(s22),
-                                       (1 if depth_transform else 0) | (2 if slope01 else 0),
+                                       (depth_transform if isinstance(depth_transform, int) and not isinstance(depth_transform, bool)
+                                        else 5 if depth_transform else 0) | (2 if slope01 else 0),
                                        self._ptr(act2), self._ptr(out)), self.ctx)
         return out
 

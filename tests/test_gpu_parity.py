@@ -1314,15 +1314,18 @@ def test_c3d2_second_block_kernels(eng):
         want = F.max_pool3d(x, kernel_size=(1, 1, 2), stride=(1, 1, 2)).numpy()          # (n, 32, 12, 15, 7)
     got = eng.c3d2_stage2(eng.to_device(act1), tables).cpu().numpy()                      # [n][12][15][7][32]
     np.testing.assert_allclose(got.transpose(0, 4, 1, 2, 3), want, rtol=1e-4, atol=2e-6 * np.abs(want).max())
-    # conv2_1 through Winograd's F(2, 3) along depth: the same sums in another association
-    got_w = eng.c3d2_stage2(eng.to_device(act1), tables, depth_transform=True).cpu().numpy()
-    np.testing.assert_allclose(got_w.transpose(0, 4, 1, 2, 3), want, rtol=1e-4, atol=4e-6 * np.abs(want).max())
+    # the convolutions through Winograd's F(2, 3) along depth (the same sums in another association): conv2_1 alone,
+    # conv2_2 alone (partial sums over the two K chunks swapped through LDS), both
     assert tables[6]                                       # slopes in [0.1, 0.4]: the two-instruction PReLU ran above
-    got_g = eng.c3d2_stage2(eng.to_device(act1), tables[:6] + (False,), depth_transform=True).cpu().numpy()
-    np.testing.assert_array_equal(got_g, got_w)            # general and [0, 1] PReLU forms agree bit for bit
-    print("second block, max |diff| / scale: direct %.2e, conv2_1 depth-transformed %.2e"
-          % (np.abs(got.transpose(0, 4, 1, 2, 3) - want).max() / np.abs(want).max(),
-             np.abs(got_w.transpose(0, 4, 1, 2, 3) - want).max() / np.abs(want).max()))
+    scale = np.abs(want).max()
+    for bits in (1, 4, True):
+        got_w = eng.c3d2_stage2(eng.to_device(act1), tables, depth_transform=bits).cpu().numpy()
+        np.testing.assert_allclose(got_w.transpose(0, 4, 1, 2, 3), want, rtol=1e-4, atol=4e-6 * scale)
+        got_g = eng.c3d2_stage2(eng.to_device(act1), tables[:6] + (False,), depth_transform=bits).cpu().numpy()
+        np.testing.assert_array_equal(got_g, got_w)        # general and [0, 1] PReLU forms agree bit for bit
+        print("second block, depth transform bits %s: max |diff| / scale %.2e (direct %.2e)"
+              % (bits, np.abs(got_w.transpose(0, 4, 1, 2, 3) - want).max() / scale,
+                 np.abs(got.transpose(0, 4, 1, 2, 3) - want).max() / scale))
 
 
 def test_bench_two_ranks_share_one_gpu():
