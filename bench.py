@@ -723,10 +723,15 @@ def main():
                                         "direct-form kernel" if wino else
                                         "the kernel also issues 1.25 x 16/15 of conv1_1's products (depth halo recomputed per "
                                         "item, K padded 15 -> 16)")}
+            # both kernels pad 15 output positions to a 16-row M tile; depth-transformed they issue 2/3 of the products
+            issued2 = (16.0 / 15.0) * (2.0 / 3.0 if wino else 1.0)
             stage2_roofline = {"bound": "mfma", "achieved": tf2, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf2 / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
-                               "kernel": "c3d2_conv21_kernel + c3d2_conv22_kernel (conv2_1, conv2_2 + pool2)",
+                               "kernel": ("c3d2_conv21w_kernel + c3d2_conv22w_kernel (conv2_1, conv2_2 + pool2 via Winograd "
+                                          "F(2,3) along depth)") if wino else
+                                         "c3d2_conv21_kernel + c3d2_conv22_kernel (conv2_1, conv2_2 + pool2)",
                                "avg_launch_ms": float(s2_ms.mean()), "algorithmic_gflop_per_cube": STAGE2_GFLOP_PER_UTT,
+                               "issued_over_algorithmic": issued2, "mfma_pipe_frac": tf2 / F32_MATRIX_PEAK_TFLOPS * issued2,
                                "share_of_step": float(s2_ms.sum()) / args.steps / ms_per_step}
         result = {
             "metric": "utterances/sec (MFCC->embed->cosine)", "value": value, "unit": "utterances/s",
@@ -752,7 +757,8 @@ def main():
                              "note": "whole step vs the dense f32 matrix peak of the N GPUs: the C3D2 forward "
                                      "(676.6 MFLOP per utterance: conv1_1 .. pool2 in libsvk MFMA kernels, conv3_1 .. FC5 "
                                      "on PyTorch-ROCm / MIOpen) is ~95 % of the step; SURVEY 8(d) ceiling = 232 k utt/s "
-                                     "per GPU"},
+                                     "per GPU for the direct-form sums (conv1_2, conv2_1, conv2_2 -- 76 % of the multiply-adds -- "
+                                     "run through Winograd F(2,3) along depth and issue 2/3 of theirs)"},
             "eer": {"eer": eer, "auc": auc, "eer_device": eer_dev, "auc_device": auc_dev, "pairs": int(labels.size),
                     "short_clips": bad},
         }

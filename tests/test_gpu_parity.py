@@ -1366,8 +1366,11 @@ def test_bench_two_ranks_share_one_gpu():
         assert "synthetic" in rec["data"] and "5001-clip corpus" in rec["config"]["workload"]
         roof = rec["roofline"]
         assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
-        assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"]) and 0.2 < roof["frac"] < 1.0
-        assert "c3d2_stage1_kernel" in roof["kernel"] and roof["avg_launch_ms"] > 0
+        # (frac counts SURVEY 8(d)'s direct-form multiply-adds: with conv1_2 through the depth transform -- 2/3 of the
+        # products -- it may pass 1; the share of the matrix pipe's issue slots is mfma_pipe_frac)
+        assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"]) and 0.2 < roof["frac"] < 1.5
+        assert 0.2 < roof["mfma_pipe_frac"] < 1.0 and roof["mfma_pipe_frac"] == pytest.approx(roof["frac"] * roof["issued_over_algorithmic"])
+        assert "c3d2_stage1w_kernel" in roof["kernel"] and roof["avg_launch_ms"] > 0
         assert rec["roofline_frontend"]["bound"] == "hbm" and rec["roofline_e2e"]["bound"] == "mfma"
 
 
