@@ -274,6 +274,16 @@ int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float*
                     const float* d_slope21, const float* d_w22frag, const float* d_bias22, const float* d_slope22,
                     int32_t flags, float* d_act2, float* d_out);
 
+/* conv3_1 (32 -> 64, kernel (3,1,3)) -> BN -> PReLU, model.py:126-128 + :159-161, one f32-MFMA kernel through Winograd's
+ * F(2, 3) along depth (as svk_c3d2_stage2 flags bits 0 / 2; there is no direct-form variant of this one).
+ *   d_in    [n_utt][12][15][7][32]   = svk_c3d2_stage2's output
+ *   d_wfrag [4 nt][9 taps][2 chunks][64][4]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: W31[co][16 chunk + 4 kk + e][kd][kw],
+ *           tap 3 kd + kw (BatchNorm folded);  d_bias / d_slope [64]
+ *   flags   bit 1: the caller asserts every PReLU slope lies in [0, 1]
+ *   d_out   [n_utt][10][15][5][64]   channels last                                                                    */
+int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
+                    const float* d_slope, int32_t flags, float* d_out);
+
 /* What follows each of conv3_1 .. conv4_2 (model.py:159-167; those convolutions run on the host framework): + bias
  * (BatchNorm folded), PReLU -- one in-place pass over channels-last activations d_x [n_rows][n_channels]
  * (n_channels a multiple of 4): x <- prelu(x + bias[c], slope[c]).                                            */

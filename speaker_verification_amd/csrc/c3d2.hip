@@ -1109,6 +1109,123 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
   }
 }
 
+// ---- conv3_1 (32 -> 64, kernel (3,1,3)) + BN + PReLU (model.py:126-128, :159-161), depth-transformed like the kernels
+// above.  No taps along h, so item = (cube, block of 3 rows): region 12 depths x 3 rows x 7 columns of 32 channels
+// (36 KB as pixels of 36 floats: pixel stride 9 sixteen-byte slots, odd, so pixels that differ mod 16 never share a bank
+// slot; the 15 pixels of a tile span 19, three lanes of a quarter wave take a second pass).  M tile = 3 rows x 5 output
+// columns of one depth pair (15 positions + 1 dummy), five tiles per item; wave = N tile (16 of the 64 output channels),
+// 4 k x 3 kw x 2 chunks = 24 weight fragments = 96 VGPRs; 96 MFMAs per tile where the direct form issues 144. ----
+constexpr int C31_PIXF = 36;
+constexpr int C31_PIX = 12 * 3 * 7;                           // pixel p = (d * 3 + hl) * 7 + w
+constexpr int C31_LDS_FLOATS = C31_PIXF * C31_PIX;
+constexpr int C31_PLANE = C31_PIXF * 21;                      // floats per depth plane
+
+struct Conv31Params {
+  const float* in;      // [n][12][15][7][32]
+  const f32x4* wfrag;   // [4 nt][9 taps][2 chunks][64]: e: W[16 nt + (l & 15)][16 chunk + 4 (l >> 4) + e][kd][kw], tap = 3 kd + kw
+  const float* bias;    // [64]
+  const float* slope;   // [64]
+  float* out;           // [n][10][15][5][64]
+  int32_t n_utt;
+};
+
+template <bool SLOPE01>
+__global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_c31[];
+  float* reg = smem_c31;
+  const int lane = threadIdx.x & 63, nt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  f32x4 G[4][3][2];   // [k][kw][chunk]
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const f32x4 g0 = p.wfrag[((nt * 9 + kw) * 2 + ch) * 64 + lane], g1 = p.wfrag[((nt * 9 + 3 + kw) * 2 + ch) * 64 + lane],
+                  g2 = p.wfrag[((nt * 9 + 6 + kw) * 2 + ch) * 64 + lane];
+      G[0][kw][ch] = g0;
+      G[1][kw][ch] = 0.5f * ((g0 + g2) + g1);
+      G[2][kw][ch] = 0.5f * ((g0 + g2) - g1);
+      G[3][kw][ch] = g2;
+    }
+  const float b = p.bias[16 * nt + i], sl = p.slope[16 * nt + i];
+  // A row of this lane: position m = i -> (row hl = m / 5, column w' = m % 5); m = 15 is a dummy (reads position 14)
+  const int mi = i < 15 ? i : 14;
+  const float* const a0 = reg + C31_PIXF * ((mi / 5) * 7 + mi % 5) + 4 * kk;
+  const int n_items = p.n_utt * 5;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int u = item / 5, rb = item - u * 5;
+    // stage [12 d][3 rows][7 w][32 c]: per depth 672 contiguous floats = 168 sixteen-byte pieces; 2 016 in all, eight
+    // per thread, four in flight at a time (168 VGPRs at three workgroups per CU)
+    const float* src = p.in + ((int64_t)u * 12 * 15 + 3 * rb) * (7 * 32);
+#pragma unroll 1
+    for (int base = threadIdx.x; base < 2016; base += 256 * 4) {
+      f32x4 sv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = base + 256 * k;
+        const int d = e / 168, r = e - d * 168;
+        if (e < 2016) sv[k] = *reinterpret_cast<const f32x4*>(src + (int64_t)d * (15 * 7 * 32) + 4 * r);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = base + 256 * k;
+        const int d = e / 168, r = e - d * 168;
+        if (e < 2016) *reinterpret_cast<f32x4*>(reg + C31_PIXF * (d * 21 + (r >> 3)) + 4 * (r & 7)) = sv[k];
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int P = 0; P < 5; ++P) {
+      const float* ap = a0 + 2 * C31_PLANE * P;
+      f32x4 acc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = k == 1 ? (f32x4){b, b, b, b} : (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 x[4];
+      f32x2 t[4][2];
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C31_PLANE * dd);
+#pragma unroll
+      for (int st = 0; st < 6; ++st) {   // step = (column tap kw, 16-channel chunk)
+        const int kw = st >> 1, ch = st & 1;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) wino_input_pair(x, hf, t);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < 6) {
+          const int off = C31_PIXF * ((st + 1) >> 1) + 16 * ((st + 1) & 1);
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C31_PLANE * dd + off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e >> 1][e & 1], G[k][kw][ch][e], acc[k], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // rows 4 kk + r = position m -> (row 3 rb + m / 5, column m % 5); column i = channel 16 nt + i; depths 2 P, 2 P + 1
+      float* o = p.out + (((int64_t)u * 10 + 2 * P) * 15 + 3 * rb) * (5 * 64) + 16 * nt + i;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const f32x2 c0 = hf ? __builtin_shufflevector(acc[0], acc[0], 2, 3) : __builtin_shufflevector(acc[0], acc[0], 0, 1);
+        const f32x2 c1 = hf ? __builtin_shufflevector(acc[1], acc[1], 2, 3) : __builtin_shufflevector(acc[1], acc[1], 0, 1);
+        const f32x2 c2 = hf ? __builtin_shufflevector(acc[2], acc[2], 2, 3) : __builtin_shufflevector(acc[2], acc[2], 0, 1);
+        const f32x2 c3 = hf ? __builtin_shufflevector(acc[3], acc[3], 2, 3) : __builtin_shufflevector(acc[3], acc[3], 0, 1);
+        const f32x2 y0 = pk_add(pk_add(c0, c1), c2), y1 = pk_sub(pk_sub(c1, c2), c3);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int m = 4 * kk + 2 * hf + q;
+          if (m < 15) {
+            o[m * 64] = prelu_t<SLOPE01>(y0[q], sl);                       // positions are contiguous: (row, column) = m
+            o[(int64_t)15 * 5 * 64 + m * 64] = prelu_t<SLOPE01>(y1[q], sl);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 
 }  // namespace
 
@@ -1195,6 +1312,30 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     }
 #endif
   }
+  return SVK_OK;
+}
+
+extern "C" int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
+                               const float* d_slope, int32_t flags, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_utt >= 0, "n_utt negative");
+  if (n_utt == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_in && d_wfrag && d_bias && d_slope && d_out, "NULL buffer");
+  SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_wfrag)) & 15) == 0,
+              "buffers must be 16-byte aligned");
+  SVK_REQUIRE(ctx, (int64_t)n_utt * 5 < ((int64_t)1 << 31), "too many cubes for one launch");
+  Conv31Params p{d_in, reinterpret_cast<const f32x4*>(d_wfrag), d_bias, d_slope, d_out, n_utt};
+  void (*kern)(const Conv31Params) = (flags & 2) ? c3d2_conv31w_kernel<true> : c3d2_conv31w_kernel<false>;
+  const size_t lds = sizeof(float) * (size_t)C31_LDS_FLOATS;
+  SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t items = (int64_t)n_utt * 5;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess ||
+      per_cu < 1)
+    per_cu = 2;
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(256), lds, ctx->stream,
+                     p);
+  SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }
 

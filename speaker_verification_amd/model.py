@@ -113,11 +113,13 @@ class FusedEmbedder:
             self.fc_w_cl = None
             # engine for svk_bias_prelu after conv3_1 .. conv4_2 (GPU + channels-last only; SVK_C3D2_TAIL=0 disables)
             self.fused_tail = None
+            self.conv31_kernel = False       # conv3_1 in libsvk behind svk_c3d2_stage2 (SVK_C3D2_CONV31=0 disables)
             if channels_last and self.fc_w.is_cuda:
                 import os
                 if os.environ.get("SVK_C3D2_TAIL", "1") != "0":
                     from .engine import get_engine
                     self.fused_tail = get_engine(self.fc_w.device.index)
+                    self.conv31_kernel = os.environ.get("SVK_C3D2_CONV31", "1") != "0"
             # First layer as patch-matrix x weight GEMM.  MIOpen has no direct kernel for a 1-channel
             # Conv3d and falls back to im2col + per-group GEMM + layout transposes (6.5 ms per 978
             # cubes).  Here ONE strided copy gathers, for every group of G adjacent output columns, the
@@ -296,9 +298,43 @@ class FusedEmbedder:
                         per_channel(s2, 32), slope01)
         return self._stage2
 
+    def conv31_tables(self):
+        """Operand fragments of `svk_c3d2_conv31` (conv3_1: 32 -> 64, k(3,1,3), stride 1, no pool), BN folded, or None
+        when the layer differs:  wfrag [4 nt][9][2][64][4]: lane (co = 16 nt + (l & 15), kk = l >> 4):
+        W[co][16 chunk + 4 kk + e][kd][kw], tap 3 kd + kw."""
+        hit = getattr(self, "_conv31", False)
+        if hit is not False:
+            return hit
+        self._conv31 = None
+        if len(self.stages) < 5:
+            return None
+        w, b, sl, st, pool, _ = self.stages[4]
+        if tuple(w.shape) != (64, 32, 3, 1, 3) or tuple(st) != (1, 1, 1) or pool:
+            return None
+        dev = w.device
+        lane = torch.arange(64, device=dev)
+        ch, kq = lane & 15, lane >> 4
+        a = w.contiguous()[:, :, :, 0, :]                                    # [co][ci][kd][kw]
+        frag = torch.empty((4, 9, 2, 64, 4), dtype=torch.float32, device=dev)
+        for nt in range(4):
+            for kd in range(3):
+                for kw in range(3):
+                    for chunk in range(2):
+                        for e in range(4):
+                            frag[nt, 3 * kd + kw, chunk, :, e] = a[16 * nt + ch, 16 * chunk + 4 * kq + e, kd, kw]
+        slope = sl.expand(64).contiguous() if sl.numel() == 1 else sl.contiguous()
+        self._conv31 = (frag.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
+        return self._conv31
+
     @torch.no_grad()
     def from_stage2(self, z, n):
-        """Embeddings from the output of `svk_c3d2_stage2`: the activation after pool2, [n][12][15][7][32]."""
+        """Embeddings from the output of `svk_c3d2_stage2`: the activation after pool2, [n][12][15][7][32].  conv3_1 runs
+        in libsvk too (`svk_c3d2_conv31`) when the engine is there and SVK_C3D2_CONV31 != 0."""
+        t31 = self.conv31_tables() if (self.fused_tail is not None and self.conv31_kernel and z.is_cuda) else None
+        if t31 is not None:
+            y = self.fused_tail.c3d2_conv31(z.view(n, 12, 15, 7, 32), t31)
+            x = y.view(n, 10, 15, 5, 64).permute(0, 4, 1, 2, 3)             # (n, 64, 10, 15, 5), channels_last_3d memory
+            return self._run(x, start=5)
         x = z.view(n, 12, 15, 7, 32).permute(0, 4, 1, 2, 3)                 # (n, 32, 12, 15, 7), channels_last_3d memory
         return self._run(x, start=4)
 

@@ -1328,6 +1328,52 @@ def test_c3d2_second_block_kernels(eng):
                  np.abs(got.transpose(0, 4, 1, 2, 3) - want).max() / scale))
 
 
+def test_c3d2_conv31_kernel(eng, monkeypatch):
+    """svk_c3d2_conv31 (conv3_1 -> BN -> PReLU, model.py:126-128,159-161, Winograd F(2,3) along depth) against the same
+    layer on torch-CPU with unfolded BatchNorm; per-channel and negative slopes; and the whole embedding path with and
+    without it."""
+    import torch.nn.functional as F
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    model = seeded_model(61, n_labels=8)
+    model.load_state_dict(perturb_inference_state(model.state_dict(), 62))
+    emb = model.to(eng.device).eval().fused_inference(channels_last=True)
+    tables = emb.conv31_tables()
+    assert tables is not None and tables[3]
+    rng = np.random.default_rng(5)
+    n = 3
+    act = rng.standard_normal((n, 12, 15, 7, 32)).astype(np.float32)            # [n][d][h][w][c]
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+    def layer(slope):
+        with torch.no_grad():
+            x = F.conv3d(torch.from_numpy(act.transpose(0, 4, 1, 2, 3).copy()), state["conv3_1.weight"], state["conv3_1.bias"])
+            x = F.batch_norm(x, state["batch_norm3_1.running_mean"], state["batch_norm3_1.running_var"],
+                             state["batch_norm3_1.weight"], state["batch_norm3_1.bias"], training=False, eps=1e-5)
+            return F.prelu(x, slope).numpy()                                     # (n, 64, 10, 15, 5)
+    want = layer(state["PReLu3_1.weight"])
+    scale = np.abs(want).max()
+    got = eng.c3d2_conv31(eng.to_device(act), tables).cpu().numpy()              # [n][10][15][5][64]
+    np.testing.assert_allclose(got.transpose(0, 4, 1, 2, 3), want, rtol=1e-4, atol=4e-6 * scale)
+    same = eng.c3d2_conv31(eng.to_device(act), tables[:3] + (False,)).cpu().numpy()
+    np.testing.assert_array_equal(same, got)                                     # general and [0, 1] PReLU forms agree
+    sn = torch.linspace(-0.5, 0.4, 64)
+    got_n = eng.c3d2_conv31(eng.to_device(act), (tables[0], tables[1], sn.to(eng.device), False)).cpu().numpy()
+    np.testing.assert_allclose(got_n.transpose(0, 4, 1, 2, 3), layer(sn), rtol=1e-4, atol=4e-6 * scale)
+    print("conv3_1 kernel, max |diff| / scale: %.2e" % (np.abs(got.transpose(0, 4, 1, 2, 3) - want).max() / scale))
+    # the whole path with and without it
+    pcm, _ = synth.corpus(3, 3)
+    with_k = VerificationPipeline(model, crop_rng="device", crop_seed=9, normalize=True, preemph_cof=0.98)
+    assert with_k.embedder.conv31_kernel
+    a = with_k.embed(pcm).cpu().numpy()
+    monkeypatch.setenv("SVK_C3D2_CONV31", "0")
+    without = VerificationPipeline(model, crop_rng="device", crop_seed=9, normalize=True, preemph_cof=0.98)
+    assert not without.embedder.conv31_kernel
+    b = without.embed(pcm).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-6 * np.abs(b).max())
+    assert eng.lib.svk_c3d2_conv31(eng.ctx, None, 1, None, None, None, 0, None) == -1
+
+
 def test_bench_two_ranks_share_one_gpu():
     """The N > 1 path on the device: `bench.py --gpus 2 --backend gloo` starts two rank processes on this one GPU
     (RCCL refuses two ranks on a device, so the all-gather goes through gloo / host memory; everything else is the
