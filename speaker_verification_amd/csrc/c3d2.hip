@@ -1,3 +1,12 @@
+// The C3D2 embedding network's first two blocks and conv3_1 (model.py:110-128, :141-161) on v_mfma_f32_16x16x4_f32.
+//   c3d2_stage1_kernel            cube + conv1_1 + conv1_2 + pool1, direct form (described right below)
+//   c3d2_stage1w_kernel           the same with conv1_2 through Winograd's F(2, 3) along depth -- the default
+//   c3d2_conv21_kernel / conv21w  conv2_1, direct / depth-transformed
+//   c3d2_conv22_kernel / conv22w  conv2_2 + pool2, direct / depth-transformed
+//   c3d2_conv31w_kernel           conv3_1, depth-transformed
+//   bias_prelu_kernel             + bias, PReLU behind the convolutions PyTorch-ROCm still runs (conv3_2 .. conv4_2)
+// BatchNorm (eval mode) is folded into weights and biases by the host (model.FusedEmbedder).
+//
 // The first block of the C3D2 embedding network as ONE gfx950 kernel:
 //   feature rows + crop starts -> cube (utils.py:351-379) -> conv1_1 (1 -> 16, k(3,1,5)) + BN + PReLU
 //   -> conv1_2 (16 -> 16, k(3,9,1), stride (1,2,1)) + BN + PReLU -> MaxPool3d((1,1,2))
