@@ -1374,6 +1374,49 @@ def test_c3d2_conv31_kernel(eng, monkeypatch):
     assert eng.lib.svk_c3d2_conv31(eng.ctx, None, 1, None, None, None, 0, None) == -1
 
 
+def test_network_kernels_many_items_per_workgroup(eng):
+    """The network kernels are persistent (a workgroup loops over work items, the first block prefetching the next item's
+    patch inside the current one's matrix work): the small-batch tests above give every workgroup at most one item, so
+    here each gets several -- the depth-transformed kernels against the direct-form ones (validated against torch-CPU
+    above) and conv3_1 against PyTorch-ROCm's convolution, on batches of 64 / 256 / 200 cubes; bitwise repeatable."""
+    import torch.nn.functional as F
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    model = seeded_model(71, n_labels=8)
+    model.load_state_dict(perturb_inference_state(model.state_dict(), 72))
+    emb = model.to(eng.device).eval().fused_inference(channels_last=True)
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(5)
+    # first block: 64 cubes = 2 304 items over 256 workgroups
+    n, T = 64, 150
+    feat = torch.randn((n, T, 40), device=eng.device, generator=g) * 2 - 6
+    crops = torch.randint(0, T - 80, (n, 20), device=eng.device, dtype=torch.int32, generator=g)
+    crops[7] = -1
+    t1 = emb.stage1_tables()
+    direct = eng.c3d2_stage1(feat, crops, t1, folded=False)
+    wino = eng.c3d2_stage1(feat, crops, t1, folded=False, depth_transform=True)
+    scale = float(direct.abs().max())
+    assert float((wino - direct).abs().max()) <= 4e-6 * scale
+    assert torch.equal(wino, eng.c3d2_stage1(feat, crops, t1, folded=False, depth_transform=True))
+    assert float(wino[7].abs().max()) == pytest.approx(float(direct[7].abs().max()), rel=1e-6)   # the zero cube
+    # second block: 256 cubes = 2 304 / 5 376 items over 512 workgroups
+    act1 = torch.randn((256, 16, 36, 18, 16), device=eng.device, generator=g)
+    t2 = emb.stage2_tables()
+    d2 = eng.c3d2_stage2(act1, t2)
+    w2 = eng.c3d2_stage2(act1, t2, depth_transform=True)
+    assert float((w2 - d2).abs().max()) <= 4e-6 * float(d2.abs().max())
+    assert torch.equal(w2, eng.c3d2_stage2(act1, t2, depth_transform=True))
+    del act1, d2
+    # conv3_1: 200 cubes = 1 000 items over 768 workgroups, against the framework's convolution of the folded weights
+    act2 = torch.randn((200, 12, 15, 7, 32), device=eng.device, generator=g)
+    t31 = emb.conv31_tables()
+    got = eng.c3d2_conv31(act2, t31)                                          # [n][10][15][5][64]
+    wf, bf, sl = emb.stages[4][0], emb.stages[4][1], emb.stages[4][2]
+    with torch.no_grad():
+        want = F.prelu(F.conv3d(act2.permute(0, 4, 1, 2, 3), wf, bf), sl).permute(0, 2, 3, 4, 1)
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert torch.equal(got, eng.c3d2_conv31(act2, t31))
+
+
 def test_bench_two_ranks_share_one_gpu():
     """The N > 1 path on the device: `bench.py --gpus 2 --backend gloo` starts two rank processes on this one GPU
     (RCCL refuses two ranks on a device, so the all-gather goes through gloo / host memory; everything else is the
