@@ -391,6 +391,135 @@ __global__ __launch_bounds__(256) void mel_features_kernel(const float* __restri
   }
 }
 
+// The same stage with the mel product on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32 like the fused front
+// end's mel tile): a workgroup owns 64 frames (one 16-frame M tile per wave), walks the filters in blocks of 64 (four
+// N tiles per wave) and the bins in chunks of 64; both operands are staged in LDS with rows of 68 floats (the 16 rows
+// of a tile then start in 16 different 16-byte bank slots) and read as ds_read_b128 fragments -- K permuted identically
+// on both (lane (i, kk) holds bins 16 g + 4 kk .. + 3, MFMA step e uses element e).  Used for banks of up to 256 filters
+// (the 64 x nf tile of log-mel energies must fit LDS); larger banks take the VALU kernel above.
+constexpr int MM_FR = 64, MM_CH = 64, MM_LD = 68;
+typedef float mm_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mel_features_mfma_kernel(const float* __restrict__ power, int nframes, int nbins,
+                                                                const float* __restrict__ bank, int nf, int out_kind,
+                                                                int ncep, int dc_elim, const float* __restrict__ dct,
+                                                                float* __restrict__ feat, float* __restrict__ energy) {
+  extern __shared__ __attribute__((aligned(16))) char smem_mm[];
+  float* ptile = reinterpret_cast<float*>(smem_mm);        // [64 frames][68]
+  float* btile = ptile + MM_FR * MM_LD;                    // [64 filters][68]
+  float* etot = btile + 64 * MM_LD;                        // [64]
+  float* lmel = etot + MM_FR;                              // [64][nf]
+  const float EPS = 2.220446049250313e-16f;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, kk = lane >> 4;
+  const int64_t f0 = (int64_t)blockIdx.x * MM_FR;
+  const int nfr = (int)(nframes - f0 < MM_FR ? nframes - f0 : MM_FR);
+  float esum = 0.f;                                        // thread (frame t / 4, quarter t % 4 of a chunk): energy partial
+  // Order: bins outermost, so a power chunk is staged once for all (up to four) filter blocks; the accumulators of every
+  // block stay in registers.  The NEXT step's global loads are issued before this step's MFMAs (coalesced, element e =
+  // t + 256 j -> (row e / 64, bin e % 64); zero beyond the frames / filters / bins).
+  const int nfb = (nf + 63) >> 6;                           // 1 .. 4 filter blocks
+  mm_f32x4 acc[4][4];
+#pragma unroll
+  for (int fbi = 0; fbi < 4; ++fbi)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[fbi][nt] = (mm_f32x4){0.f, 0.f, 0.f, 0.f};
+  float pv[16], bv[16];
+  auto load_power = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int e = t + 256 * j, r = e >> 6, k = e & 63;
+      pv[j] = (r < nfr && k0 + k < nbins) ? power[(f0 + r) * nbins + k0 + k] : 0.f;
+    }
+  };
+  auto load_bank = [&](int k0, int fb) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int e = t + 256 * j, r = e >> 6, k = e & 63;
+      bv[j] = (fb + r < nf && k0 + k < nbins) ? bank[(int64_t)(fb + r) * nbins + k0 + k] : 0.f;
+    }
+  };
+  load_power(0);
+  load_bank(0, 0);
+  for (int k0 = 0; k0 < nbins; k0 += MM_CH) {
+#pragma unroll
+    for (int fbi = 0; fbi < 4; ++fbi) {
+      if (fbi >= nfb) break;
+      __syncthreads();                                     // the previous step's fragment reads are done
+      if (fbi == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ptile[((t + 256 * j) >> 6) * MM_LD + (t & 63)] = pv[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) btile[((t + 256 * j) >> 6) * MM_LD + (t & 63)] = bv[j];
+      __syncthreads();
+      if (fbi + 1 < nfb) {
+        load_bank(k0, 64 * (fbi + 1));
+      } else if (k0 + MM_CH < nbins) {
+        load_power(k0 + MM_CH);
+        load_bank(k0 + MM_CH, 0);
+      }
+      if (fbi == 0) {   // frame energy = the sum over ALL bins (feature.py:202)
+        const float* pr = ptile + (t >> 2) * MM_LD + (t & 3) * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const mm_f32x4 v = *reinterpret_cast<const mm_f32x4*>(pr + 4 * q);
+          esum += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+      }
+      const float* ar = ptile + (16 * wave + i) * MM_LD + 4 * kk;
+      const float* br = btile + i * MM_LD + 4 * kk;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const mm_f32x4 a = *reinterpret_cast<const mm_f32x4*>(ar + 16 * g);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const mm_f32x4 b = *reinterpret_cast<const mm_f32x4*>(br + 16 * nt * MM_LD + 16 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[fbi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[fbi][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // rows 4 kk + r = frame 16 wave + 4 kk + r, column i = filter 64 fbi + 16 nt + i
+#pragma unroll
+  for (int fbi = 0; fbi < 4; ++fbi)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      if (64 * fbi + 16 * nt + i < nf) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float m = acc[fbi][nt][r] == 0.f ? EPS : acc[fbi][nt][r];  // feature.py:217
+          lmel[(16 * wave + 4 * kk + r) * nf + 64 * fbi + 16 * nt + i] = out_kind == SVK_OUT_MFE ? m : logf(m);
+        }
+      }
+  esum += __shfl_xor(esum, 2, 64);
+  esum += __shfl_xor(esum, 1, 64);
+  if ((t & 3) == 0) etot[t >> 2] = esum == 0.f ? EPS : esum;  // feature.py:205
+  __syncthreads();
+  if (energy && t < nfr) energy[f0 + t] = etot[t];
+  const int cols = out_kind == SVK_OUT_MFCC ? ncep : nf;
+  for (int idx = t; idx < nfr * cols; idx += 256) {
+    const int r = idx / cols, cc = idx - r * cols;
+    float v;
+    if (out_kind != SVK_OUT_MFCC) {
+      v = lmel[r * nf + cc];
+    } else if (cc == 0 && dc_elim) {
+      v = logf(etot[r]);                             // feature.py:151-152
+    } else {
+      const float* d = dct + (int64_t)cc * nf;
+      const float* lm = lmel + r * nf;
+      float a0 = 0.f, a1 = 0.f;
+      int n = 0;
+      for (; n + 1 < nf; n += 2) {
+        a0 = fmaf(lm[n], d[n], a0);
+        a1 = fmaf(lm[n + 1], d[n + 1], a1);
+      }
+      if (n < nf) a0 = fmaf(lm[n], d[n], a0);
+      v = a0 + a1;
+    }
+    feat[(f0 + r) * cols + cc] = v;
+  }
+}
+
 // scipy.fftpack.dct(type=2, norm='ortho'): D[k][n] = sqrt(2/N) cos(pi k (2n+1) / 2N), D[0][n] = sqrt(1/N)
 __global__ __launch_bounds__(256) void dct_table_kernel(float* __restrict__ d, int ncep, int nf) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -758,6 +887,16 @@ int svk_mel_features(svk_ctx* ctx, const float* d_power, int32_t n_frames, int32
                        reinterpret_cast<float*>(ctx->work), num_ceps, num_filters);
     SVK_LAUNCH_CHECK(ctx);
     dct = reinterpret_cast<const float*>(ctx->work);
+  }
+  if (num_filters <= 256) {   // the mel product on MFMA
+    const size_t lds = sizeof(float) * (size_t)(MM_FR * MM_LD + 64 * MM_LD + MM_FR + MM_FR * num_filters);
+    SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(mel_features_mfma_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mel_features_mfma_kernel, dim3((unsigned)((n_frames + MM_FR - 1) / MM_FR)), dim3(256), lds, ctx->stream,
+                       d_power, n_frames, n_bins, d_bank, num_filters, out_kind, num_ceps, dc_elimination, dct, d_feat,
+                       d_energy);
+    SVK_LAUNCH_CHECK(ctx);
+    return SVK_OK;
   }
   const size_t lds = sizeof(float) * (size_t)(MEL_FR * MEL_CH + 64 * (MEL_CH + 1) + MEL_FR + MEL_FR * num_filters);
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(mel_features_kernel),

@@ -1098,6 +1098,15 @@ def test_mel_stage_wide_banks(eng):
     from speaker_verification_amd import _lib
     from scipy.fftpack import dct
     rng = np.random.default_rng(8)
+    # 300 filters: past the 256 the MFMA form of the kernel takes (its 64 x nf tile must fit LDS) -> the VALU form;
+    # 10 filters over 129 bins and 130 frames: partial N tile, partial K chunk, three M tiles of one workgroup in use
+    for T, bins, nf in ((130, 129, 10), (77, 1025, 300)):
+        power = rng.random((T, bins)) * 50.0
+        power[3] = 0.0
+        bank = rng.random((nf, bins)) * (rng.random((nf, bins)) < 0.3)
+        f, e = eng.mel_features(power, bank, _lib.OUT_LMFE, want_energy=True)
+        np.testing.assert_allclose(f.cpu().numpy(), np.log(ref.zero_handling(power @ bank.T)), **FEAT_TOL)
+        np.testing.assert_allclose(e.cpu().numpy(), ref.zero_handling(power.sum(axis=1)), rtol=2e-4)
     T, bins, nf = 77, 1025, 200
     power = rng.random((T, bins)) * 50.0
     power[5] = 0.0                                                     # zero frame: energy and mel energies -> eps
