@@ -583,6 +583,105 @@ __global__ __launch_bounds__(256) void cmvnw_kernel(const float* __restrict__ sr
   }
 }
 
+// The same on clips that fit LDS (the reference's own use: a few hundred frames of 13 .. 40 coefficients, window 301 --
+// longer than the clip): one workgroup per (clip, group of columns) keeps the columns in LDS, builds float64 PREFIX
+// sums along time by wave-wide scans, and every window sum is then two look-ups: the symmetric padding is the
+// periodic extension x[0 .. T-1], x[T-1 .. 0] of period 2 T, whose prefix sums follow from the clip's own
+// (P2[m] = m <= T ? P[m] : 2 P[T] - P[2 T - m]; F(n) = floor(n / 2T) * 2 P[T] + P2[n mod 2T]).  Both passes (mean, then
+// the std of the centred rows) run in the one kernel: one read + one write of the array instead of two + two, and no
+// serial walk.  LDS: 20 bytes per element (the column as f32, prefix sums of y and y * y as f64).
+constexpr int CW_CAP = 3900;   // elements per workgroup: 78 KB of LDS, two workgroups per CU
+__device__ __forceinline__ double cw_prefix_at(const double* P, int T, int n) {   // F(n), n any integer
+  const int two = 2 * T;
+  int q = 0, r = n;   // |n| is a few periods at most (window / clip length): compare-and-step beats an integer division
+  while (r < 0) {
+    r += two;
+    --q;
+  }
+  while (r >= two) {
+    r -= two;
+    ++q;
+  }
+  const double p2 = r <= T ? P[r] : 2.0 * P[T] - P[two - r];
+  return (double)q * (2.0 * P[T]) + p2;
+}
+__global__ __launch_bounds__(256) void cmvnw_tile_kernel(const float* __restrict__ src, int max_frames, int ncols,
+                                                         const int32_t* __restrict__ n_frames, int win, int variance, int cg,
+                                                         float* __restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) char smem_cw[];
+  const int utt = blockIdx.y, c0 = blockIdx.x * cg;
+  const int nc = ncols - c0 < cg ? ncols - c0 : cg;
+  int T = n_frames ? n_frames[utt] : max_frames;
+  T = T < max_frames ? T : max_frames;
+  if (T <= 0 || nc <= 0) return;
+  double* P = reinterpret_cast<double*>(smem_cw);           // [nc][T + 1]
+  double* Q = P + (size_t)cg * (max_frames + 1);            // [nc][T + 1]
+  float* A = reinterpret_cast<float*>(Q + (size_t)cg * (max_frames + 1));   // [nc][T], column-major
+  const float* base = src + (int64_t)utt * max_frames * ncols + c0;
+  float* out = dst + (int64_t)utt * max_frames * ncols + c0;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int half = (win - 1) / 2;
+  const double inv_win = 1.0 / (double)win;
+  for (int idx = t; idx < nc * T; idx += 256) {
+    const int r = idx / nc, c = idx - r * nc;
+    A[c * T + r] = base[(int64_t)r * ncols + c];
+  }
+  __syncthreads();
+  // prefix sums of A (and of A * A) along time: a wave per column, 64 rows per scan step
+  auto scan_columns = [&](bool squares) {
+    for (int c = wave; c < nc; c += 4) {
+      double carry = 0.0, carry2 = 0.0;
+      double* Pc = P + (size_t)c * (T + 1);
+      double* Qc = Q + (size_t)c * (T + 1);
+      if (lane == 0) {
+        Pc[0] = 0.0;
+        if (squares) Qc[0] = 0.0;
+      }
+      for (int s0 = 0; s0 < T; s0 += 64) {
+        const double v = s0 + lane < T ? (double)A[c * T + s0 + lane] : 0.0;
+        double a = v, b = v * v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const double ua = __shfl_up(a, d, 64), ub = __shfl_up(b, d, 64);
+          if (lane >= d) {
+            a += ua;
+            b += ub;
+          }
+        }
+        if (s0 + lane < T) {
+          Pc[s0 + lane + 1] = carry + a;
+          if (squares) Qc[s0 + lane + 1] = carry2 + b;
+        }
+        carry += __shfl(a, 63, 64);
+        carry2 += __shfl(b, 63, 64);
+      }
+    }
+  };
+  scan_columns(false);
+  __syncthreads();
+  for (int idx = t; idx < nc * T; idx += 256) {
+    const int r = idx / nc, c = idx - r * nc;
+    const double* Pc = P + (size_t)c * (T + 1);
+    const double mean = (cw_prefix_at(Pc, T, r + half + 1) - cw_prefix_at(Pc, T, r - half)) * inv_win;
+    const float y = (float)((double)A[c * T + r] - mean);
+    if (variance) A[c * T + r] = y;
+    else out[(int64_t)r * ncols + c] = y;
+  }
+  if (!variance) return;
+  __syncthreads();
+  scan_columns(true);
+  __syncthreads();
+  for (int idx = t; idx < nc * T; idx += 256) {
+    const int r = idx / nc, c = idx - r * nc;
+    const double* Pc = P + (size_t)c * (T + 1);
+    const double* Qc = Q + (size_t)c * (T + 1);
+    const double mean = (cw_prefix_at(Pc, T, r + half + 1) - cw_prefix_at(Pc, T, r - half)) * inv_win;
+    double var = (cw_prefix_at(Qc, T, r + half + 1) - cw_prefix_at(Qc, T, r - half)) * inv_win - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    out[(int64_t)r * ncols + c] = (float)((double)A[c * T + r] / (sqrt(var) + 9.313225746154785e-10));
+  }
+}
+
 // ---- 'derivative' features, bug-compatible (Q11) -------------------------------------------------
 __global__ __launch_bounds__(256) void derivative_kernel(const float* __restrict__ in, int64_t total, int ncols,
                                                          int delta, float inv_scale, float* __restrict__ out) {
@@ -916,6 +1015,16 @@ int svk_cmvnw(svk_ctx* ctx, const float* d_in, int32_t n_utt, int32_t max_frames
   if (n_utt == 0 || max_frames == 0 || n_cols == 0) return SVK_OK;
   SVK_REQUIRE(ctx, d_in && d_out && d_in != d_out, "NULL or aliased buffer");
   SVK_REQUIRE(ctx, !variance || (d_tmp && d_tmp != d_in && d_tmp != d_out), "variance pass needs a distinct d_tmp");
+  if (max_frames <= CW_CAP) {   // the clip's columns fit LDS: prefix sums, both passes in one kernel
+    const int cg = std::min<int>(n_cols, CW_CAP / max_frames);
+    const size_t lds = (size_t)cg * ((size_t)max_frames * sizeof(float) + 2 * (size_t)(max_frames + 1) * sizeof(double));
+    SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(cmvnw_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+    hipLaunchKernelGGL(cmvnw_tile_kernel, dim3((unsigned)((n_cols + cg - 1) / cg), (unsigned)n_utt), dim3(256), lds, ctx->stream,
+                       d_in, max_frames, n_cols, d_n_frames, win, variance, cg, d_out);
+    SVK_LAUNCH_CHECK(ctx);
+    return SVK_OK;
+  }
   // rows per thread: long enough to amortise the direct window sum of a segment's first row, short enough
   // to keep a few hundred threads per clip
   const int seg = max_frames <= 1024 ? 32 : 128;
