@@ -451,7 +451,9 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       const int u = item / 36, rem = item - u * 36, q = rem / 18, j = rem - q * 18;
       const int hl = i >> 1, wc = i & 1;
       const float* const wbase = act + 2 * (160 * WPIXF) * pair + 68 * hl + 16 * wc + 4 * kk;
-      float* const obase = p.out + (int64_t)u * p.s_n + (int64_t)(TD * q + 2 * pair) * p.s_d + (int64_t)j * p.s_w + i;
+      // (wave-uniform 64-bit bases + one 32-bit lane offset: the stores need no per-store address VALU)
+      float* const obase = p.out + (int64_t)u * p.s_n + (int64_t)(TD * q + 2 * pair) * p.s_d + (int64_t)j * p.s_w;
+      const int olane = kk * (int)p.s_hp + i;
       // (the SIMD's two waves do not share its issue slots evenly -- the older one, part 0, gets about two in three, and
       // s_setprio changes nothing, measured -- but the younger one fills what the older leaves: the phase lasts the SUM
       // of both waves' MFMA + VALU time whichever way the five tiles are split, so 3 + 2 it is)
@@ -510,11 +512,14 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
         // rows 4 kk + r of the tile: output row h0 + 2 kk + (r >> 1), column r & 1: pool = max over r pairs
         if (tl < 4 || kk >= 2) {
           const f32x4 y0 = acc[0] + acc[1] + acc[2] + b2, y1 = acc[1] - acc[2] - acc[3] + b2;
-          float* o = obase + (int64_t)(h0 / 2 + kk) * p.s_hp;
-          o[0] = fmaxf(prelu_t<SLOPE01>(y0[0], sl2), prelu_t<SLOPE01>(y0[1], sl2));
-          o[p.s_par] = fmaxf(prelu_t<SLOPE01>(y0[2], sl2), prelu_t<SLOPE01>(y0[3], sl2));
-          o[p.s_d] = fmaxf(prelu_t<SLOPE01>(y1[0], sl2), prelu_t<SLOPE01>(y1[1], sl2));
-          o[p.s_d + p.s_par] = fmaxf(prelu_t<SLOPE01>(y1[2], sl2), prelu_t<SLOPE01>(y1[3], sl2));
+          float* const o00 = obase + (int64_t)(h0 / 2) * p.s_hp;
+          float* const o01 = o00 + p.s_par;
+          float* const o10 = o00 + p.s_d;
+          float* const o11 = o10 + p.s_par;
+          o00[olane] = fmaxf(prelu_t<SLOPE01>(y0[0], sl2), prelu_t<SLOPE01>(y0[1], sl2));
+          o01[olane] = fmaxf(prelu_t<SLOPE01>(y0[2], sl2), prelu_t<SLOPE01>(y0[3], sl2));
+          o10[olane] = fmaxf(prelu_t<SLOPE01>(y1[0], sl2), prelu_t<SLOPE01>(y1[1], sl2));
+          o11[olane] = fmaxf(prelu_t<SLOPE01>(y1[2], sl2), prelu_t<SLOPE01>(y1[3], sl2));
         }
       }
     }
@@ -842,7 +847,10 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
         __builtin_amdgcn_sched_barrier(0);
       }
       // rows 4 kk + r = output column w'; column i = channel 16 nt + i; depths 2 P and 2 P + 1
-      float* o = p.out + (((int64_t)u * A2_D + 2 * P) * S2_H + hb + hl) * (A2_W * 32) + i;
+      // (wave-uniform 64-bit bases + one 32-bit lane offset + immediates: the stores need no per-store address VALU)
+      float* const o0 = p.out + (((int64_t)u * A2_D + 2 * P) * S2_H + hb + hl) * (A2_W * 32);
+      float* const o1 = o0 + (int64_t)S2_H * (A2_W * 32);
+      const int lo = 4 * kk * 32 + i;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         // y0 = (a0 + a1) + a2, y1 = (a1 - a2) - a3 as packed adds (every VALU instruction here is paid in MFMA slots)
@@ -860,8 +868,8 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
         for (int r = 0; r < 4; ++r) {
           const int wq = 4 * kk + r;
           if (wq < A2_W) {
-            o[wq * 32 + 16 * nt] = prelu_t<SLOPE01>(y0[r >> 1][r & 1], sl[nt]);
-            o[(int64_t)S2_H * (A2_W * 32) + wq * 32 + 16 * nt] = prelu_t<SLOPE01>(y1[r >> 1][r & 1], sl[nt]);
+            o0[lo + r * 32 + 16 * nt] = prelu_t<SLOPE01>(y0[r >> 1][r & 1], sl[nt]);
+            o1[lo + r * 32 + 16 * nt] = prelu_t<SLOPE01>(y1[r >> 1][r & 1], sl[nt]);
           }
         }
       }
@@ -1107,11 +1115,12 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
         const f32x4 v0 = own[0][y] + *reinterpret_cast<const f32x4*>(xi + 256 * y);
         const f32x4 v1 = own[1][y] + *reinterpret_cast<const f32x4*>(xi + 512 + 256 * y);
         // rows 4 kk + r = output row h'; pool over the column pair, PReLU first (model.py:156-158)
-        float* o = p.out + ((((int64_t)u * O2_D + C22W_TD * q + 2 * ch + y) * O2_H) * O2_W + j) * 32 + 16 * nt + i;
+        float* const o = p.out + ((((int64_t)u * O2_D + C22W_TD * q + 2 * ch + y) * O2_H) * O2_W + j) * 32 + 16 * nt;   // uniform
+        const int olane = 4 * kk * (O2_W * 32) + i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int hq = 4 * kk + r;
-          if (hq < O2_H) o[(int64_t)hq * (O2_W * 32)] = fmaxf(prelu_t<SLOPE01>(v0[r], sl), prelu_t<SLOPE01>(v1[r], sl));
+          if (hq < O2_H) o[olane + r * (O2_W * 32)] = fmaxf(prelu_t<SLOPE01>(v0[r], sl), prelu_t<SLOPE01>(v1[r], sl));
         }
       }
     }
@@ -1213,7 +1222,8 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
         __builtin_amdgcn_sched_barrier(0);
       }
       // rows 4 kk + r = position m -> (row 3 rb + m / 5, column m % 5); column i = channel 16 nt + i; depths 2 P, 2 P + 1
-      float* o = p.out + (((int64_t)u * 10 + 2 * P) * 15 + 3 * rb) * (5 * 64) + 16 * nt + i;
+      float* const o = p.out + (((int64_t)u * 10 + 2 * P) * 15 + 3 * rb) * (5 * 64) + 16 * nt;   // wave-uniform
+      const int olane = 4 * kk * 64 + i;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const f32x2 c0 = hf ? __builtin_shufflevector(acc[0], acc[0], 2, 3) : __builtin_shufflevector(acc[0], acc[0], 0, 1);
@@ -1225,8 +1235,8 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
         for (int q = 0; q < 2; ++q) {
           const int m = 4 * kk + 2 * hf + q;
           if (m < 15) {
-            o[m * 64] = prelu_t<SLOPE01>(y0[q], sl);                       // positions are contiguous: (row, column) = m
-            o[(int64_t)15 * 5 * 64 + m * 64] = prelu_t<SLOPE01>(y1[q], sl);
+            o[olane + (2 * hf + q) * 64] = prelu_t<SLOPE01>(y0[q], sl);    // positions are contiguous: (row, column) = m
+            o[15 * 5 * 64 + olane + (2 * hf + q) * 64] = prelu_t<SLOPE01>(y1[q], sl);
           }
         }
       }
