@@ -286,6 +286,16 @@ int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float*
 int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);
 
+/* conv3_2 (64 -> 64, kernel (3,7,1)) -> BN -> PReLU, model.py:129-131 + :162-164, depth-transformed; its transformed
+ * weights do not fit one workgroup's registers: four workgroup roles (one per 16-channel N tile), four waves = four
+ * 16-channel K chunks each, partial sums added through LDS.
+ *   d_in    [n_utt][10][15][5][64]   = svk_c3d2_conv31's output
+ *   d_wfrag [4 nt][21 taps][4 chunks][64][4]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: W32[co][16 chunk + 4 kk + e][kd][kh],
+ *           tap 7 kd + kh (BatchNorm folded);  d_bias / d_slope [64];  flags bit 1: every PReLU slope lies in [0, 1]
+ *   d_out   [n_utt][8][9][5][64]     channels last                                                                    */
+int svk_c3d2_conv32(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
+                    const float* d_slope, int32_t flags, float* d_out);
+
 /* What follows each of conv3_1 .. conv4_2 (model.py:159-167; those convolutions run on the host framework): + bias
  * (BatchNorm folded), PReLU -- one in-place pass over channels-last activations d_x [n_rows][n_channels]
  * (n_channels a multiple of 4): x <- prelu(x + bias[c], slope[c]).                                            */

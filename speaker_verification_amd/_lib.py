@@ -78,6 +78,7 @@ SIGNATURES = {
     "svk_c3d2_stage1": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_stage2": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "svk_c3d2_conv31": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "svk_c3d2_conv32": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "svk_bias_prelu": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "svk_comm_unique_id": (C.c_int, [_vp, C.c_char_p]),
     "svk_comm_init": (C.c_int, [_vp, C.c_char_p, _i32, _i32]),

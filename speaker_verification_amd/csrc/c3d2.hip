@@ -1245,6 +1245,160 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
   }
 }
 
+// ---- conv3_2 (64 -> 64, kernel (3,7,1)) + BN + PReLU (model.py:129-131, :162-164), depth-transformed.  Its transformed
+// weights are 4 x 7 x 64 x 64 floats = 448 KB: sixteen (N tile, 16-channel K chunk) slabs of 112 VGPRs x 64 lanes.  A
+// workgroup takes ONE N tile (role = blockIdx & 3) with its four K chunks, one per wave, so the four waves produce
+// partial sums over a quarter of K each and add them up through LDS; the four roles read the same input (from L2).
+// Item = (cube, depth pair): the pair's four input planes (15 x 5 pixels of 64 channels, pixel stride 68 floats = 17
+// sixteen-byte slots) sit in LDS; no taps along w, so the 45 output positions (9 rows x 5 columns) are CONSECUTIVE pixels
+// and row tap kh is a shift by 5 pixels: M tile t = pixels 16 t .. 16 t + 15 (three tiles, the last with 3 dummies),
+// every fragment address an immediate offset from one lane base.  One workgroup per CU (106 KB of LDS): the next item's
+// planes are fetched into registers during the MFMAs and parked after the barrier, like the first block's patch. ----
+constexpr int C32_PIXF = 68;
+constexpr int C32_PLANE = 75 * C32_PIXF;                       // floats per input plane in LDS
+constexpr int C32_IN_FLOATS = 4 * C32_PLANE + 16 * C32_PIXF;   // + slack: the dummy rows of the last tile read past plane 3
+constexpr int C32_XCH_FLOATS = 4 * 3 * 2 * 64 * 4;             // [wave][tile][y][lane] f32x4
+constexpr int C32_LDS_FLOATS = C32_IN_FLOATS + C32_XCH_FLOATS;
+constexpr int C32_NV = 19;                                     // 16-byte pieces per thread and item (4 800 / 256, rounded up)
+
+struct Conv32Params {
+  const float* in;      // [n][10][15][5][64]
+  const f32x4* wfrag;   // [4 nt][21 taps][4 chunks][64]: e: W[16 nt + (l & 15)][16 chunk + 4 (l >> 4) + e][kd][kh], tap = 7 kd + kh
+  const float* bias;    // [64]
+  const float* slope;   // [64]
+  float* out;           // [n][8][9][5][64]
+  int32_t n_utt;
+};
+
+template <bool SLOPE01>
+__global__ __launch_bounds__(256) void c3d2_conv32w_kernel(const Conv32Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_c32[];
+  float* reg = smem_c32;
+  float* exch = reg + C32_IN_FLOATS;
+  const int lane = threadIdx.x & 63, ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  // role (N tile) and item group of this workgroup.  Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD
+  // has its own L2: the four roles of a group read the same planes, so they are given the same XCD when the grid allows
+  int nt, group;
+  if ((gridDim.x & 31) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    nt = slot & 3;
+    group = xcd + 8 * (slot >> 2);
+  } else {
+    nt = blockIdx.x & 3;
+    group = blockIdx.x >> 2;
+  }
+  f32x4 G[4][7];   // [k][kh], this workgroup's N tile, this wave's K chunk
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+    const f32x4 g0 = p.wfrag[((nt * 21 + kh) * 4 + ch) * 64 + lane], g1 = p.wfrag[((nt * 21 + 7 + kh) * 4 + ch) * 64 + lane],
+                g2 = p.wfrag[((nt * 21 + 14 + kh) * 4 + ch) * 64 + lane];
+    G[0][kh] = g0;
+    G[1][kh] = 0.5f * ((g0 + g2) + g1);
+    G[2][kh] = 0.5f * ((g0 + g2) - g1);
+    G[3][kh] = g2;
+  }
+  const float b = ch == 0 ? p.bias[16 * nt + i] : 0.f, sl = p.slope[16 * nt + i];
+  const float* const a0 = reg + C32_PIXF * i + 16 * ch + 4 * kk;   // pixel i of plane 0, this wave's chunk, this lane's K piece
+  const int n_items = p.n_utt * 4;                                  // (cube, pair)
+  const int stride = gridDim.x >> 2;                                // workgroups per role
+  f32x4 pre[C32_NV];
+  auto fetch = [&](int item) {   // the pair's four planes are 19 200 contiguous floats
+    const float* src = p.in + ((int64_t)(item >> 2) * 10 + 2 * (item & 3)) * (15 * 5 * 64);
+#pragma unroll
+    for (int k = 0; k < C32_NV; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      if (e < 4800) pre[k] = *reinterpret_cast<const f32x4*>(src + 4 * e);
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int k = 0; k < C32_NV; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      if (e < 4800) *reinterpret_cast<f32x4*>(reg + C32_PIXF * (e >> 4) + 4 * (e & 15)) = pre[k];
+    }
+  };
+  int item = group;
+  if (item < n_items) {
+    fetch(item);
+    park();
+  }
+  __syncthreads();
+  for (; item < n_items; item += stride) {
+    const int next = item + stride;
+    if (next < n_items) fetch(next);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int tl = 0; tl < 3; ++tl) {
+      const float* ap = a0 + 16 * C32_PIXF * tl;
+      f32x4 acc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = k == 1 ? (f32x4){b, b, b, b} : (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 x[4];
+      f32x2 t[4][2];
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C32_PLANE * dd);
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) wino_input_pair(x, hf, t);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kh + 1 < 7) {
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C32_PLANE * dd + 5 * C32_PIXF * (kh + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e >> 1][e & 1], G[k][kh][e], acc[k], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      f32x4 y0, y1;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const f32x2 c0 = hf ? __builtin_shufflevector(acc[0], acc[0], 2, 3) : __builtin_shufflevector(acc[0], acc[0], 0, 1);
+        const f32x2 c1 = hf ? __builtin_shufflevector(acc[1], acc[1], 2, 3) : __builtin_shufflevector(acc[1], acc[1], 0, 1);
+        const f32x2 c2 = hf ? __builtin_shufflevector(acc[2], acc[2], 2, 3) : __builtin_shufflevector(acc[2], acc[2], 0, 1);
+        const f32x2 c3 = hf ? __builtin_shufflevector(acc[3], acc[3], 2, 3) : __builtin_shufflevector(acc[3], acc[3], 0, 1);
+        const f32x2 s0 = pk_add(pk_add(c0, c1), c2), s1 = pk_sub(pk_sub(c1, c2), c3);
+        y0[2 * hf] = s0[0];
+        y0[2 * hf + 1] = s0[1];
+        y1[2 * hf] = s1[0];
+        y1[2 * hf + 1] = s1[1];
+      }
+      float* xo = exch + (((ch * 3 + tl) * 2) * 64 + lane) * 4;
+      *reinterpret_cast<f32x4*>(xo) = y0;
+      *reinterpret_cast<f32x4*>(xo + 256) = y1;
+    }
+    __syncthreads();   // every wave's partial sums are in LDS; nobody reads the input planes any more
+    if (next < n_items) park();
+    // the six (tile, y) units of the item: wave w adds up units w and w + 4 (four partial sums each), PReLU, stores
+    {
+      const int u = item >> 2, P = item & 3;
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        const int unit = ch + 4 * rep;   // = 2 tile + y
+        if (unit < 6) {
+          const float* xi = exch + (unit * 64 + lane) * 4;
+          f32x4 v = *reinterpret_cast<const f32x4*>(xi);
+#pragma unroll
+          for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(xi + w * (3 * 2 * 64 * 4));
+          const int tl = unit >> 1, y = unit & 1;
+          // rows 4 kk + r = position 16 tl + 4 kk + r (< 45): positions are contiguous in the output, channels last
+          float* const o = p.out + (((int64_t)u * 8 + 2 * P + y) * 45 + 16 * tl) * 64 + 16 * nt;
+          const int olane = 4 * kk * 64 + i;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * tl + 4 * kk + r < 45) o[olane + r * 64] = prelu_t<SLOPE01>(v[r], sl);
+        }
+      }
+    }
+    __syncthreads();   // the next planes are in place; the exchange buffer may be overwritten
+  }
+}
+
 
 }  // namespace
 
@@ -1354,6 +1508,30 @@ extern "C" int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     per_cu = 2;
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(256), lds, ctx->stream,
                      p);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+extern "C" int svk_c3d2_conv32(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
+                               const float* d_slope, int32_t flags, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_utt >= 0, "n_utt negative");
+  if (n_utt == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_in && d_wfrag && d_bias && d_slope && d_out, "NULL buffer");
+  SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_wfrag)) & 15) == 0,
+              "buffers must be 16-byte aligned");
+  SVK_REQUIRE(ctx, (int64_t)n_utt * 4 < ((int64_t)1 << 29), "too many cubes for one launch");
+  Conv32Params p{d_in, reinterpret_cast<const f32x4*>(d_wfrag), d_bias, d_slope, d_out, n_utt};
+  void (*kern)(const Conv32Params) = (flags & 2) ? c3d2_conv32w_kernel<true> : c3d2_conv32w_kernel<false>;
+  const size_t lds = sizeof(float) * (size_t)C32_LDS_FLOATS;
+  if (lds > (size_t)ctx->lds_per_cu)
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_conv32 needs %zu bytes of LDS per workgroup (device: %d)", lds,
+                    ctx->lds_per_cu);
+  SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // four roles (N tiles) x up to num_cu / 4 workgroups each: one workgroup per CU, the four roles of an item side by side
+  const int64_t items = (int64_t)n_utt * 4;
+  const int64_t per_role = std::max<int64_t>(1, std::min<int64_t>(items, ctx->num_cu / 4));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(4 * per_role)), dim3(256), lds, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }

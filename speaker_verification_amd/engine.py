@@ -466,6 +466,19 @@ class Engine:
                                        2 if slope01 else 0, self._ptr(out)), self.ctx)
         return out
 
+    def c3d2_conv32(self, act, tables):
+        """svk_c3d2_conv32: [n, 10, 15, 5, 64] (svk_c3d2_conv31's output) -> conv3_2 + BN + PReLU -> [n, 8, 9, 5, 64]
+        f32, channels last (Winograd F(2, 3) along depth, partial sums over four K chunks added through LDS)."""
+        torch = _torch()
+        n = act.shape[0]
+        wfrag, bias, slope = tables[:3]
+        slope01 = bool(tables[3]) if len(tables) > 3 else False
+        out = torch.empty((n, 8, 9, 5, 64), dtype=torch.float32, device=self.device)
+        self._stream()
+        check(self.lib.svk_c3d2_conv32(self.ctx, self._ptr(act), n, self._ptr(wfrag), self._ptr(bias), self._ptr(slope),
+                                       2 if slope01 else 0, self._ptr(out)), self.ctx)
+        return out
+
     def bias_prelu_(self, x, bias, slope):
         """svk_bias_prelu, in place on a channels-last activation: x (n, C, D, H, W) with channels_last_3d memory (or
         any [rows, C] contiguous tensor): x <- prelu(x + bias[c], slope[c])."""

@@ -114,12 +114,14 @@ class FusedEmbedder:
             # engine for svk_bias_prelu after conv3_1 .. conv4_2 (GPU + channels-last only; SVK_C3D2_TAIL=0 disables)
             self.fused_tail = None
             self.conv31_kernel = False       # conv3_1 in libsvk behind svk_c3d2_stage2 (SVK_C3D2_CONV31=0 disables)
+            self.conv32_kernel = False       # ... and conv3_2 behind it (SVK_C3D2_CONV32=0 disables)
             if channels_last and self.fc_w.is_cuda:
                 import os
                 if os.environ.get("SVK_C3D2_TAIL", "1") != "0":
                     from .engine import get_engine
                     self.fused_tail = get_engine(self.fc_w.device.index)
                     self.conv31_kernel = os.environ.get("SVK_C3D2_CONV31", "1") != "0"
+                    self.conv32_kernel = self.conv31_kernel and os.environ.get("SVK_C3D2_CONV32", "1") != "0"
             # First layer as patch-matrix x weight GEMM.  MIOpen has no direct kernel for a 1-channel
             # Conv3d and falls back to im2col + per-group GEMM + layout transposes (6.5 ms per 978
             # cubes).  Here ONE strided copy gathers, for every group of G adjacent output columns, the
@@ -326,6 +328,34 @@ class FusedEmbedder:
         self._conv31 = (frag.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
         return self._conv31
 
+    def conv32_tables(self):
+        """Operand fragments of `svk_c3d2_conv32` (conv3_2: 64 -> 64, k(3,7,1), stride 1, no pool), BN folded, or None
+        when the layer differs:  wfrag [4 nt][21][4 chunks][64][4]: lane (co = 16 nt + (l & 15), kk = l >> 4):
+        W[co][16 chunk + 4 kk + e][kd][kh], tap 7 kd + kh."""
+        hit = getattr(self, "_conv32", False)
+        if hit is not False:
+            return hit
+        self._conv32 = None
+        if len(self.stages) < 6:
+            return None
+        w, b, sl, st, pool, _ = self.stages[5]
+        if tuple(w.shape) != (64, 64, 3, 7, 1) or tuple(st) != (1, 1, 1) or pool:
+            return None
+        dev = w.device
+        lane = torch.arange(64, device=dev)
+        ch, kq = lane & 15, lane >> 4
+        a = w.contiguous()[:, :, :, :, 0]                                    # [co][ci][kd][kh]
+        frag = torch.empty((4, 21, 4, 64, 4), dtype=torch.float32, device=dev)
+        for nt in range(4):
+            for kd in range(3):
+                for kh in range(7):
+                    for chunk in range(4):
+                        for e in range(4):
+                            frag[nt, 7 * kd + kh, chunk, :, e] = a[16 * nt + ch, 16 * chunk + 4 * kq + e, kd, kh]
+        slope = sl.expand(64).contiguous() if sl.numel() == 1 else sl.contiguous()
+        self._conv32 = (frag.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
+        return self._conv32
+
     @torch.no_grad()
     def from_stage2(self, z, n):
         """Embeddings from the output of `svk_c3d2_stage2`: the activation after pool2, [n][12][15][7][32].  conv3_1 runs
@@ -333,6 +363,11 @@ class FusedEmbedder:
         t31 = self.conv31_tables() if (self.fused_tail is not None and self.conv31_kernel and z.is_cuda) else None
         if t31 is not None:
             y = self.fused_tail.c3d2_conv31(z.view(n, 12, 15, 7, 32), t31)
+            t32 = self.conv32_tables() if self.conv32_kernel else None
+            if t32 is not None:
+                y = self.fused_tail.c3d2_conv32(y, t32)
+                x = y.view(n, 8, 9, 5, 64).permute(0, 4, 1, 2, 3)           # (n, 64, 8, 9, 5), channels_last_3d memory
+                return self._run(x, start=6)
             x = y.view(n, 10, 15, 5, 64).permute(0, 4, 1, 2, 3)             # (n, 64, 10, 15, 5), channels_last_3d memory
             return self._run(x, start=5)
         x = z.view(n, 12, 15, 7, 32).permute(0, 4, 1, 2, 3)                 # (n, 32, 12, 15, 7), channels_last_3d memory

@@ -1383,6 +1383,52 @@ def test_c3d2_conv31_kernel(eng, monkeypatch):
     assert eng.lib.svk_c3d2_conv31(eng.ctx, None, 1, None, None, None, 0, None) == -1
 
 
+def test_c3d2_conv32_kernel(eng, monkeypatch):
+    """svk_c3d2_conv32 (conv3_2 -> BN -> PReLU, model.py:129-131,162-164: depth-transformed, four workgroup roles, partial
+    sums over four K chunks added through LDS) against the same layer on torch-CPU with unfolded BatchNorm, small batches
+    (a partial last group of roles) and one with several items per workgroup; the embedding path with and without it."""
+    import torch.nn.functional as F
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    model = seeded_model(81, n_labels=8)
+    model.load_state_dict(perturb_inference_state(model.state_dict(), 82))
+    emb = model.to(eng.device).eval().fused_inference(channels_last=True)
+    tables = emb.conv32_tables()
+    assert tables is not None and tables[3]
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(6)
+
+    def layer(act, slope):
+        with torch.no_grad():
+            x = F.conv3d(torch.from_numpy(act.transpose(0, 4, 1, 2, 3).copy()), state["conv3_2.weight"], state["conv3_2.bias"])
+            x = F.batch_norm(x, state["batch_norm3_2.running_mean"], state["batch_norm3_2.running_var"],
+                             state["batch_norm3_2.weight"], state["batch_norm3_2.bias"], training=False, eps=1e-5)
+            return F.prelu(x, slope).numpy()                                     # (n, 64, 8, 9, 5)
+    for n in (1, 3, 70):                     # 4 / 12 items (fewer than 64 groups), 280 items over 64 groups
+        act = rng.standard_normal((n, 10, 15, 5, 64)).astype(np.float32)
+        want = layer(act, state["PReLu3_2.weight"])
+        scale = np.abs(want).max()
+        got = eng.c3d2_conv32(eng.to_device(act), tables).cpu().numpy()          # [n][8][9][5][64]
+        np.testing.assert_allclose(got.transpose(0, 4, 1, 2, 3), want, rtol=1e-4, atol=4e-6 * scale)
+        print("conv3_2 kernel, %d cubes, max |diff| / scale: %.2e" % (n, np.abs(got.transpose(0, 4, 1, 2, 3) - want).max() / scale))
+    same = eng.c3d2_conv32(eng.to_device(act), tables[:3] + (False,)).cpu().numpy()
+    np.testing.assert_array_equal(same, got)                                     # general and [0, 1] PReLU forms agree
+    np.testing.assert_array_equal(eng.c3d2_conv32(eng.to_device(act), tables).cpu().numpy(), got)   # repeatable
+    sn = torch.linspace(-0.5, 0.4, 64)
+    got_n = eng.c3d2_conv32(eng.to_device(act), (tables[0], tables[1], sn.to(eng.device), False)).cpu().numpy()
+    np.testing.assert_allclose(got_n.transpose(0, 4, 1, 2, 3), layer(act, sn), rtol=1e-4, atol=4e-6 * scale)
+    pcm, _ = synth.corpus(3, 3)
+    with_k = VerificationPipeline(model, crop_rng="device", crop_seed=9, normalize=True, preemph_cof=0.98)
+    assert with_k.embedder.conv32_kernel
+    a = with_k.embed(pcm).cpu().numpy()
+    monkeypatch.setenv("SVK_C3D2_CONV32", "0")
+    without = VerificationPipeline(model, crop_rng="device", crop_seed=9, normalize=True, preemph_cof=0.98)
+    assert not without.embedder.conv32_kernel and without.embedder.conv31_kernel
+    b = without.embed(pcm).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-6 * np.abs(b).max())
+    assert eng.lib.svk_c3d2_conv32(eng.ctx, None, 1, None, None, None, 0, None) == -1
+
+
 def test_network_kernels_many_items_per_workgroup(eng):
     """The network kernels are persistent (a workgroup loops over work items, the first block prefetching the next item's
     patch inside the current one's matrix work): the small-batch tests above give every workgroup at most one item, so
