@@ -572,7 +572,7 @@ def main():
         feat, n_frames = pipe.features(voiced, vlen)
         idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, 0, pipe.bad_clips)
         ms = _median_ms(torch, lambda: pipe.embed_features(feat, idx), max(args.steps, 5))
-        print(json.dumps({"workload": "1024 cubes: svk_c3d2_stage1 + svk_c3d2_stage2 + svk_c3d2_conv31 + conv3_2 .. FC5 (PyTorch-ROCm)",
+        print(json.dumps({"workload": "1024 cubes: svk_c3d2_stage1 + svk_c3d2_stage2 + svk_c3d2_conv31 + svk_c3d2_conv32 + conv4_1 .. FC5 (PyTorch-ROCm)",
                           "ms": ms, "utt_per_s": 1024 / ms * 1e3, "tflops": 1024 * C3D2_GFLOP_PER_UTT / ms}))
         return 0
     n_total = args.corpus
@@ -755,9 +755,9 @@ def main():
                              "unit": "TFLOP/s", "frac": e2e_tflops / (F32_MATRIX_PEAK_TFLOPS * world),
                              "gflop_per_utt": C3D2_GFLOP_PER_UTT,
                              "note": "whole step vs the dense f32 matrix peak of the N GPUs: the C3D2 forward "
-                                     "(676.6 MFLOP per utterance: conv1_1 .. conv3_1 in libsvk MFMA kernels, conv3_2 .. FC5 "
+                                     "(676.6 MFLOP per utterance: conv1_1 .. conv3_2 in libsvk MFMA kernels, conv4_1 .. FC5 "
                                      "on PyTorch-ROCm / MIOpen) is ~95 % of the step; SURVEY 8(d) ceiling = 232 k utt/s "
-                                     "per GPU for the direct-form sums (conv1_2, conv2_1, conv2_2, conv3_1 -- 80 % of the multiply-adds -- "
+                                     "per GPU for the direct-form sums (conv1_2 .. conv3_2 -- 89 % of the multiply-adds -- "
                                      "run through Winograd F(2,3) along depth and issue 2/3 of theirs)"},
             "eer": {"eer": eer, "auc": auc, "eer_device": eer_dev, "auc_device": auc_dev, "pairs": int(labels.size),
                     "short_clips": bad},

@@ -1,10 +1,11 @@
-// The C3D2 embedding network's first two blocks and conv3_1 (model.py:110-128, :141-161) on v_mfma_f32_16x16x4_f32.
+// The C3D2 embedding network's first three blocks (model.py:110-131, :141-164) on v_mfma_f32_16x16x4_f32.
 //   c3d2_stage1_kernel            cube + conv1_1 + conv1_2 + pool1, direct form (described right below)
 //   c3d2_stage1w_kernel           the same with conv1_2 through Winograd's F(2, 3) along depth -- the default
 //   c3d2_conv21_kernel / conv21w  conv2_1, direct / depth-transformed
 //   c3d2_conv22_kernel / conv22w  conv2_2 + pool2, direct / depth-transformed
 //   c3d2_conv31w_kernel           conv3_1, depth-transformed
-//   bias_prelu_kernel             + bias, PReLU behind the convolutions PyTorch-ROCm still runs (conv3_2 .. conv4_2)
+//   c3d2_conv32w_kernel           conv3_2, depth-transformed, K split over the waves of a workgroup
+//   bias_prelu_kernel             + bias, PReLU behind the convolutions PyTorch-ROCm still runs (conv4_1, conv4_2)
 // BatchNorm (eval mode) is folded into weights and biases by the host (model.FusedEmbedder).
 //
 // The first block of the C3D2 embedding network as ONE gfx950 kernel:

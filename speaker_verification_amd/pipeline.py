@@ -152,7 +152,8 @@ class VerificationPipeline:
             # never reach HBM; PyTorch-ROCm runs the remaining six convolutions and the FC layer
             tables2 = self.embedder.stage2_tables() if self.stage2_kernel else None
             if tables2 is not None:
-                # ... and conv2_1, conv2_2, pool2 in two more: PyTorch-ROCm runs conv3_1 .. FC5
+                # ... and conv2_1, conv2_2, pool2 in two more (conv3_1, conv3_2 follow inside from_stage2): PyTorch-ROCm
+                # runs conv4_1 .. FC5
                 rec = self.kernel_events is not None
                 if rec:
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]

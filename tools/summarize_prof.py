@@ -20,7 +20,7 @@ from collections import defaultdict
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OURS = ("frontend_kernel", "cmvn_kernel", "vad_kernel", "cube_gather_kernel", "cosine_kernel", "cosine_tiled_kernel",
         "inv_norm_kernel", "draw_crops_kernel", "cube_windows_kernel", "cube_windows_c3d2_kernel", "decimate_kernel", "resample_kernel",
-        "c3d2_stage1w_kernel", "c3d2_stage1_kernel", "c3d2_conv21w_kernel", "c3d2_conv22w_kernel", "c3d2_conv31w_kernel", "c3d2_conv21_kernel",
+        "c3d2_stage1w_kernel", "c3d2_stage1_kernel", "c3d2_conv21w_kernel", "c3d2_conv22w_kernel", "c3d2_conv31w_kernel", "c3d2_conv32w_kernel", "c3d2_conv21_kernel",
         "c3d2_conv22_kernel", "bias_prelu_kernel", "cmvnw_kernel", "spectrum_pow2_kernel",
         "spectrum_dft_kernel", "spectrum_fft_kernel", "mel_features_kernel")
 
