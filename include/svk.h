@@ -287,8 +287,8 @@ int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float*
                     const float* d_slope, int32_t flags, float* d_out);
 
 /* conv3_2 (64 -> 64, kernel (3,7,1)) -> BN -> PReLU, model.py:129-131 + :162-164, depth-transformed; its transformed
- * weights do not fit one workgroup's registers: four workgroup roles (one per 16-channel N tile), four waves = four
- * 16-channel K chunks each, partial sums added through LDS.
+ * weights do not fit one workgroup's registers: two workgroup roles (a pair of 16-channel N tiles each), eight waves =
+ * (N tile, 16-channel K chunk), partial sums over the four chunks added through LDS.
  *   d_in    [n_utt][10][15][5][64]   = svk_c3d2_conv31's output
  *   d_wfrag [4 nt][21 taps][4 chunks][64][4]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: W32[co][16 chunk + 4 kk + e][kd][kh],
  *           tap 7 kd + kh (BatchNorm folded);  d_bias / d_slope [64];  flags bit 1: every PReLU slope lies in [0, 1]

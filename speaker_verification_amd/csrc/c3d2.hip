@@ -1248,19 +1248,22 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
 
 // ---- conv3_2 (64 -> 64, kernel (3,7,1)) + BN + PReLU (model.py:129-131, :162-164), depth-transformed.  Its transformed
 // weights are 4 x 7 x 64 x 64 floats = 448 KB: sixteen (N tile, 16-channel K chunk) slabs of 112 VGPRs x 64 lanes.  A
-// workgroup takes ONE N tile (role = blockIdx & 3) with its four K chunks, one per wave, so the four waves produce
-// partial sums over a quarter of K each and add them up through LDS; the four roles read the same input (from L2).
+// workgroup of EIGHT waves takes two N tiles (role = one of two N tile pairs) with their four K chunks each -- wave =
+// (N tile of the pair, K chunk) -- so the four waves of an N tile produce partial sums over a quarter of K each and add
+// them up through LDS; the two roles read the same input (from their XCD's L2).
 // Item = (cube, depth pair): the pair's four input planes (15 x 5 pixels of 64 channels, pixel stride 68 floats = 17
 // sixteen-byte slots) sit in LDS; no taps along w, so the 45 output positions (9 rows x 5 columns) are CONSECUTIVE pixels
 // and row tap kh is a shift by 5 pixels: M tile t = pixels 16 t .. 16 t + 15 (three tiles, the last with 3 dummies),
-// every fragment address an immediate offset from one lane base.  One workgroup per CU (106 KB of LDS): the next item's
-// planes are fetched into registers during the MFMAs and parked after the barrier, like the first block's patch. ----
+// every fragment address an immediate offset from one lane base.  One workgroup per CU (131 KB of LDS), two waves per
+// SIMD (with four waves -- one N tile per workgroup, half the LDS but still one workgroup per CU -- every LDS wait, the
+// parking of the planes and the reduction ran with nothing beside them: 0.49 ms per 1 024 cubes); the next item's planes
+// are fetched into registers during the MFMAs and parked after the barrier, like the first block's patch. ----
 constexpr int C32_PIXF = 68;
 constexpr int C32_PLANE = 75 * C32_PIXF;                       // floats per input plane in LDS
 constexpr int C32_IN_FLOATS = 4 * C32_PLANE + 16 * C32_PIXF;   // + slack: the dummy rows of the last tile read past plane 3
-constexpr int C32_XCH_FLOATS = 4 * 3 * 2 * 64 * 4;             // [wave][tile][y][lane] f32x4
+constexpr int C32_XCH_FLOATS = 8 * 3 * 2 * 64 * 4;             // [wave][tile][y][lane] f32x4
 constexpr int C32_LDS_FLOATS = C32_IN_FLOATS + C32_XCH_FLOATS;
-constexpr int C32_NV = 19;                                     // 16-byte pieces per thread and item (4 800 / 256, rounded up)
+constexpr int C32_NV = 10;                                     // 16-byte pieces per thread and item (4 800 / 512, rounded up)
 
 struct Conv32Params {
   const float* in;      // [n][10][15][5][64]
@@ -1272,24 +1275,26 @@ struct Conv32Params {
 };
 
 template <bool SLOPE01>
-__global__ __launch_bounds__(256) void c3d2_conv32w_kernel(const Conv32Params p) {
+__global__ __launch_bounds__(512) void c3d2_conv32w_kernel(const Conv32Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem_c32[];
   float* reg = smem_c32;
   float* exch = reg + C32_IN_FLOATS;
-  const int lane = threadIdx.x & 63, ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
-  // role (N tile) and item group of this workgroup.  Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD
-  // has its own L2: the four roles of a group read the same planes, so they are given the same XCD when the grid allows
-  int nt, group;
-  if ((gridDim.x & 31) == 0) {
+  const int ch = wave & 3, half = wave >> 2;   // this wave's K chunk; which of the workgroup's two N tiles
+  // role (N tile pair) and item group of this workgroup.  Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each
+  // XCD has its own L2: the two roles of a group read the same planes, so they are given the same XCD when the grid allows
+  int role, group;
+  if ((gridDim.x & 15) == 0) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    nt = slot & 3;
-    group = xcd + 8 * (slot >> 2);
+    role = slot & 1;
+    group = xcd + 8 * (slot >> 1);
   } else {
-    nt = blockIdx.x & 3;
-    group = blockIdx.x >> 2;
+    role = blockIdx.x & 1;
+    group = blockIdx.x >> 1;
   }
-  f32x4 G[4][7];   // [k][kh], this workgroup's N tile, this wave's K chunk
+  const int nt = 2 * role + half;
+  f32x4 G[4][7];   // [k][kh], this wave's N tile and K chunk
 #pragma unroll
   for (int kh = 0; kh < 7; ++kh) {
     const f32x4 g0 = p.wfrag[((nt * 21 + kh) * 4 + ch) * 64 + lane], g1 = p.wfrag[((nt * 21 + 7 + kh) * 4 + ch) * 64 + lane],
@@ -1302,20 +1307,20 @@ __global__ __launch_bounds__(256) void c3d2_conv32w_kernel(const Conv32Params p)
   const float b = ch == 0 ? p.bias[16 * nt + i] : 0.f, sl = p.slope[16 * nt + i];
   const float* const a0 = reg + C32_PIXF * i + 16 * ch + 4 * kk;   // pixel i of plane 0, this wave's chunk, this lane's K piece
   const int n_items = p.n_utt * 4;                                  // (cube, pair)
-  const int stride = gridDim.x >> 2;                                // workgroups per role
+  const int stride = gridDim.x >> 1;                                // workgroups per role
   f32x4 pre[C32_NV];
   auto fetch = [&](int item) {   // the pair's four planes are 19 200 contiguous floats
     const float* src = p.in + ((int64_t)(item >> 2) * 10 + 2 * (item & 3)) * (15 * 5 * 64);
 #pragma unroll
     for (int k = 0; k < C32_NV; ++k) {
-      const int e = threadIdx.x + 256 * k;
+      const int e = threadIdx.x + 512 * k;
       if (e < 4800) pre[k] = *reinterpret_cast<const f32x4*>(src + 4 * e);
     }
   };
   auto park = [&]() {
 #pragma unroll
     for (int k = 0; k < C32_NV; ++k) {
-      const int e = threadIdx.x + 256 * k;
+      const int e = threadIdx.x + 512 * k;
       if (e < 4800) *reinterpret_cast<f32x4*>(reg + C32_PIXF * (e >> 4) + 4 * (e & 15)) = pre[k];
     }
   };
@@ -1369,23 +1374,24 @@ __global__ __launch_bounds__(256) void c3d2_conv32w_kernel(const Conv32Params p)
         y1[2 * hf] = s1[0];
         y1[2 * hf + 1] = s1[1];
       }
-      float* xo = exch + (((ch * 3 + tl) * 2) * 64 + lane) * 4;
+      float* xo = exch + (((wave * 3 + tl) * 2) * 64 + lane) * 4;
       *reinterpret_cast<f32x4*>(xo) = y0;
       *reinterpret_cast<f32x4*>(xo + 256) = y1;
     }
     __syncthreads();   // every wave's partial sums are in LDS; nobody reads the input planes any more
     if (next < n_items) park();
-    // the six (tile, y) units of the item: wave w adds up units w and w + 4 (four partial sums each), PReLU, stores
+    // the six (tile, y) units of the item and N tile: wave (half, ch) adds up units ch and ch + 4 (the partial sums of its
+    // half's four waves), PReLU, stores
     {
       const int u = item >> 2, P = item & 3;
 #pragma unroll
       for (int rep = 0; rep < 2; ++rep) {
         const int unit = ch + 4 * rep;   // = 2 tile + y
         if (unit < 6) {
-          const float* xi = exch + (unit * 64 + lane) * 4;
+          const float* xi = exch + ((half * 4 * 6 + unit) * 64 + lane) * 4;
           f32x4 v = *reinterpret_cast<const f32x4*>(xi);
 #pragma unroll
-          for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(xi + w * (3 * 2 * 64 * 4));
+          for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(xi + w * (6 * 64 * 4));
           const int tl = unit >> 1, y = unit & 1;
           // rows 4 kk + r = position 16 tl + 4 kk + r (< 45): positions are contiguous in the output, channels last
           float* const o = p.out + (((int64_t)u * 8 + 2 * P + y) * 45 + 16 * tl) * 64 + 16 * nt;
@@ -1529,10 +1535,10 @@ extern "C" int svk_c3d2_conv32(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_conv32 needs %zu bytes of LDS per workgroup (device: %d)", lds,
                     ctx->lds_per_cu);
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  // four roles (N tiles) x up to num_cu / 4 workgroups each: one workgroup per CU, the four roles of an item side by side
+  // two roles (N tile pairs) x up to num_cu / 2 workgroups each: one workgroup of eight waves per CU
   const int64_t items = (int64_t)n_utt * 4;
-  const int64_t per_role = std::max<int64_t>(1, std::min<int64_t>(items, ctx->num_cu / 4));
-  hipLaunchKernelGGL(kern, dim3((unsigned)(4 * per_role)), dim3(256), lds, ctx->stream, p);
+  const int64_t per_role = std::max<int64_t>(1, std::min<int64_t>(items, ctx->num_cu / 2));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(2 * per_role)), dim3(512), lds, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }
