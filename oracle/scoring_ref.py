@@ -17,10 +17,11 @@ the GPU box too.
 
 Parity status: PINNED by `tests/golden/scoring.npz` (made by
 `tools/make_golden.py` calling the reference's own `compute_Similarity`,
-`get_eer_auc` and `Siamese.l2_dist`).  `Siamese.forward` needs a GPU in the
-reference (`.cuda()` at `siamese.py:16,21`) and could not be executed when the
-fixtures were made: its loss formula is restated from the source and is
-"parity unpinned".
+`get_eer_auc`, `Siamese.l2_dist` and -- since round 3 -- `Siamese.forward`:
+the reference's forward only needs the `.cuda()` ATTRIBUTE (`siamese.py:16,21`),
+so the generator makes `torch.Tensor.cuda` the identity and runs it on the CPU
+as written; `contrastive_loss` below is held to its losses at <= 1e-6 relative
+(`sf_*` arrays, four (LAMBDA, M) pairs).
 """
 import numpy as np
 

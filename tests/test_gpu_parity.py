@@ -857,6 +857,35 @@ def test_siamese(eng, golden):
     assert o1.grad is not None and torch.isfinite(o1.grad).all()
 
 
+def test_siamese_forward_against_reference_loss(eng, golden):
+    """`Siamese.forward` on ROCm against the REFERENCE's own forward (siamese.py:10-27, run on the CPU by
+    tools/make_golden.py with `.cuda()` made the identity): the reference's C3D2 under seed 77 supplies the parameter
+    norms, twelve embedding pairs, four (LAMBDA, M) pairs -- rel 1e-5.  Both the autograd path (loss.backward) and the
+    inference path (`svk_l2_dist` under no_grad) are held to the same numbers."""
+    from speaker_verification_amd.model import seeded_model
+    from speaker_verification_amd.siamese import Siamese
+    g = golden["scoring"]
+    seed, n_labels, n_ch = (int(v) for v in g["sf_model_seed"])
+    net = seeded_model(seed, n_labels=n_labels, num_channels=n_ch).to(eng.device)
+    norms = np.array([float(torch.norm(p.detach())) for p in net.parameters()])
+    np.testing.assert_allclose(norms, g["sf_param_norms"], rtol=1e-6, atol=1e-12)   # same init as the reference's C3D2
+    y = torch.from_numpy(g["sf_y"]).to(eng.device)
+    o1, o2 = torch.from_numpy(g["sf_o1"]).to(eng.device), torch.from_numpy(g["sf_o2"]).to(eng.device)
+    for k, (lam, m) in enumerate(g["sf_cases"]):
+        sia = Siamese(LAMBDA=float(lam), M=float(m))
+        with torch.no_grad():
+            assert float(sia(net, y, o1, o2)) == pytest.approx(float(g["sf_loss"][k]), rel=1e-5)   # svk_l2_dist inside
+        a = o1.clone().requires_grad_()
+        loss = sia(net, y, a, o2)
+        assert float(loss.detach()) == pytest.approx(float(g["sf_loss"][k]), rel=1e-5)
+        loss.backward()
+        assert torch.isfinite(a.grad).all()
+    d = Siamese(0.0, 1.0).l2_dist(o1, o2).cpu().numpy()
+    np.testing.assert_allclose(d, g["sf_dist"], rtol=1e-6)
+    assert float(d[g["sf_y"] == 1].mean()) == pytest.approx(float(g["sf_same_mean"][0]), rel=1e-6)
+    assert float(d[g["sf_y"] == 0].mean()) == pytest.approx(float(g["sf_notsame_mean"][0]), rel=1e-6)
+
+
 # ---- whole path -------------------------------------------------------------------------------------------
 def test_pipeline_end_to_end_and_eer(eng):
     from speaker_verification_amd import evaluation
@@ -1179,8 +1208,9 @@ def test_rccl_wrappers_single_rank(eng):
 def test_siamese_train_step_on_rocm(eng):
     """SURVEY 8f-4 / train_siamese.py:37-175: one contrastive step (embed both cubes of each pair, `Siamese.forward`
     loss = contrastive + LAMBDA * sum of parameter norms, backward, SGD) on the GPU against the SAME step on
-    torch-CPU: loss, every gradient and every updated parameter.  (`Siamese.forward` needs CUDA in the reference,
-    so its loss is pinned to the restated formula of oracle/scoring_ref.py, "parity unpinned" -- see its header.)"""
+    torch-CPU: loss, every gradient and every updated parameter.  (The loss VALUE is pinned to the reference's own
+    `Siamese.forward` by `test_siamese_forward_against_reference_loss`; the restated formula used at the end of this
+    test is held to the same golden numbers in tests/test_oracle_golden.py.)"""
     import copy
     from speaker_verification_amd.model import seeded_model
     from speaker_verification_amd.train_siamese import make_criterion, siamese_train_step

@@ -218,8 +218,26 @@ def test_scoring(golden):
     np.testing.assert_allclose(scoring_ref.l2_dist(g["l2_o1"], g["l2_o2"]), g["l2_dist"], rtol=1e-6)
 
 
+def test_contrastive_loss_against_reference_forward(golden):
+    """`Siamese.forward` (siamese.py:10-27) PINNED: tools/make_golden.py ran the reference's own forward on the CPU
+    (its only CUDA dependence is the `.cuda()` attribute, made the identity in the generator) for four (LAMBDA, M)
+    pairs on twelve embedding pairs, incl. margins below every impostor distance; the restated formula must give
+    the reference's loss, and the two means the reference prints must be those of the restated distances."""
+    g = golden["scoring"]
+    y, o1, o2 = g["sf_y"], g["sf_o1"], g["sf_o2"]
+    d = scoring_ref.l2_dist(o1, o2)
+    np.testing.assert_allclose(d, g["sf_dist"], rtol=1e-6)
+    imp = d[y == 0]                    # M = 2.0: every impostor pair inside the margin; 1.0: one; 0.05: none (d > M)
+    assert (imp < 2.0).all() and int((imp < 1.0).sum()) == 1 and (imp > 0.05).all()
+    for k, (lam, m) in enumerate(g["sf_cases"]):
+        loss = scoring_ref.contrastive_loss(y, o1, o2, g["sf_param_norms"], LAMBDA=lam, M=m)
+        assert loss == pytest.approx(float(g["sf_loss"][k]), rel=1e-6), (lam, m)
+        assert float(d[y == 1].mean()) == pytest.approx(float(g["sf_same_mean"][k]), rel=1e-6)
+        assert float(d[y == 0].mean()) == pytest.approx(float(g["sf_notsame_mean"][k]), rel=1e-6)
+
+
 def test_contrastive_loss_formula():
-    """siamese.py:14-25 restated; unpinned (the reference's forward needs CUDA)."""
+    """siamese.py:14-25 restated, on a hand-computable case (the pinned values: the test above)."""
     y = np.array([1, 0, 1, 0], dtype=np.float32)
     o1 = np.zeros((4, 3), dtype=np.float32)
     o2 = np.array([[3, 4, 0], [0.6, 0.8, 0], [0, 0, 0], [3, 0, 0]], dtype=np.float32)   # d = 5, 1, 0, 3

@@ -312,6 +312,49 @@ def scoring_fixture(ref_eval, ref_siamese):
     o2 = rng.standard_normal((9, 128)).astype(np.float32)
     g["l2_o1"], g["l2_o2"] = o1, o2
     g["l2_dist"] = sia.l2_dist(torch.from_numpy(o1), torch.from_numpy(o2)).numpy()
+
+    # ---- Siamese.forward (siamese.py:10-27) as written.  Its only CUDA dependence is the `.cuda()` ATTRIBUTE
+    # (siamese.py:16,21): with a harness-side `torch.Tensor.cuda = identity` (same category as `np.lib.pad = np.pad`
+    # above; the reference is not edited) the reference's own forward runs on the CPU, prints its two lines and
+    # returns the loss.  The model only contributes its parameter norms: the reference's C3D2 under a fixed seed. ----
+    sink = io.StringIO()
+    real_stdout, sys.stdout = sys.stdout, sink
+    try:
+        torch.manual_seed(77)
+        import model as ref_model
+        net = ref_model.C3D2(100, 1)
+    finally:
+        sys.stdout = real_stdout
+    g["sf_model_seed"] = np.array([77, 100, 1])
+    g["sf_param_norms"] = np.array([float(torch.norm(p_)) for p_ in net.parameters()], dtype=np.float64)
+    n_pairs = 12
+    e1 = (0.11 * rng.standard_normal((n_pairs, 128))).astype(np.float32)
+    e2 = (0.11 * rng.standard_normal((n_pairs, 128))).astype(np.float32)
+    e2[:3] = e1[:3] + (0.01 * rng.standard_normal((3, 128))).astype(np.float32)     # three near-identical pairs
+    yy = np.array([1, 1, 0, 1, 0, 0, 1, 0, 1, 0, 0, 1], dtype=np.float32)
+    g["sf_o1"], g["sf_o2"], g["sf_y"] = e1, e2, yy
+    cases = [(0.001, 2.0), (0.01, 1.0), (0.0, 1.75), (0.05, 0.05)]    # M = 1.0 / 0.05: most / all impostor pairs have d > M
+    g["sf_cases"] = np.array(cases, dtype=np.float64)
+    saved_cuda = getattr(torch.Tensor, "cuda")
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    losses, same, notsame = [], [], []
+    try:
+        for lam, m in cases:
+            sink = io.StringIO()
+            real_stdout, sys.stdout = sys.stdout, sink
+            try:
+                with torch.no_grad():
+                    loss = ref_siamese.Siamese(LAMBDA=lam, M=m).forward(net, torch.from_numpy(yy), torch.from_numpy(e1),
+                                                                         torch.from_numpy(e2))
+            finally:
+                sys.stdout = real_stdout
+            losses.append(float(loss))
+            same.append(float(re.search(r"^Same: (\S+)", sink.getvalue(), re.M).group(1)))
+            notsame.append(float(re.search(r"^Not same: (\S+)", sink.getvalue(), re.M).group(1)))
+    finally:
+        torch.Tensor.cuda = saved_cuda
+    g["sf_loss"], g["sf_same_mean"], g["sf_notsame_mean"] = np.array(losses), np.array(same), np.array(notsame)
+    g["sf_dist"] = sia.l2_dist(torch.from_numpy(e1), torch.from_numpy(e2)).numpy()
     np.savez_compressed(os.path.join(OUT, "scoring.npz"), **g)
     print("scoring.npz", sum(v.nbytes for v in g.values()) // 1024, "KiB raw")
 
