@@ -25,6 +25,7 @@ class SvkError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"{_STATUS_NAMES.get(code, code)}: {message}")
         self.code = code
+        self.message = message
 
 
 class FrontendCfg(C.Structure):

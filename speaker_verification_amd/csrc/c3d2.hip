@@ -108,7 +108,7 @@ __device__ __forceinline__ void fetch_patch(const Stage1Params& p, int item, int
   for (int dd = 0; dd < PD; ++dd) {
     f32x2 v = (f32x2){0.f, 0.f};
     const int start = __builtin_amdgcn_readlane(starts_v, dd);   // wave-uniform
-    if (h < NFRAME && start >= 0 && start + h < p.max_frames)
+    if (h < NFRAME && (unsigned)start < (unsigned)p.max_frames && h < p.max_frames - start)   // (cannot overflow for any int32 start)
       v = *reinterpret_cast<const f32x2*>(base + (start + h) * NCOEF);  // < 2^31 floats per clip
     regs[dd] = v;
   }
@@ -318,7 +318,7 @@ __device__ __forceinline__ void fetch_patch_w(const Stage1Params& p, int item, i
   for (int dd = 0; dd < WPD; ++dd) {
     f32x2 v = (f32x2){0.f, 0.f};
     const int start = __builtin_amdgcn_readlane(starts_v, WPD * dhalf + dd);   // wave-uniform (dhalf = wave >> 2)
-    if (h < NFRAME && start >= 0 && start + h < p.max_frames)
+    if (h < NFRAME && (unsigned)start < (unsigned)p.max_frames && h < p.max_frames - start)   // (cannot overflow for any int32 start)
       v = *reinterpret_cast<const f32x2*>(base + (start + h) * NCOEF);
     regs[dd] = v;
   }
@@ -1427,6 +1427,9 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     void (*kern)(const Conv21Params) = !wino ? c3d2_conv21_kernel
                                        : (flags & 2) ? c3d2_conv21w_kernel<true> : c3d2_conv21w_kernel<false>;
     const size_t lds = sizeof(float) * (size_t)(wino ? C21W_LDS_FLOATS : C21_LDS_FLOATS);
+    if (lds > (size_t)ctx->lds_per_cu)
+      return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage2 (conv2_1) needs %zu bytes of LDS per workgroup (device: %d)",
+                      lds, ctx->lds_per_cu);
     SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t items = (int64_t)n_utt * (S2_H / (wino ? C21W_TH : C21_TH));
     int per_cu = 0;
@@ -1442,6 +1445,9 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     if (flags & 4) {   // conv2_2 through the depth transform
       void (*kern)(const Conv22Params) = (flags & 2) ? c3d2_conv22w_kernel<true> : c3d2_conv22w_kernel<false>;
       const size_t lds = sizeof(float) * (size_t)C22W_LDS_FLOATS;
+      if (lds > (size_t)ctx->lds_per_cu)
+        return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage2 (conv2_2) needs %zu bytes of LDS per workgroup (device: %d)",
+                        lds, ctx->lds_per_cu);
       SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const int64_t items = (int64_t)n_utt * (O2_W * (O2_D / C22W_TD));
       int per_cu = 0;
@@ -1454,6 +1460,9 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
       return SVK_OK;
     }
     const size_t lds = sizeof(float) * (size_t)C22_LDS_FLOATS;
+    if (lds > (size_t)ctx->lds_per_cu)
+      return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage2 (conv2_2) needs %zu bytes of LDS per workgroup (device: %d)",
+                      lds, ctx->lds_per_cu);
     SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(c3d2_conv22_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t items = (int64_t)n_utt * (O2_W * 2);
@@ -1507,6 +1516,9 @@ extern "C" int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   Conv31Params p{d_in, reinterpret_cast<const f32x4*>(d_wfrag), d_bias, d_slope, d_out, n_utt};
   void (*kern)(const Conv31Params) = (flags & 2) ? c3d2_conv31w_kernel<true> : c3d2_conv31w_kernel<false>;
   const size_t lds = sizeof(float) * (size_t)C31_LDS_FLOATS;
+  if (lds > (size_t)ctx->lds_per_cu)
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_conv31 needs %zu bytes of LDS per workgroup (device: %d)", lds,
+                    ctx->lds_per_cu);
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t items = (int64_t)n_utt * 5;
   int per_cu = 0;

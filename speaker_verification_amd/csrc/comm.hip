@@ -9,6 +9,9 @@
 // ABI of rccl.h (ncclUniqueId = 128 bytes, ncclFloat = 7, ncclSuccess = 0).
 #include <dlfcn.h>
 
+#include <cstdio>
+#include <mutex>
+
 #include "svk_internal.h"
 
 namespace {
@@ -30,13 +33,13 @@ struct Rccl {
   all_gather_fn all_gather = nullptr;
   comm_destroy_fn comm_destroy = nullptr;
   get_error_string_fn get_error_string = nullptr;
-  bool tried = false;
+  char load_error[256] = "";   // dlerror() text of the failed bind, captured once (dlerror() clears itself on read)
 };
 Rccl g_rccl;
+std::once_flag g_rccl_once;
 
 const Rccl* rccl(svk_ctx* ctx) {
-  if (!g_rccl.tried) {
-    g_rccl.tried = true;
+  std::call_once(g_rccl_once, [] {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (g_rccl.handle) break;
@@ -47,10 +50,15 @@ const Rccl* rccl(svk_ctx* ctx) {
       g_rccl.all_gather = (all_gather_fn)dlsym(g_rccl.handle, "ncclAllGather");
       g_rccl.comm_destroy = (comm_destroy_fn)dlsym(g_rccl.handle, "ncclCommDestroy");
       g_rccl.get_error_string = (get_error_string_fn)dlsym(g_rccl.handle, "ncclGetErrorString");
+      if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_gather || !g_rccl.comm_destroy)
+        snprintf(g_rccl.load_error, sizeof(g_rccl.load_error), "a required nccl* symbol is missing");
+    } else {
+      const char* why = dlerror();
+      snprintf(g_rccl.load_error, sizeof(g_rccl.load_error), "%s", why ? why : "dlopen failed");
     }
-  }
-  if (!g_rccl.handle || !g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_gather || !g_rccl.comm_destroy) {
-    svk_fail(ctx, SVK_ERR_RCCL, "librccl.so.1 could not be loaded (%s)", g_rccl.handle ? "missing symbol" : dlerror());
+  });
+  if (g_rccl.load_error[0]) {
+    svk_fail(ctx, SVK_ERR_RCCL, "librccl.so.1 could not be loaded (%s)", g_rccl.load_error);
     return nullptr;
   }
   return &g_rccl;

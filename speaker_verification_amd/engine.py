@@ -85,7 +85,7 @@ class Engine:
     def __del__(self):
         try:
             for hit in self._plans.values():
-                if not isinstance(hit, Exception):
+                if not isinstance(hit, str):
                     self.lib.svk_frontend_plan_destroy(hit[0])
             if self.ctx:
                 self.lib.svk_destroy(self.ctx)
@@ -124,9 +124,9 @@ class Engine:
         from .speechpy import feature as _feature
         key = spec.key()
         hit = self._plans.get(key)
-        if isinstance(hit, Exception):           # a configuration the fused kernel refused before
-            raise hit
-        if hit is None:
+        if isinstance(hit, str):                 # a configuration the fused kernel refused before: a FRESH exception
+            raise _lib.SvkError(_lib.SVK_ERR_UNSUPPORTED, hit)   # each time (a cached one would chain every caller's
+        if hit is None:                                          # traceback -- and its frames' inputs -- forever)
             bank = np.ascontiguousarray(
                 _feature.filterbanks(spec.num_filters, spec.nfft // 2 + 1, spec.fs, spec.low_freq,
                                      spec.high_freq or spec.fs / 2), dtype=np.float64)
@@ -138,7 +138,7 @@ class Engine:
                                                         C.byref(handle)), self.ctx)
             except _lib.SvkError as err:
                 if err.code == _lib.SVK_ERR_UNSUPPORTED:
-                    self._plans[key] = err
+                    self._plans[key] = err.message or "unsupported front-end configuration"
                 raise
             hit = (handle, cfg)
             self._plans[key] = hit

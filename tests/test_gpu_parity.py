@@ -690,6 +690,33 @@ def test_error_paths(eng):
         eng.vad_energy(np.zeros((1, 4800), dtype=np.float32), 1000)
 
 
+def test_staged_fall_through_does_not_pin_its_inputs(eng):
+    """`Engine.plan` used to cache the SvkError of a configuration the fused kernel refuses and re-raise the
+    SAME object on every call; each raise chained a traceback whose frames held the caller's PCM.  Now a fresh exception
+    per call: after N calls on the staged path no input survives."""
+    import gc
+    import weakref
+    from speaker_verification_amd import _lib
+    from speaker_verification_amd.engine import spec_from_seconds
+    spec = spec_from_seconds(16000, 0.025, 0.01, 400, 40, 13, _lib.OUT_MFCC)      # nfft 400: not a fused configuration
+    with pytest.raises(_lib.SvkError) as first:
+        eng.plan(spec)
+    with pytest.raises(_lib.SvkError) as second:
+        eng.plan(spec)
+    assert first.value is not second.value and first.value.code == _lib.SVK_ERR_UNSUPPORTED == second.value.code
+    assert str(first.value) == str(second.value)
+    del first, second
+    refs = []
+    for k in range(5):
+        pcm = torch.from_numpy(synth.noise_clip(k, 8000)).to(eng.device)
+        refs.append(weakref.ref(pcm))
+        feat, nf, _ = eng.features(pcm, spec)
+        assert feat.shape == (1, int(nf[0]), 13)
+        del pcm, feat, nf
+    gc.collect()
+    assert [r() is None for r in refs] == [True] * 5
+
+
 def test_concatenated_ragged_offsets(eng):
     """The `d_offsets` form of the C-ABI: clips of different lengths back to back in one buffer."""
     from speaker_verification_amd import _lib
@@ -919,13 +946,16 @@ def test_pipeline_end_to_end_and_eer(eng):
         ref_emb.append(model_ref.c3d2_embed(state, model_ref.feature_cube(feat, crops[i])[None]).numpy()[0])
     ref_emb = np.stack(ref_emb)
     scale = np.abs(ref_emb).max()
-    np.testing.assert_allclose(emb, ref_emb, rtol=2e-3, atol=2e-4 * scale)
+    # (the bench's parity leg observes 7.6e-6 of the scale on 2 048 clips; 5e-5 leaves room for other weights, no more)
+    print("end to end: embedding max |diff| / scale %.2e" % (np.abs(emb - ref_emb).max() / scale))
+    np.testing.assert_allclose(emb, ref_emb, rtol=0, atol=5e-5 * scale)
 
     ids, last = enroll_last_utterance(emb, spk)                                # Q17
     scores = pipe.score(emb, emb[last]).cpu().numpy()
     ref_scores = scoring_ref.cosine_matrix(ref_emb, ref_emb[last])
     np.testing.assert_allclose(scores, scoring_ref.cosine_matrix(emb, emb[last]), rtol=0, atol=1e-5)
-    np.testing.assert_allclose(scores, ref_scores, rtol=0, atol=2e-3)
+    print("end to end: cosine max |diff| %.2e" % np.abs(scores - ref_scores).max())
+    np.testing.assert_allclose(scores, ref_scores, rtol=0, atol=2e-5)
     assert scores.std() > 0.05                                                  # well-conditioned scores
     labels = (spk[:, None] == ids[None, :]).astype(np.float64)
     eer_gpu, auc_gpu, _, _ = evaluation.get_eer_auc(labels.flatten(), scores.astype(np.float64).flatten())
@@ -1092,7 +1122,18 @@ def test_file_driven_enrol_and_evaluate(eng, golden, tmp_path, monkeypatch, caps
     gap = np.sort(g["eval_scores"], axis=1)
     if (gap[:, -1] - gap[:, -2]).min() > 2e-4:
         assert res["accuracy"] == pytest.approx(float(g["eval_accuracy_pct"][0]))
-    assert res["eer"] * 100 == pytest.approx(float(g["eval_eer_pct"][0]), abs=12.0)
+    # EER: the reference's number from the reference's scores through THIS build's function ...
+    eer_gold, auc_gold = evaluation.get_eer_auc(g["eval_labels"].flatten(), g["eval_scores"].flatten())[:2]
+    assert eer_gold * 100 == pytest.approx(float(g["eval_eer_pct"][0]), abs=1e-6)
+    assert auc_gold * 100 == pytest.approx(float(g["eval_auc_pct"][0]), abs=1e-6)
+    # ... and from the GPU's scores whenever they rank the 27 pairs as the reference's do (the ROC only sees the order;
+    # scores agree to 1e-4, so only a near-tie inside that band could reorder them)
+    flat = np.sort(g["eval_scores"].flatten())
+    if np.diff(flat).min() > 2e-4:
+        np.testing.assert_array_equal(np.argsort(res["scores"][:, cols].flatten(), kind="stable"),
+                                      np.argsort(g["eval_scores"].flatten(), kind="stable"))
+        assert res["eer"] * 100 == pytest.approx(float(g["eval_eer_pct"][0]), abs=1e-6)
+        assert res["auc"] * 100 == pytest.approx(float(g["eval_auc_pct"][0]), abs=1e-6)
     eer_o, auc_o = scoring_ref.k_fold_eer_auc(res["labels"].flatten(), res["scores"].flatten())
     assert res["eer"] == pytest.approx(eer_o, abs=1e-9) and res["auc"] == pytest.approx(auc_o, abs=1e-9)
     # the oracle chain, item by item, on the same tree and seeds
@@ -1245,6 +1286,21 @@ def test_siamese_train_step_on_rocm(eng):
     norms = [float(torch.norm(p.detach())) for p in gpu_model.parameters()]
     want = scoring_ref.contrastive_loss(y.numpy(), o1.cpu().numpy(), o2.cpu().numpy(), norms, 0.001, 2.0)
     assert loss == pytest.approx(want, rel=1e-4)
+
+
+def _cpu_layers(state, x, layers, pool=True):
+    """conv -> BatchNorm (eval, UNFOLDED) -> PReLU for each (tag, stride) of `layers` on torch-CPU, then MaxPool3d((1,1,2))
+    when `pool`: model.py:141-169 layer by layer, the oracle of the libsvk network kernels.  x: (n, C, D, H, W)."""
+    import torch.nn.functional as F
+    with torch.no_grad():
+        for tag, stride in layers:
+            x = F.conv3d(x, state[f"conv{tag}.weight"], state[f"conv{tag}.bias"], stride=stride)
+            x = F.batch_norm(x, state[f"batch_norm{tag}.running_mean"], state[f"batch_norm{tag}.running_var"],
+                             state[f"batch_norm{tag}.weight"], state[f"batch_norm{tag}.bias"], training=False, eps=1e-5)
+            x = F.prelu(x, state[f"PReLu{tag}.weight"])
+        if pool:
+            x = F.max_pool3d(x, kernel_size=(1, 1, 2), stride=(1, 1, 2))
+    return x.numpy()
 
 
 def test_c3d2_first_block_kernel(eng):
@@ -1481,6 +1537,18 @@ def test_network_kernels_many_items_per_workgroup(eng):
     wino = eng.c3d2_stage1(feat, crops, t1, folded=False, depth_transform=True)
     scale = float(direct.abs().max())
     assert float((wino - direct).abs().max()) <= 4e-6 * scale
+    # four cubes of the 64 (first, the zero cube's neighbour, middle, last: items that are a workgroup's 1st .. 9th)
+    # against the torch-CPU layers with unfolded BatchNorm: a persistent-loop bug common to both forms cannot pass
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    pick = [0, 8, 31, 63]
+    fh, ch = feat.cpu().numpy(), crops.cpu().numpy()
+    cubes = np.stack([model_ref.feature_cube(fh[u], np.maximum(ch[u], 0))[0] for u in pick])[:, None]
+    want1 = _cpu_layers(state, torch.from_numpy(cubes), (("1_1", (1, 1, 1)), ("1_2", (1, 2, 1))))   # (4, 16, 16, 36, 18)
+    for name, got in (("direct", direct), ("depth-transformed", wino)):
+        g4 = got[pick].permute(0, 4, 1, 2, 3).cpu().numpy()
+        err = np.abs(g4 - want1).max() / np.abs(want1).max()
+        print("first block, 64 cubes, %s vs torch-CPU: max |diff| / scale %.2e" % (name, err))
+        np.testing.assert_allclose(g4, want1, rtol=1e-4, atol=4e-6 * np.abs(want1).max())
     assert torch.equal(wino, eng.c3d2_stage1(feat, crops, t1, folded=False, depth_transform=True))
     assert float(wino[7].abs().max()) == pytest.approx(float(direct[7].abs().max()), rel=1e-6)   # the zero cube
     # second block: 256 cubes = 2 304 / 5 376 items over 512 workgroups
@@ -1490,6 +1558,13 @@ def test_network_kernels_many_items_per_workgroup(eng):
     w2 = eng.c3d2_stage2(act1, t2, depth_transform=True)
     assert float((w2 - d2).abs().max()) <= 4e-6 * float(d2.abs().max())
     assert torch.equal(w2, eng.c3d2_stage2(act1, t2, depth_transform=True))
+    pick = [0, 100, 201, 255]
+    want2 = _cpu_layers(state, act1[pick].permute(0, 4, 1, 2, 3).cpu().contiguous(), (("2_1", (1, 1, 1)), ("2_2", (1, 2, 1))))
+    for name, got in (("direct", d2), ("depth-transformed", w2)):
+        g4 = got[pick].permute(0, 4, 1, 2, 3).cpu().numpy()
+        print("second block, 256 cubes, %s vs torch-CPU: max |diff| / scale %.2e"
+              % (name, np.abs(g4 - want2).max() / np.abs(want2).max()))
+        np.testing.assert_allclose(g4, want2, rtol=1e-4, atol=4e-6 * np.abs(want2).max())
     del act1, d2
     # conv3_1: 200 cubes = 1 000 items over 768 workgroups, against the framework's convolution of the folded weights
     act2 = torch.randn((200, 12, 15, 7, 32), device=eng.device, generator=g)
@@ -1575,6 +1650,16 @@ def test_network_block_error_paths(eng):
     y = eng.c3d2_stage1(torch.randn((3, 90, 40), device=eng.device), torch.full((3, 20), -1, dtype=torch.int32,
                                                                               device=eng.device), tables, folded=False)
     assert bool(torch.isfinite(y).all()) and torch.equal(y[0], y[1]) and torch.equal(y[1], y[2])
+    # crop starts the C-ABI cannot trust: INT32_MAX (start + row would wrap negative), INT32_MAX - 79, max_frames, INT32_MIN
+    # -- all read as "no frames" (zero rows), never out of bounds; both kernel forms
+    featr = torch.randn((3, 90, 40), device=eng.device)
+    for wild in (2**31 - 1, 2**31 - 80, 90, -2**31):
+        bad = torch.full((3, 20), -1, dtype=torch.int32, device=eng.device)
+        bad[1] = wild
+        for dt in (False, True):
+            yb = eng.c3d2_stage1(featr, bad, tables, folded=False, depth_transform=dt)
+            torch.cuda.synchronize()
+            assert torch.equal(yb[1], yb[0]), (wild, dt)
 
 
 def test_bias_prelu_pass(eng):
