@@ -83,25 +83,81 @@ def parse(argv=None):
 # --------------------------------------------------------------------------------------------------
 # launcher: python bench.py --gpus N  ->  N fresh rank processes (never a re-exec of this one)
 # --------------------------------------------------------------------------------------------------
-def launch_ranks(n, argv):
+RANK_LOG_DIR = os.path.join(REPO, "gpurun_out", "bench_ranks")   # gpurun merges gpurun_out/ back: the logs survive the box
+INIT_TIMEOUT_S = 120                                               # torch's default is 10 min (RCCL) / 30 min (gloo)
+
+
+def _tail(path, lines=30):
+    try:
+        with open(path, "rb") as fh:
+            return b"\n".join(fh.read().splitlines()[-lines:]).decode("utf-8", "replace")
+    except OSError:
+        return ""
+
+
+def launch_ranks(n, argv, poll_s=0.2, grace_s=5.0):
+    """N fresh rank processes of this script.  Every rank's stderr (and rank 0's stdout) goes to a file under
+    gpurun_out/bench_ranks/ (a temporary directory when that is not writable); all children are polled, and the FIRST
+    one that exits non-zero ends the run: the others are terminated (they would otherwise sit in init_process_group or a
+    barrier until torch's timeout), that rank's last stderr lines are printed, and the launcher exits non-zero within
+    seconds.  Rank 0's one JSON line is relayed only when every rank succeeded."""
+    import signal
     import socket
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    log_dir = RANK_LOG_DIR
+    try:
+        os.makedirs(log_dir, exist_ok=True)
+        open(os.path.join(log_dir, ".w"), "w").close()
+        os.unlink(os.path.join(log_dir, ".w"))
+    except OSError:
+        log_dir = tempfile.mkdtemp(prefix="svk_bench_ranks_")
+    procs, files = [], []
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        err = open(os.path.join(log_dir, "rank%d.stderr" % rank), "wb")
+        out = open(os.path.join(log_dir, "rank%d.stdout" % rank), "wb")
+        files += [err, out]
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode("utf-8", "replace"))
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.stderr.write("bench.py: rank(s) failed: %s\n" % bad)
+                                      stdout=out, stderr=err))
+    codes = [None] * n
+    failed = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            break
+        time.sleep(poll_s)
+    if failed is not None:
+        # a dead rank leaves its peers waiting in a collective: end them now (children we started, by PID)
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                p.send_signal(signal.SIGTERM)
+        deadline = time.time() + grace_s
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                try:
+                    codes[r] = p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    codes[r] = p.wait()
+    for f in files:
+        f.close()
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with code %d; the other ranks were terminated (codes %s).  Last lines of "
+                         "%s/rank%d.stderr:\n%s\n" % (failed, codes[failed], codes, log_dir, failed,
+                                                     _tail(os.path.join(log_dir, "rank%d.stderr" % failed))))
         return 1
+    sys.stderr.write(_tail(os.path.join(log_dir, "rank0.stderr"), 200) + "\n")     # warnings of a good run stay visible
+    with open(os.path.join(log_dir, "rank0.stdout"), "rb") as fh:
+        sys.stdout.write(fh.read().decode("utf-8", "replace"))
+    sys.stdout.flush()
     return 0
 
 
@@ -127,10 +183,14 @@ def selftest_rank():
     import torch
     import torch.distributed as dist
     from speaker_verification_amd import distributed as svdist
+    from datetime import timedelta
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if os.environ.get("SVK_BENCH_FAIL_RANK") == str(rank):      # test hook: this rank dies before the rendezvous
+        sys.stderr.write("rank %d: SVK_BENCH_FAIL_RANK set, exiting with code 3 before init_process_group\n" % rank)
+        return 3
     if world > 1:
         with _stdout_to_stderr():
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=timedelta(seconds=INIT_TIMEOUT_S))
             dist.barrier()
     n_total = 1003
     lo, hi = svdist.shard_bounds(n_total, world, rank)
@@ -440,18 +500,29 @@ def cpu_child(sample_dir):
         pool.map(_cpu_count_frames, range(min(n, 2 * cores)), chunksize=1)            # warm the workers
         r, _ = rate(lambda: pool.map(_cpu_count_frames, range(n), chunksize=max(1, n // (8 * cores))), n)
         out["stages"]["frontend_allcores"] = {"utt_per_s": r, "clips": n, "cores": cores, "how": "multiprocessing.Pool"}
-        # ---- the whole per-utterance chain on all cores: one single-threaded worker per core, batch 1 ----
-        t0 = time.perf_counter()
-        embs = np.stack(pool.map(_cpu_chain, range(n), chunksize=max(1, n // (8 * cores))))
-        enroll = embs[::max(1, n // 40)][:40]
-        for i in range(n):                                                           # evaluation.py:73-77, pair by pair
-            scoring_ref.compute_similarity(embs[i], enroll)
-        dt = time.perf_counter() - t0
-    out["value"] = n / dt
-    out["seconds"] = dt
+    # ---- the whole per-utterance chain (batch 1, like evaluation.py:113-121), one single-threaded worker per slot, at
+    # several pool sizes: with SMT and memory-bound batch-1 convolutions "one worker per hardware thread" is not the
+    # fastest use of the host (1.6 utt/s per thread at 256 workers vs 115 on one).  `value` = the best. ----
+    sweep = sorted({max(1, cores // 4), max(1, cores // 2), cores})
+    out["chain_sweep"] = {}
+    best = None
+    for workers in sweep:
+        with ctx.Pool(workers) as pool:
+            pool.map(_cpu_count_frames, range(min(n, 2 * workers)), chunksize=1)      # warm: imports, first-touch
+            t0 = time.perf_counter()
+            embs_w = np.stack(pool.map(_cpu_chain, range(n), chunksize=max(1, n // (8 * workers))))
+            enroll = embs_w[::max(1, n // 40)][:40]
+            for i in range(n):                                                       # evaluation.py:73-77, pair by pair
+                scoring_ref.compute_similarity(embs_w[i], enroll)
+            dt_w = time.perf_counter() - t0
+        out["chain_sweep"][str(workers)] = {"utt_per_s": n / dt_w, "seconds": dt_w, "workers": workers}
+        if best is None or n / dt_w > best[0]:
+            best = (n / dt_w, dt_w, workers)
+        embs = embs_w                                                                # (identical whatever the pool size)
+    out["value"], out["seconds"], out["workers"] = best
     np.save(os.path.join(sample_dir, "cpu_emb.npy"), embs)
     # ---- C3D2 alone: batch 1 (evaluation.py:113-121) and batch 64, 1 thread and all threads ----
-    cubes = np.stack([model_ref.feature_cube(_cpu_features(i), _CPU["crops"][i]) for i in range(64)])
+    cubes = np.stack([model_ref.feature_cube(_cpu_features(i % n), _CPU["crops"][i % n]) for i in range(64)])
 
     def bounded(fn, per_call, budget=4.0, most=64):
         """utt/s of repeated `fn()` calls: one untimed call, then as many as fit `budget` seconds (torch-CPU
@@ -531,17 +602,29 @@ def main():
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", tag)
     import torch
     import torch.distributed as dist
-    n_dev = torch.cuda.device_count()
+    from datetime import timedelta
+    n_dev = torch.cuda.device_count()                      # (counting devices does not initialise the GPU)
+    if os.environ.get("SVK_BENCH_FAIL_RANK") == str(rank):
+        sys.stderr.write("rank %d: SVK_BENCH_FAIL_RANK set, exiting with code 3 before init_process_group\n" % rank)
+        return 3
+    if args.backend == "nccl" and world > n_dev:
+        # RCCL wants one device per rank: say so before any GPU call instead of failing inside the rendezvous
+        sys.stderr.write("bench.py: --gpus %d over RCCL needs %d devices, this host shows %d (torch.cuda.device_count()); "
+                         "use --backend gloo to rehearse several ranks on one GPU\n" % (world, world, n_dev))
+        return 2
     device_index = local_rank if args.backend == "nccl" else local_rank % max(1, n_dev)
     torch.cuda.set_device(device_index)
     use_dist = world > 1 or os.environ.get("SVK_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL with one rank
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         with _stdout_to_stderr():
+            # a rank that died before the rendezvous must not hold the others for torch's default 10 / 30 minutes
+            # (the launcher ends them within seconds; under torch.distributed.run this timeout is the bound)
             if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device_index),
+                                        timeout=timedelta(seconds=INIT_TIMEOUT_S))
             else:
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=timedelta(seconds=INIT_TIMEOUT_S))
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -640,10 +723,13 @@ def main():
         full, scores = one_step(True)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = [dt / args.steps * 1e3]
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                       # each rank's own wall time of the K steps ...
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        dt = max(float(t.item()) for t in every)           # ... and the max over ranks is the job's
     bad = int(pipe.bad_clips.item())
 
     result = None
@@ -748,6 +834,13 @@ def main():
             "backend": ("rccl (torch 'nccl')" if args.backend == "nccl" else "gloo") if use_dist else None,
             "allgather_us": float(np.median([a.elapsed_time(b) for a, b in ag_events])) * 1e3 if use_dist else None,
             "allgather_bytes_per_rank": svdist.shard_rows(n_total, world) * 128 * 4,
+            "per_rank_ms": per_rank_ms,
+            # what shaped RCCL's choice of algorithm / transport, when the caller set any of it (NCCL_DEBUG=INFO prints the
+            # ring / tree and the xGMI links picked to each rank's stderr file under gpurun_out/bench_ranks/)
+            "rccl_env": {k: v for k, v in os.environ.items()
+                         if k.startswith(("NCCL_", "RCCL_")) or k in ("HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES")},
+            "rccl_expectation_us": {"direct_one_shot": 62, "ring": 435,
+                                    "note": "SURVEY section 5, 9.5 MB per rank at 8 ranks over 153 GB/s xGMI links"},
             "roofline": main_roofline,
             "roofline_frontend": frontend_roofline,
             "roofline_stage2": stage2_roofline,
@@ -827,10 +920,12 @@ def main():
             par["full_matrix_eer_cpu_ref"] = float(scoring_ref.get_eer_auc(labels.flatten(), s_or.flatten())[0])
             result["parity"] = par
             result["cpu_baseline"] = {
-                "value": rec["value"], "unit": "utterances/s", "cores": rec["cores"], "kind": "port",
+                "value": rec["value"], "unit": "utterances/s", "cores": rec["workers"], "kind": "port",
                 "sample": "the first %d clips of the corpus through oracle/ in a fresh process: vad -> /32768 -> preemph "
-                          "-> lmfe -> cmvn -> cube -> C3D2 batch 1 -> per-pair cosine, one single-threaded worker "
-                          "per core (multiprocessing.Pool(%d)); %.1f s" % (ns, rec["cores"], rec["seconds"]),
+                          "-> lmfe -> cmvn -> cube -> C3D2 batch 1 -> per-pair cosine, single-threaded workers "
+                          "(multiprocessing.Pool): the best of %s workers = %d (%.1f s); the host shows %d hardware threads"
+                          % (ns, sorted(int(k) for k in rec["chain_sweep"]), rec["workers"], rec["seconds"], rec["cores"]),
+                "host_threads": rec["cores"], "chain_by_workers": rec["chain_sweep"],
                 "cpu_model": rec["cpu_model"], "os_cpu_count": rec["os_cpu_count"], "versions": rec["versions"],
                 "variants": rec["stages"], "child_wall_s": rec["wall_s"]}
     if rank == 0:

@@ -140,3 +140,42 @@ def test_bench_launcher_reports_a_failed_rank(tmp_path):
     proc = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--selftest", "--steps", "x"],
                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert proc.returncode != 0
+
+
+@pytest.mark.parametrize("dead", [1, 0])
+def test_bench_launcher_fails_fast_when_one_rank_dies(dead):
+    """ONE rank exits before `init_process_group` (a bad device index, a missing MIOpen db, OOM ...)
+    while the other sits in the rendezvous.  The launcher must notice the dead child, terminate the waiting one, print
+    the dead rank's stderr and return non-zero in seconds -- not after torch's 10 / 30 minute timeout."""
+    import subprocess
+    import sys
+    import time
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SVK_BENCH_FAIL_RANK"] = str(dead)
+    t0 = time.time()
+    proc = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--selftest"],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    took = time.time() - t0
+    err = proc.stderr.decode()
+    assert proc.returncode != 0 and took < 30, (proc.returncode, took, err[-500:])
+    assert proc.stdout.decode().strip() == ""                         # no JSON line from a failed job
+    assert "rank %d exited with code 3" % dead in err and "SVK_BENCH_FAIL_RANK" in err, err[-800:]
+
+
+def test_bench_refuses_more_rccl_ranks_than_devices():
+    """`--gpus N` over RCCL on a host with fewer devices fails before any GPU call, with the reason (this container has
+    no GPU at all: device_count() = 0)."""
+    import subprocess
+    import sys
+    import time
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("host has two devices")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    proc = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1"],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert proc.returncode != 0 and time.time() - t0 < 60
+    assert "needs 2 devices" in proc.stderr.decode()

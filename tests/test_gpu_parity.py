@@ -895,7 +895,7 @@ def test_siamese_forward_against_reference_loss(eng, golden):
     seed, n_labels, n_ch = (int(v) for v in g["sf_model_seed"])
     net = seeded_model(seed, n_labels=n_labels, num_channels=n_ch).to(eng.device)
     norms = np.array([float(torch.norm(p.detach())) for p in net.parameters()])
-    np.testing.assert_allclose(norms, g["sf_param_norms"], rtol=1e-6, atol=1e-12)   # same init as the reference's C3D2
+    np.testing.assert_allclose(norms, g["sf_param_norms"], rtol=5e-6, atol=1e-12)   # same init as the reference's C3D2 (f32 norms: summation order)
     y = torch.from_numpy(g["sf_y"]).to(eng.device)
     o1, o2 = torch.from_numpy(g["sf_o1"]).to(eng.device), torch.from_numpy(g["sf_o2"]).to(eng.device)
     for k, (lam, m) in enumerate(g["sf_cases"]):
