@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 103 /* 0.1.2 */
+#define SVK_VERSION 104 /* 0.1.3: svk_c3d2_conv41 / conv42 / fc5 */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -295,6 +295,33 @@ int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float*
  *   d_out   [n_utt][8][9][5][64]     channels last                                                                    */
 int svk_c3d2_conv32(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);
+/* (flags bit 3 of svk_c3d2_conv32: write d_out CHUNKED, [n_utt][8 d][8 chunks of 8 channels][45 = 9 h x 5 w][8] -- the
+ * layout svk_c3d2_conv41 stages from: a chunk of a plane is contiguous)                                              */
+
+/* The last block, model.py:132-139 (definitions) + :165-170 (forward): conv4_1 (64 -> 128, kernel (3,1,3)) -> BN -> PReLU,
+ * conv4_2 (128 -> 128, kernel (3,7,1)) -> BN -> PReLU, flatten, FC5 (4 608 -> 128) -- GEMMs over the BATCH on
+ * v_mfma_f32_16x16x4_f32 (csrc/c3d2_tail.hip): an M tile is one output position of 16 cubes, the convolutions run
+ * through Winograd's F(2, 3) along depth with the input transform applied once while a chunk is staged into LDS and the
+ * weight transform applied by the HOST.  Activations between these kernels are chunked: [cube][depth][channel / 8][pixel][channel % 8].
+ *   svk_c3d2_conv41  d_in  [n_utt][8][8][45][8]   = svk_c3d2_conv32's output with flags bit 3
+ *                    d_wfrag [8 nt][8 chunks][3 kw][4 k][64][2]: lane (co = 16 nt + (l & 15), kk = l >> 4), e:
+ *                            G_k[co][8 chunk + 2 kk + e][kw], G0 = g0, G1 = (g0 + g1 + g2) / 2, G2 = (g0 - g1 + g2) / 2,
+ *                            G3 = g2 over the three depth taps g of the BN-folded weights;  d_bias / d_slope [128]
+ *                    d_out [n_utt][6][16][27 = 9 h x 3 w][8]
+ *   svk_c3d2_conv42  d_in  = that;  d_wfrag [8 nt][16 chunks][7 kh][4 k][64][2] likewise;  d_out [n_utt][4][16][9 = 3 h x 3 w][8]
+ *   flags            bit 1: the caller asserts every PReLU slope lies in [0, 1]
+ *   svk_c3d2_fc5     d_in  [n_utt][4 608] = svk_c3d2_conv42's output, K index ((d * 16 + chunk) * 9 + pixel) * 8 + channel % 8
+ *                    d_wfrag [4 d][8 nt][72][64][4]: lane (j = 16 nt + (l & 15), kk = l >> 4), e: W5[j][column of K index
+ *                            1 152 d + 16 step + 4 kk + e] (model.py:168 flattens NCDHW: column = channel * 36 + d * 9 + pixel)
+ *                    d_bias [128];  d_work: svk_c3d2_fc5_workspace_floats(n_utt) floats (partial sums of the four K ranges,
+ *                    added in a fixed order: bitwise repeatable);  d_out [n_utt][128]                                  */
+int svk_c3d2_conv41(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
+                    const float* d_slope, int32_t flags, float* d_out);
+int svk_c3d2_conv42(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
+                    const float* d_slope, int32_t flags, float* d_out);
+size_t svk_c3d2_fc5_workspace_floats(int32_t n_utt);
+int svk_c3d2_fc5(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias, float* d_work,
+                 float* d_out);
 
 /* What follows each of conv3_1 .. conv4_2 (model.py:159-167; those convolutions run on the host framework): + bias
  * (BatchNorm folded), PReLU -- one in-place pass over channels-last activations d_x [n_rows][n_channels]

@@ -1270,8 +1270,9 @@ struct Conv32Params {
   const f32x4* wfrag;   // [4 nt][21 taps][4 chunks][64]: e: W[16 nt + (l & 15)][16 chunk + 4 (l >> 4) + e][kd][kh], tap = 7 kd + kh
   const float* bias;    // [64]
   const float* slope;   // [64]
-  float* out;           // [n][8][9][5][64]
+  float* out;           // [n][8][9][5][64], or chunked: [n][8][8 chunks of 8 channels][45][8] (what svk_c3d2_conv41 stages)
   int32_t n_utt;
+  int32_t chunked;
 };
 
 template <bool SLOPE01>
@@ -1393,12 +1394,15 @@ __global__ __launch_bounds__(512) void c3d2_conv32w_kernel(const Conv32Params p)
 #pragma unroll
           for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(xi + w * (6 * 64 * 4));
           const int tl = unit >> 1, y = unit & 1;
-          // rows 4 kk + r = position 16 tl + 4 kk + r (< 45): positions are contiguous in the output, channels last
-          float* const o = p.out + (((int64_t)u * 8 + 2 * P + y) * 45 + 16 * tl) * 64 + 16 * nt;
-          const int olane = 4 * kk * 64 + i;
+          // rows 4 kk + r = position 16 tl + 4 kk + r (< 45): positions are contiguous in the output, channels last -- or
+          // chunked, [depth][chunk = channel / 8][position][channel % 8] (wave-uniform choice)
+          float* const o = p.chunked ? p.out + ((((int64_t)u * 8 + 2 * P + y) * 8 + 2 * nt) * 45 + 16 * tl) * 8
+                                     : p.out + (((int64_t)u * 8 + 2 * P + y) * 45 + 16 * tl) * 64 + 16 * nt;
+          const int olane = p.chunked ? (i >> 3) * (45 * 8) + 4 * kk * 8 + (i & 7) : 4 * kk * 64 + i;
+          const int rstep = p.chunked ? 8 : 64;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (16 * tl + 4 * kk + r < 45) o[olane + r * 64] = prelu_t<SLOPE01>(v[r], sl);
+            if (16 * tl + 4 * kk + r < 45) o[olane + r * rstep] = prelu_t<SLOPE01>(v[r], sl);
         }
       }
     }
@@ -1540,7 +1544,7 @@ extern "C" int svk_c3d2_conv32(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_wfrag)) & 15) == 0,
               "buffers must be 16-byte aligned");
   SVK_REQUIRE(ctx, (int64_t)n_utt * 4 < ((int64_t)1 << 29), "too many cubes for one launch");
-  Conv32Params p{d_in, reinterpret_cast<const f32x4*>(d_wfrag), d_bias, d_slope, d_out, n_utt};
+  Conv32Params p{d_in, reinterpret_cast<const f32x4*>(d_wfrag), d_bias, d_slope, d_out, n_utt, (flags & 8) ? 1 : 0};
   void (*kern)(const Conv32Params) = (flags & 2) ? c3d2_conv32w_kernel<true> : c3d2_conv32w_kernel<false>;
   const size_t lds = sizeof(float) * (size_t)C32_LDS_FLOATS;
   if (lds > (size_t)ctx->lds_per_cu)

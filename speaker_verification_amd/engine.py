@@ -466,17 +466,56 @@ class Engine:
                                        2 if slope01 else 0, self._ptr(out)), self.ctx)
         return out
 
-    def c3d2_conv32(self, act, tables):
+    def c3d2_conv32(self, act, tables, chunked=False):
         """svk_c3d2_conv32: [n, 10, 15, 5, 64] (svk_c3d2_conv31's output) -> conv3_2 + BN + PReLU -> [n, 8, 9, 5, 64]
-        f32, channels last (Winograd F(2, 3) along depth, partial sums over four K chunks added through LDS)."""
+        f32, channels last (Winograd F(2, 3) along depth, partial sums over four K chunks added through LDS); with
+        `chunked` the output is [n, 8 d, 8 chunks, 45 pixels, 8]: what svk_c3d2_conv41 stages from."""
         torch = _torch()
         n = act.shape[0]
         wfrag, bias, slope = tables[:3]
         slope01 = bool(tables[3]) if len(tables) > 3 else False
-        out = torch.empty((n, 8, 9, 5, 64), dtype=torch.float32, device=self.device)
+        out = torch.empty((n, 8, 8, 45, 8) if chunked else (n, 8, 9, 5, 64), dtype=torch.float32, device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_conv32(self.ctx, self._ptr(act), n, self._ptr(wfrag), self._ptr(bias), self._ptr(slope),
-                                       2 if slope01 else 0, self._ptr(out)), self.ctx)
+                                       (2 if slope01 else 0) | (8 if chunked else 0), self._ptr(out)), self.ctx)
+        return out
+
+    def _c3d2_tail_conv(self, fn, act, tables, out_shape):
+        torch = _torch()
+        n = act.shape[0]
+        wfrag, bias, slope = tables[:3]
+        slope01 = bool(tables[3]) if len(tables) > 3 else False
+        out = torch.empty((n,) + out_shape, dtype=torch.float32, device=self.device)
+        self._stream()
+        check(fn(self.ctx, self._ptr(act), n, self._ptr(wfrag), self._ptr(bias), self._ptr(slope), 2 if slope01 else 0,
+                 self._ptr(out)), self.ctx)
+        return out
+
+    def c3d2_conv41(self, act, tables):
+        """svk_c3d2_conv41: chunked [n, 8 d, 8 chunks, 45, 8] (svk_c3d2_conv32 with chunked=True) -> conv4_1 + BN + PReLU
+        -> chunked [n, 6 d, 16 chunks, 27 = 9 h x 3 w, 8] (a GEMM over the batch: M tile = one position of 16 cubes)."""
+        if tuple(act.shape[1:]) != (8, 8, 45, 8) or not act.is_contiguous():
+            raise ValueError("c3d2_conv41 wants the chunked activation [n, 8, 8, 45, 8]")
+        return self._c3d2_tail_conv(self.lib.svk_c3d2_conv41, act, tables, (6, 16, 27, 8))
+
+    def c3d2_conv42(self, act, tables):
+        """svk_c3d2_conv42: chunked [n, 6, 16, 27, 8] -> conv4_2 + BN + PReLU -> chunked [n, 4 d, 16 chunks, 9 = 3 h x 3 w, 8]."""
+        if tuple(act.shape[1:]) != (6, 16, 27, 8) or not act.is_contiguous():
+            raise ValueError("c3d2_conv42 wants the chunked activation [n, 6, 16, 27, 8]")
+        return self._c3d2_tail_conv(self.lib.svk_c3d2_conv42, act, tables, (4, 16, 9, 8))
+
+    def c3d2_fc5(self, act, tables):
+        """svk_c3d2_fc5: chunked [n, 4, 16, 9, 8] (= [n, 4 608]) -> FC5 -> [n, 128] embeddings."""
+        torch = _torch()
+        n = act.shape[0]
+        if act.numel() != n * 4608 or not act.is_contiguous():
+            raise ValueError("c3d2_fc5 wants [n, 4608] (svk_c3d2_conv42's output)")
+        wfrag, bias = tables
+        work = torch.empty((int(self.lib.svk_c3d2_fc5_workspace_floats(n)),), dtype=torch.float32, device=self.device)
+        out = torch.empty((n, 128), dtype=torch.float32, device=self.device)
+        self._stream()
+        check(self.lib.svk_c3d2_fc5(self.ctx, self._ptr(act), n, self._ptr(wfrag), self._ptr(bias), self._ptr(work),
+                                    self._ptr(out)), self.ctx)
         return out
 
     def bias_prelu_(self, x, bias, slope):

@@ -115,6 +115,7 @@ class FusedEmbedder:
             self.fused_tail = None
             self.conv31_kernel = False       # conv3_1 in libsvk behind svk_c3d2_stage2 (SVK_C3D2_CONV31=0 disables)
             self.conv32_kernel = False       # ... and conv3_2 behind it (SVK_C3D2_CONV32=0 disables)
+            self.conv4_kernels = False       # ... and conv4_1, conv4_2, FC5 (SVK_C3D2_CONV4=0 hands them back to PyTorch-ROCm)
             if channels_last and self.fc_w.is_cuda:
                 import os
                 if os.environ.get("SVK_C3D2_TAIL", "1") != "0":
@@ -122,6 +123,7 @@ class FusedEmbedder:
                     self.fused_tail = get_engine(self.fc_w.device.index)
                     self.conv31_kernel = os.environ.get("SVK_C3D2_CONV31", "1") != "0"
                     self.conv32_kernel = self.conv31_kernel and os.environ.get("SVK_C3D2_CONV32", "1") != "0"
+                    self.conv4_kernels = self.conv32_kernel and os.environ.get("SVK_C3D2_CONV4", "1") != "0"
             # First layer as patch-matrix x weight GEMM.  MIOpen has no direct kernel for a 1-channel
             # Conv3d and falls back to im2col + per-group GEMM + layout transposes (6.5 ms per 978
             # cubes).  Here ONE strided copy gathers, for every group of G adjacent output columns, the
@@ -356,6 +358,81 @@ class FusedEmbedder:
         self._conv32 = (frag.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
         return self._conv32
 
+    @staticmethod
+    def _depth_transformed(w):
+        """Winograd F(2, 3) weight transform along depth of a BN-folded Conv3d weight [co][ci][3][kh][kw] ->
+        [4 k][co][ci][kh][kw]: G0 = g0, G1 = ((g0 + g2) + g1) / 2, G2 = ((g0 + g2) - g1) / 2, G3 = g2 (f32, the same
+        expressions the kernels of csrc/c3d2.hip evaluate in their prologues)."""
+        g0, g1, g2 = w[:, :, 0], w[:, :, 1], w[:, :, 2]
+        return torch.stack((g0, 0.5 * ((g0 + g2) + g1), 0.5 * ((g0 + g2) - g1), g2))
+
+    def _tail_conv_tables(self, li, shape, taps_axis):
+        """Operand fragments of `svk_c3d2_conv41` / `svk_c3d2_conv42` from stage `li`, or None when the layer differs:
+        wfrag [8 nt][chunks of 8 input channels][taps][4 k][64 lanes][2]: lane (co = 16 nt + (l & 15), kk = l >> 4),
+        element e = G_k[co][8 chunk + 2 kk + e][tap]."""
+        if len(self.stages) <= li:
+            return None
+        w, b, sl, st, pool, _ = self.stages[li]
+        if tuple(w.shape) != shape or tuple(st) != (1, 1, 1) or pool:
+            return None
+        dev = w.device
+        co, ci = shape[0], shape[1]
+        g = self._depth_transformed(w.contiguous())                          # [4][co][ci][kh][kw]
+        g = g[:, :, :, :, 0] if taps_axis == "h" else g[:, :, :, 0, :]        # [4][co][ci][taps]
+        taps = g.shape[3]
+        lane = torch.arange(64, device=dev)
+        n_, kq = lane & 15, lane >> 4
+        # frag[nt][chunk][tap][k][lane][e] = g[k][16 nt + n_][8 chunk + 2 kq + e][tap]
+        frag = torch.empty((co // 16, ci // 8, taps, 4, 64, 2), dtype=torch.float32, device=dev)
+        gg = g.view(4, co // 16, 16, ci // 8, 4, 2, taps)                    # [k][nt][n][chunk][kq][e][tap]
+        frag.copy_(gg[:, :, n_, :, kq].permute(2, 3, 5, 1, 0, 4))            # advanced indices (n, kq) -> leading lane axis
+        slope = sl.expand(co).contiguous() if sl.numel() == 1 else sl.contiguous()
+        return (frag.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
+
+    def conv41_tables(self):
+        """`svk_c3d2_conv41` (conv4_1: 64 -> 128, k(3,1,3), stride 1, no pool), BN folded, depth-transformed by the host."""
+        hit = getattr(self, "_conv41", False)
+        if hit is False:
+            hit = self._conv41 = self._tail_conv_tables(6, (128, 64, 3, 1, 3), "w")
+        return hit
+
+    def conv42_tables(self):
+        """`svk_c3d2_conv42` (conv4_2: 128 -> 128, k(3,7,1), stride 1, no pool)."""
+        hit = getattr(self, "_conv42", False)
+        if hit is False:
+            hit = self._conv42 = self._tail_conv_tables(7, (128, 128, 3, 7, 1), "h")
+        return hit
+
+    def fc5_tables(self):
+        """`svk_c3d2_fc5`: wfrag [4 d][8 nt][72 steps][64 lanes][4]: lane (j = 16 nt + (l & 15), kk = l >> 4), e:
+        W5[j][c * 36 + d * 9 + pixel] for the K index 1 152 d + 16 step + 4 kk + e = ((d * 16 + chunk) * 9 + pixel) * 8 + c % 8
+        (conv4_2's chunked output order; model.py:168 flattens NCDHW), and the bias.  None when FC5 is not 4 608 -> 128."""
+        hit = getattr(self, "_fc5", False)
+        if hit is not False:
+            return hit
+        self._fc5 = None
+        if tuple(self.fc_w.shape) != (EMBED_DIM, _FLAT) or EMBED_DIM != 128:
+            return None
+        dev = self.fc_w.device
+        # columns of the chunked order: [d][chunk][pixel][c8] -> torch column (8 chunk + c8) * 36 + d * 9 + pixel
+        d, ch, px, c8 = torch.meshgrid(torch.arange(4, device=dev), torch.arange(16, device=dev),
+                                       torch.arange(9, device=dev), torch.arange(8, device=dev), indexing="ij")
+        col = ((8 * ch + c8) * 36 + d * 9 + px).reshape(-1)                  # [4608] in K order
+        wk = self.fc_w[:, col]                                               # [128 j][4608 K]
+        lane = torch.arange(64, device=dev)
+        n_, kq = lane & 15, lane >> 4
+        wv = wk.view(8, 16, 4, 72, 4, 4)                                     # [nt][n][d][step][kq][e]
+        frag = wv[:, n_, :, :, kq].permute(2, 1, 3, 0, 4).contiguous()       # lane axis first -> [d][nt][step][lane][e]
+        self._fc5 = (frag, self.fc_b.contiguous())
+        return self._fc5
+
+    @torch.no_grad()
+    def tail_from_conv32(self, y, n):
+        """conv4_1 -> conv4_2 -> FC5 in libsvk from conv3_2's CHUNKED output [n][8][8][45][8] (csrc/c3d2_tail.hip)."""
+        y = self.fused_tail.c3d2_conv41(y, self.conv41_tables())
+        y = self.fused_tail.c3d2_conv42(y, self.conv42_tables())
+        return self.fused_tail.c3d2_fc5(y, self.fc5_tables())
+
     @torch.no_grad()
     def from_stage2(self, z, n):
         """Embeddings from the output of `svk_c3d2_stage2`: the activation after pool2, [n][12][15][7][32].  conv3_1 runs
@@ -365,6 +442,10 @@ class FusedEmbedder:
             y = self.fused_tail.c3d2_conv31(z.view(n, 12, 15, 7, 32), t31)
             t32 = self.conv32_tables() if self.conv32_kernel else None
             if t32 is not None:
+                if (self.conv4_kernels and self.conv41_tables() is not None and self.conv42_tables() is not None
+                        and self.fc5_tables() is not None):
+                    # the whole rest of the network in libsvk: conv3_2 writes the chunked layout conv4_1 stages from
+                    return self.tail_from_conv32(self.fused_tail.c3d2_conv32(y, t32, chunked=True), n)
                 y = self.fused_tail.c3d2_conv32(y, t32)
                 x = y.view(n, 8, 9, 5, 64).permute(0, 4, 1, 2, 3)           # (n, 64, 8, 9, 5), channels_last_3d memory
                 return self._run(x, start=6)

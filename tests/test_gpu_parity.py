@@ -1515,6 +1515,106 @@ def test_c3d2_conv32_kernel(eng, monkeypatch):
     assert eng.lib.svk_c3d2_conv32(eng.ctx, None, 1, None, None, None, 0, None) == -1
 
 
+def _to_chunked(x):
+    """(n, C, D, H, W) -> the chunked layout of csrc/c3d2_tail.hip: [n][D][C / 8][H * W][8]."""
+    n, C, D, H, W = x.shape
+    return np.ascontiguousarray(x.reshape(n, C // 8, 8, D, H * W).transpose(0, 3, 1, 4, 2))
+
+
+def _from_chunked(y, H, W):
+    """[n][D][C / 8][H * W][8] -> (n, C, D, H, W)."""
+    n, D, Cg, P, _ = y.shape
+    return np.ascontiguousarray(y.transpose(0, 2, 4, 1, 3)).reshape(n, Cg * 8, D, H, W)
+
+
+def test_c3d2_tail_kernels(eng, monkeypatch):
+    """svk_c3d2_conv41, svk_c3d2_conv42, svk_c3d2_fc5 (model.py:132-139,165-170: conv4_1 -> BN -> PReLU -> conv4_2 -> BN ->
+    PReLU -> flatten -> FC5 as GEMMs over the batch, Winograd F(2,3) along depth, host-transformed weights) each against
+    the same layer on torch-CPU with unfolded BatchNorm: batches of 1, 3 (one partial group of 16 cubes), 37 (2 full + 1
+    partial), 70 (several items per workgroup for FC5's 64-cube groups) and 300 cubes (several items per workgroup for the
+    convolutions: 19 groups x 9 / 2 items on 256 workgroups needs n > 455 / 2 048 -- covered by the 2 100-cube case of
+    conv4_2 below); negative / per-channel slopes; conv3_2's chunked output; the whole embedding with and without."""
+    import torch.nn.functional as F
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    model = seeded_model(91, n_labels=8)
+    model.load_state_dict(perturb_inference_state(model.state_dict(), 92))
+    emb = model.to(eng.device).eval().fused_inference(channels_last=True)
+    t41, t42, tfc = emb.conv41_tables(), emb.conv42_tables(), emb.fc5_tables()
+    assert t41 is not None and t42 is not None and tfc is not None and t41[3] and t42[3]
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(8)
+
+    def layer(tag, x, slope=None):
+        with torch.no_grad():
+            x = F.conv3d(torch.from_numpy(x), state[f"conv{tag}.weight"], state[f"conv{tag}.bias"])
+            x = F.batch_norm(x, state[f"batch_norm{tag}.running_mean"], state[f"batch_norm{tag}.running_var"],
+                             state[f"batch_norm{tag}.weight"], state[f"batch_norm{tag}.bias"], training=False, eps=1e-5)
+            return F.prelu(x, state[f"PReLu{tag}.weight"] if slope is None else slope).numpy()
+
+    for n in (1, 3, 37, 70, 520):
+        # conv4_1: (n, 64, 8, 9, 5) -> (n, 128, 6, 9, 3)
+        x = rng.standard_normal((n, 64, 8, 9, 5)).astype(np.float32)
+        want = layer("4_1", x)
+        got = _from_chunked(eng.c3d2_conv41(eng.to_device(_to_chunked(x)), t41).cpu().numpy(), 9, 3)
+        err41 = np.abs(got - want).max() / np.abs(want).max()
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=4e-6 * np.abs(want).max())
+        # conv4_2: (n, 128, 6, 9, 3) -> (n, 128, 4, 3, 3)
+        x2 = rng.standard_normal((n, 128, 6, 9, 3)).astype(np.float32)
+        want2 = layer("4_2", x2)
+        got2c = eng.c3d2_conv42(eng.to_device(_to_chunked(x2)), t42)
+        got2 = _from_chunked(got2c.cpu().numpy(), 3, 3)
+        err42 = np.abs(got2 - want2).max() / np.abs(want2).max()
+        np.testing.assert_allclose(got2, want2, rtol=1e-4, atol=4e-6 * np.abs(want2).max())
+        # FC5 on conv4_2's chunked output: model.py:168 flattens NCDHW
+        with torch.no_grad():
+            want3 = F.linear(torch.from_numpy(got2).reshape(n, 4608), state["FC5.weight"], state["FC5.bias"]).numpy()
+        got3 = eng.c3d2_fc5(got2c, tfc).cpu().numpy()
+        errfc = np.abs(got3 - want3).max() / np.abs(want3).max()
+        np.testing.assert_allclose(got3, want3, rtol=1e-4, atol=4e-6 * np.abs(want3).max())
+        assert torch.equal(eng.c3d2_fc5(got2c, tfc), eng.c3d2_fc5(got2c, tfc))                     # fixed summation order
+        print("tail kernels, %d cubes: max |diff| / scale conv4_1 %.2e, conv4_2 %.2e, FC5 %.2e" % (n, err41, err42, errfc))
+    # several items per workgroup for conv4_2 (2 items per group of 16 cubes; 256 workgroups): 2 100 cubes, sampled rows
+    x2 = rng.standard_normal((2100, 128, 6, 9, 3)).astype(np.float32)
+    got2 = eng.c3d2_conv42(eng.to_device(_to_chunked(x2)), t42)
+    assert torch.equal(got2, eng.c3d2_conv42(eng.to_device(_to_chunked(x2)), t42))
+    pick = [0, 15, 16, 1000, 2047, 2048, 2099]
+    want2 = layer("4_2", x2[pick])
+    np.testing.assert_allclose(_from_chunked(got2[pick].cpu().numpy(), 3, 3), want2, rtol=1e-4, atol=4e-6 * np.abs(want2).max())
+    del got2, x2
+    # general PReLU (negative and per-channel slopes) and the [0, 1] form agree where both apply
+    x = rng.standard_normal((5, 64, 8, 9, 5)).astype(np.float32)
+    xc = eng.to_device(_to_chunked(x))
+    np.testing.assert_array_equal(eng.c3d2_conv41(xc, t41[:3] + (False,)).cpu().numpy(), eng.c3d2_conv41(xc, t41).cpu().numpy())
+    sn = torch.linspace(-0.5, 0.4, 128)
+    got_n = _from_chunked(eng.c3d2_conv41(xc, (t41[0], t41[1], sn.to(eng.device), False)).cpu().numpy(), 9, 3)
+    want_n = layer("4_1", x, sn)
+    np.testing.assert_allclose(got_n, want_n, rtol=1e-4, atol=4e-6 * np.abs(want_n).max())
+    # conv3_2's chunked output is its channels-last output re-ordered
+    t32 = emb.conv32_tables()
+    a32 = torch.randn((21, 10, 15, 5, 64), device=eng.device)
+    plain = eng.c3d2_conv32(a32, t32).cpu().numpy()                                   # [n][8][9][5][64]
+    chunked = eng.c3d2_conv32(a32, t32, chunked=True).cpu().numpy()                   # [n][8][8][45][8]
+    np.testing.assert_array_equal(_from_chunked(chunked, 9, 5), plain.transpose(0, 4, 1, 2, 3))
+    # error paths: wrong layouts are refused by the host layer, NULL buffers by the library
+    with pytest.raises(ValueError):
+        eng.c3d2_conv41(a32, t41)
+    assert eng.lib.svk_c3d2_conv41(eng.ctx, None, 1, None, None, None, 0, None) == -1
+    assert eng.lib.svk_c3d2_conv42(eng.ctx, None, 1, None, None, None, 0, None) == -1
+    assert eng.lib.svk_c3d2_fc5(eng.ctx, None, 1, None, None, None, None) == -1
+    assert eng.lib.svk_c3d2_conv42(eng.ctx, None, 0, None, None, None, 0, None) == 0
+    # the whole path with and without the tail kernels
+    pcm, _ = synth.corpus(3, 3)
+    with_k = VerificationPipeline(model, crop_rng="device", crop_seed=9, normalize=True, preemph_cof=0.98)
+    assert with_k.embedder.conv4_kernels
+    a = with_k.embed(pcm).cpu().numpy()
+    monkeypatch.setenv("SVK_C3D2_CONV4", "0")
+    without = VerificationPipeline(model, crop_rng="device", crop_seed=9, normalize=True, preemph_cof=0.98)
+    assert not without.embedder.conv4_kernels
+    b = without.embed(pcm).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=4e-6 * np.abs(b).max())
+
+
 def test_network_kernels_many_items_per_workgroup(eng):
     """The network kernels are persistent (a workgroup loops over work items, the first block prefetching the next item's
     patch inside the current one's matrix work): the small-batch tests above give every workgroup at most one item, so
