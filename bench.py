@@ -7,29 +7,34 @@ One STEP = one pass of the whole path over BASELINE.json's corpus, 148 642 synth
 sharded over the N ranks (rank r owns the contiguous range of ceil(148 642 / N) clips; STRONG scaling:
 the total is fixed), PCM resident in HBM:
     int16 PCM -> energy VAD -> fused pre-emphasis + log-mel(40) front end -> CMVN -> 20x80x40 cube
-    -> C3D2 embedding (PyTorch-ROCm, f32) -> all-gather of the [clips,128] shards (RCCL)
-    -> 4 874 x 40 cosine score matrix (MFMA).
-value = 148 642 clips x steps / max-over-ranks time.
+    -> C3D2 embedding (f32 MFMA, seven libsvk kernels: svk_c3d2_stage1 / stage2 / conv31 / conv32 / conv41 / conv42 / fc5)
+    -> all-gather of the [clips,128] shards (RCCL) -> 4 874 x 40 cosine score matrix (MFMA).
+value = 148 642 clips x steps / max-over-ranks time.  Nothing in the step is a framework operator: torch supplies
+device memory, streams, events and torch.distributed.
 
 Launch: with WORLD_SIZE in the environment (torch.distributed.run) this process is one rank; without it
 and --gpus N > 1 this process only starts N fresh rank processes of itself (RANK / LOCAL_RANK /
-WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), relays rank 0's JSON line and exits with the worst code.
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), polls them, ends the others when one dies, relays rank 0's JSON line.
 
 The JSON line also carries
-  roofline      -- the dominant kernel, hand-written: c3d2_stage1_kernel (cube + conv1_1 + conv1_2 + pool1 on f32
-                   MFMA, ~40 % of the step): algorithmic FLOPs per launch over the HIP-event duration of each launch
-                   in the timed region, against the 157.3 TFLOP/s f32 matrix peak;  roofline_stage2: conv2_1 + conv2_2;
+  roofline      -- the dominant kernel, c3d2_stage1w_kernel (cube + conv1_1 + conv1_2 + pool1, ~43 % of the step), bound
+                   MFMA: frac = ISSUED matrix work (SQ_INSTS_MFMA per cube from the committed PMC pass x 2 048 FLOP x
+                   cubes per launch) / the HIP-event duration of each launch in the timed region / 157.3 TFLOP/s -- a
+                   share of the f32 matrix pipe's issue slots, never above 1; algorithmic_frac = SURVEY 8(d)'s direct-form
+                   multiply-adds instead (what Winograd F(2,3) along depth saves shows as algorithmic_frac > frac);
+  roofline_network -- the same two fractions for EVERY network kernel (stage2 = conv2_1 + conv2_2, conv3_1, conv3_2,
+                   conv4_1, conv4_2, fc5) with each one's share of the step; roofline_stage2 = its stage2 row;
   roofline_frontend -- the fused front-end kernel (HBM roof): algorithmic HBM bytes of the launches it actually
                    ran (VAD-shortened clips) over their HIP-event durations;
-  roofline_e2e  -- the whole step against the f32 matrix peak: value x 0.6766 GFLOP (the C3D2 forward is
-                   95 % of the step) / 157.3 TFLOP/s -- the ceiling SURVEY 8(d) names (232 k utt/s/GPU);
-  ranks_seen / backend / allgather_us -- what torch.distributed reports and the HIP-event time of the
-                   embedding all-gather;
-  frontend_A, cosine_mfma, stage_kernels, ingest_resample -- the other hand-written kernels on their own;
+  roofline_e2e  -- the whole step against the f32 matrix peak: frac from the issued MFMA work per utterance,
+                   algorithmic_frac from SURVEY 8(d)'s 676.6 MFLOP (ceiling 232 k utt/s/GPU);
+  ranks_seen / backend / allgather_us / per_rank_ms -- what torch.distributed reports, the HIP-event time of the
+                   embedding all-gather, every rank's own step time;
+  frontend_A, cosine_mfma, stage_kernels, ingest_resample, ragged -- the other hand-written kernels / workloads on their own;
   cpu_baseline  -- the CPU oracle (NumPy/torch-CPU restatement of the reference, kind "port") timed in a
-                   fresh child process on rank 0, N = 1 only: all host cores on the per-utterance chain
-                   (`value`), plus 1-core / all-core and batch-1 / batch-64 variants per stage;
-  parity        -- GPU vs oracle on that sample + EER of the 4 874 x 40 score matrix.
+                   fresh child process on rank 0, N = 1 only: the per-utterance chain on single-threaded workers at
+                   three pool sizes (`value` = the best), plus 1-core / all-core and batch-1 / batch-64 variants per stage;
+  parity        -- the PRODUCTION path (libsvk end to end) vs the oracle on that sample + EER of the 4 874 x 40 matrix.
 """
 import argparse
 import json
@@ -49,6 +54,20 @@ F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA peak
 C3D2_GFLOP_PER_UTT = 0.6766      # 338.3 M multiply-adds per cube
 STAGE1_GFLOP_PER_UTT = 2 * (12.4416 + 143.327232) / 1e3   # conv1_1 12.44 M + conv1_2 143.33 M multiply-adds
 STAGE2_GFLOP_PER_UTT = 2 * (46.44864 + 66.3552) / 1e3     # conv2_1 46.45 M + conv2_2 66.36 M
+MFMA_FLOP = 2048                 # v_mfma_f32_16x16x4_f32: 16 x 16 x 4 multiply-adds
+# The network kernels as the pipeline times them (HIP-event spans): span name, kernel symbols in the rocprofv3 / PMC
+# summaries, SURVEY 8(a)'s direct-form multiply-adds per cube (millions), and the MFMA wave-instructions the kernel issues
+# per cube BY CONSTRUCTION (items x tiles x taps x 4-deep steps) -- replaced at run time by the committed
+# SQ_INSTS_MFMA counter of profiles/rNN_frontend_pmc.json when that file has the kernel (they agree to 1e-4).
+NETWORK_KERNELS = (
+    ("stage1", ("c3d2_stage1w_kernel",), 12.4416 + 143.327232, 118080),         # 36 items x (400 conv1_1 + 2 880 conv1_2)
+    ("stage2", ("c3d2_conv21w_kernel", "c3d2_conv22w_kernel"), 46.44864 + 66.3552, 32256 + 43008),
+    ("conv3_1", ("c3d2_conv31w_kernel",), 13.824, 9600),
+    ("conv3_2", ("c3d2_conv32w_kernel",), 30.96576, 21504),
+    ("conv4_1", ("c3d2_tail_kernel<Conv41>",), 11.943936, 15552),
+    ("conv4_2", ("c3d2_tail_kernel<Conv42>",), 12.386304, 8064),
+    ("fc5", ("fc5_kernel",), 0.589824, 144),
+)
 N_CORPUS = 148642                # VoxCeleb1 dev utterances (README.md:5-7) = BASELINE configs[4]
 N_TEST, N_TEST_SPK = 4874, 40    # VoxCeleb1 verification split (README.md:4-7)
 UTTS_PER_SPK = 123
@@ -71,7 +90,7 @@ def parse(argv=None):
     ap.add_argument("--frontend-only", action="store_true", help="time BASELINE config 2 only (for rocprof)")
     ap.add_argument("--stages-only", action="store_true", help="time the stage-level kernels only (for rocprof)")
     ap.add_argument("--c3d2-only", action="store_true",
-                    help="features of 1 024 clips once, then the network (libsvk blocks 1-2 + PyTorch rest) K times (for rocprof --pmc)")
+                    help="features of 1 024 clips once, then the network (seven libsvk kernels) K times (for rocprof --pmc)")
     ap.add_argument("--backend", default=os.environ.get("SVK_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="gloo: rehearse N ranks on ONE GPU (RCCL refuses two ranks on a device)")
     ap.add_argument("--selftest", action="store_true",
@@ -227,6 +246,20 @@ def pmc_traffic(kernel):
     except (OSError, ValueError):
         return None, None
     return rec.get("hbm_traffic_bytes_per_launch"), os.path.basename(files[-1])
+
+
+def pmc_counter(kernel, counter, per=1024.0):
+    """`counter` per cube of `kernel` from the newest committed PMC summary (the c3d2_* kernels were profiled over
+    `bench.py --c3d2-only`: 1 024 cubes per launch), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_frontend_pmc.json")), reverse=True):
+        try:
+            rec = json.load(open(path)).get(kernel, {})
+        except (OSError, ValueError):
+            continue
+        if counter in rec:
+            return rec[counter] / per, os.path.basename(path)
+    return None, None
 
 
 def _median_ms(torch, fn, reps, warm=3):
@@ -655,7 +688,7 @@ def main():
         feat, n_frames = pipe.features(voiced, vlen)
         idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, 0, pipe.bad_clips)
         ms = _median_ms(torch, lambda: pipe.embed_features(feat, idx), max(args.steps, 5))
-        print(json.dumps({"workload": "1024 cubes: svk_c3d2_stage1 + svk_c3d2_stage2 + svk_c3d2_conv31 + svk_c3d2_conv32 + conv4_1 .. FC5 (PyTorch-ROCm)",
+        print(json.dumps({"workload": "1024 cubes: svk_c3d2_stage1 + stage2 + conv31 + conv32 + conv41 + conv42 + fc5",
                           "ms": ms, "utt_per_s": 1024 / ms * 1e3, "tflops": 1024 * C3D2_GFLOP_PER_UTT / ms}))
         return 0
     n_total = args.corpus
@@ -669,11 +702,20 @@ def main():
                                 overlap_front=os.environ.get("SVK_BENCH_OVERLAP", "0") == "1")
     # random-init weights (no checkpoint ships) with BatchNorm statistics calibrated on the first 256 clips
     # of the corpus, identically on every rank (model.calibrate_batchnorm explains why)
+    # The statistics come from a training-mode forward of the torch module: run on the HOST (torch-CPU, a few seconds,
+    # outside the timed region) so that this process never calls MIOpen -- the inference path is libsvk end to end.
     cal_pcm, _ = synth.corpus_device(256, dev, first_clip=0, utts_per_speaker=UTTS_PER_SPK)
-    _, cal = pipe.embed(cal_pcm, return_intermediates=True)
-    calibrate_batchnorm(pipe.model, torch.cat([d["cube"] for d in cal]))
+    _, cal_cubes = pipe.crops_and_cubes(cal_pcm)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, threads)))        # (every hardware thread of a 256-thread host is far slower)
+    cpu_model = seeded_model(2024, n_labels=1211)
+    calibrate_batchnorm(cpu_model, cal_cubes.cpu())
+    torch.set_num_threads(threads)
+    pipe.model.load_state_dict(cpu_model.state_dict())
     pipe.refresh_model()
-    del cal_pcm, cal
+    assert pipe.embedder.tail_in_libsvk() or os.environ.get("SVK_C3D2_CONV4") == "0" or os.environ.get("SVK_C3D2_TAIL") == "0" \
+        or not pipe.stage2_kernel
+    del cal_pcm, cal_cubes, cpu_model
     n_test = min(N_TEST, n_total)
     spk_all = (np.arange(n_total) // UTTS_PER_SPK).astype(np.int32)
     ids, last = enroll_last_utterance(None, spk_all[:n_test])                  # Q17: last utterance enrols
@@ -769,56 +811,69 @@ def main():
                              "full_clip_bytes_per_utt": 48000 * 2 + 297 * 40 * 4,
                              "share_of_step": float(fe_ms.sum()) / args.steps / ms_per_step}
         main_roofline = frontend_roofline
-        stage2_roofline = None
-        if kernel_events:
-            # the dominant hand-written kernel is now the network's first block (csrc/c3d2.hip): MFMA-bound.
-            # achieved = SURVEY 8(a)'s multiply-adds of conv1_1 + conv1_2 per cube x cubes per launch x 2 / the
-            # HIP-event duration of each launch inside the timed region (events on the launch stream)
-            s1_ms = np.array([ev[0].elapsed_time(ev[1]) for ev, _ in kernel_events])
-            s2_ms = np.array([ev[1].elapsed_time(ev[2]) for ev, _ in kernel_events])
-            cubes = np.array([n for _, n in kernel_events], dtype=np.float64)
-            tf1 = float((cubes * STAGE1_GFLOP_PER_UTT).sum() / s1_ms.sum())          # GFLOP / ms = TFLOP/s
-            tf2 = float((cubes * STAGE2_GFLOP_PER_UTT).sum() / s2_ms.sum())
-            # HBM bytes of this kernel from the committed PMC passes (bench.py --c3d2-only: 1 024 cubes per launch;
-            # FETCH_SIZE x 2 + WRITE_SIZE), scaled to the cubes per launch here: its traffic is linear in the cubes
-            wino = bool(getattr(pipe, "depth_transform", False))
-            t1, t1_src = pmc_traffic("c3d2_stage1w_kernel" if wino else "c3d2_stage1_kernel")
-            # MFMA work the kernel really issues per cube, in direct-form GFLOP: conv1_1 recomputes the depth halo per item
-            # (1.25 x) with K padded 15 -> 16; conv1_2 direct issues its products once, depth-transformed 2/3 of them on
-            # 40 rows for every 36 (five 8-row tiles)
-            conv12_issued = 143.327232 * (2.0 / 3.0) * (40.0 / 36.0) if wino else 143.327232
+        stage2_roofline, network_rows, issued_gflop_per_utt = None, None, None
+        wino = bool(getattr(pipe, "depth_transform", False))
+        if kernel_events and wino:
+            # Every network kernel, from HIP events on the launch stream around each launch of the timed region.
+            #   frac            = ISSUED matrix work / time / peak: MFMA wave-instructions per cube (the committed SQ_INSTS_MFMA
+            #                     counter; by construction when no profile has the kernel) x 2 048 FLOP x cubes -- a share of
+            #                     the matrix pipe's issue slots, <= 1 by definition;
+            #   algorithmic_frac = SURVEY 8(d)'s direct-form multiply-adds x 2 / time / peak: what the reference's sums would
+            #                     cost -- it exceeds `frac` (and may pass 1) where Winograd F(2,3) along depth issues 2/3 of them.
+            cubes_total = float(sum(sp["cubes"] for sp in kernel_events))
+            network_rows = {}
+            issued_gflop_per_utt = 0.0
+            covered_ms = 0.0
+            for name, symbols, mmac, mfma_design in NETWORK_KERNELS:
+                spans = [sp[name] for sp in kernel_events if name in sp]
+                if not spans:
+                    continue
+                ms = float(sum(a.elapsed_time(b) for a, b in spans))
+                mfma, src = 0.0, []
+                for sym in symbols:
+                    got, where = pmc_counter(sym, "SQ_INSTS_MFMA")
+                    src.append(where)
+                    mfma += got if got is not None else 0.0
+                if not all(src):
+                    mfma, src = float(mfma_design), ["by construction (no committed counter)"]
+                tf_issued = cubes_total * mfma * MFMA_FLOP / ms / 1e9
+                tf_alg = cubes_total * 2 * mmac * 1e6 / ms / 1e9
+                issued_gflop_per_utt += mfma * MFMA_FLOP / 1e9
+                covered_ms += ms
+                network_rows[name] = {
+                    "bound": "mfma", "achieved": tf_issued, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf_issued / F32_MATRIX_PEAK_TFLOPS, "algorithmic_tflops": tf_alg,
+                    "algorithmic_frac": tf_alg / F32_MATRIX_PEAK_TFLOPS, "kernel": " + ".join(symbols),
+                    "avg_launch_ms": ms / len(spans), "cubes_per_launch": cubes_total / len(spans),
+                    "mfma_per_cube": mfma, "mfma_per_cube_by_construction": mfma_design, "mfma_source": src[0],
+                    "direct_form_mmac_per_cube": mmac, "share_of_step": ms / args.steps / ms_per_step}
+            t1, t1_src = pmc_traffic("c3d2_stage1w_kernel")
+            r1 = network_rows["stage1"]
+            main_roofline = dict(r1)
+            main_roofline.update({
+                "traffic": None if t1 is None else t1 * r1["cubes_per_launch"] / 1024.0, "traffic_source": t1_src,
+                "traffic_note": "PMC pass: 1 024 cubes per launch, scaled by cubes_per_launch / 1024; algorithmic bytes per cube: "
+                                "47 520 (features, re-read 36 x from L2) + 663 552 written",
+                "kernel": "c3d2_stage1w_kernel (cube + conv1_1 + conv1_2 via Winograd F(2,3) along depth + pool1, "
+                          "v_mfma_f32_16x16x4_f32)",
+                "note": "frac = issued MFMA work (SQ_INSTS_MFMA per cube x 2 048 FLOP x cubes per launch) / HIP-event launch "
+                        "time / 157.3 TFLOP/s (MI355X_MICROARCH.md): the share of the f32 matrix pipe's issue slots.  "
+                        "algorithmic_frac counts SURVEY 8(d)'s direct-form multiply-adds (conv1_1 12.44 M + conv1_2 143.33 M per "
+                        "cube) instead and exceeds it because conv1_2 issues 2/3 of its products (x 40/36 rows, five 8-row "
+                        "tiles) while conv1_1 recomputes the depth halo (20 depths for 18) with K padded 15 -> 16"})
+            stage2_roofline = network_rows.get("stage2")
+            network_rows["_covered_share_of_step"] = covered_ms / args.steps / ms_per_step
+        elif kernel_events:
+            # direct-form kernels (SVK_C3D2_DEPTH_TRANSFORM=0): issued = algorithmic up to tile padding
+            spans = [sp["stage1"] for sp in kernel_events if "stage1" in sp]
+            ms = float(sum(a.elapsed_time(b) for a, b in spans))
+            cubes_total = float(sum(sp["cubes"] for sp in kernel_events))
+            tf1 = cubes_total * STAGE1_GFLOP_PER_UTT / ms
             main_roofline = {"bound": "mfma", "achieved": tf1, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tf1 / F32_MATRIX_PEAK_TFLOPS,
-                             "traffic": None if t1 is None else t1 * float(cubes.mean()) / 1024.0, "traffic_source": t1_src,
-                             "traffic_note": "PMC pass: 1 024 cubes per launch, scaled by cubes_per_launch / 1024; algorithmic "
-                                             "bytes per cube: 47 520 (features, re-read 36 x from L2) + 663 552 written",
-                             "kernel": ("c3d2_stage1w_kernel (cube + conv1_1 + conv1_2 via Winograd F(2,3) along depth + pool1, "
-                                        "v_mfma_f32_16x16x4_f32)") if wino else
-                                       "c3d2_stage1_kernel (cube + conv1_1 + conv1_2 + pool1, v_mfma_f32_16x16x4_f32)",
-                             "avg_launch_ms": float(s1_ms.mean()), "cubes_per_launch": float(cubes.mean()),
-                             "algorithmic_gflop_per_cube": STAGE1_GFLOP_PER_UTT,
-                             "issued_over_algorithmic": (conv12_issued + 12.4416 * 1.25 * 16 / 15) / (143.327232 + 12.4416),
-                             "mfma_pipe_frac": tf1 / F32_MATRIX_PEAK_TFLOPS
-                                               * (conv12_issued + 12.4416 * 1.25 * 16 / 15) / (143.327232 + 12.4416),
-                             "share_of_step": float(s1_ms.sum()) / args.steps / ms_per_step,
-                             "note": "achieved = SURVEY 8(d)'s direct-form multiply-adds (conv1_1 12.44 M + conv1_2 143.33 M per "
-                                     "cube) x 2 / launch time, against the f32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md). "
-                                     + ("conv1_2 runs as Winograd F(2,3) along depth: 4 MFMAs where the direct form issues 6, so "
-                                        "`frac` (algorithmic) exceeds the share of the matrix pipe's issue slots the kernel fills "
-                                        "(`mfma_pipe_frac` = frac x issued_over_algorithmic); SVK_C3D2_DEPTH_TRANSFORM=0 runs the "
-                                        "direct-form kernel" if wino else
-                                        "the kernel also issues 1.25 x 16/15 of conv1_1's products (depth halo recomputed per "
-                                        "item, K padded 15 -> 16)")}
-            # both kernels pad 15 output positions to a 16-row M tile; depth-transformed they issue 2/3 of the products
-            issued2 = (16.0 / 15.0) * (2.0 / 3.0 if wino else 1.0)
-            stage2_roofline = {"bound": "mfma", "achieved": tf2, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf2 / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
-                               "kernel": ("c3d2_conv21w_kernel + c3d2_conv22w_kernel (conv2_1, conv2_2 + pool2 via Winograd "
-                                          "F(2,3) along depth)") if wino else
-                                         "c3d2_conv21_kernel + c3d2_conv22_kernel (conv2_1, conv2_2 + pool2)",
-                               "avg_launch_ms": float(s2_ms.mean()), "algorithmic_gflop_per_cube": STAGE2_GFLOP_PER_UTT,
-                               "issued_over_algorithmic": issued2, "mfma_pipe_frac": tf2 / F32_MATRIX_PEAK_TFLOPS * issued2,
-                               "share_of_step": float(s2_ms.sum()) / args.steps / ms_per_step}
+                             "frac": tf1 / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                             "kernel": "c3d2_stage1_kernel (cube + conv1_1 + conv1_2 + pool1, direct form)",
+                             "avg_launch_ms": ms / len(spans), "cubes_per_launch": cubes_total / len(spans),
+                             "share_of_step": ms / args.steps / ms_per_step}
         result = {
             "metric": "utterances/sec (MFCC->embed->cosine)", "value": value, "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -844,14 +899,21 @@ def main():
             "roofline": main_roofline,
             "roofline_frontend": frontend_roofline,
             "roofline_stage2": stage2_roofline,
-            "roofline_e2e": {"bound": "mfma", "achieved": e2e_tflops, "peak": F32_MATRIX_PEAK_TFLOPS * world,
-                             "unit": "TFLOP/s", "frac": e2e_tflops / (F32_MATRIX_PEAK_TFLOPS * world),
+            "roofline_network": network_rows,
+            "roofline_e2e": {"bound": "mfma",
+                             "achieved": None if issued_gflop_per_utt is None else value * issued_gflop_per_utt / 1e3,
+                             "peak": F32_MATRIX_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                             "frac": None if issued_gflop_per_utt is None
+                             else value * issued_gflop_per_utt / 1e3 / (F32_MATRIX_PEAK_TFLOPS * world),
+                             "issued_gflop_per_utt": issued_gflop_per_utt,
+                             "algorithmic_tflops": e2e_tflops,
+                             "algorithmic_frac": e2e_tflops / (F32_MATRIX_PEAK_TFLOPS * world),
                              "gflop_per_utt": C3D2_GFLOP_PER_UTT,
-                             "note": "whole step vs the dense f32 matrix peak of the N GPUs: the C3D2 forward "
-                                     "(676.6 MFLOP per utterance: conv1_1 .. conv3_2 in libsvk MFMA kernels, conv4_1 .. FC5 "
-                                     "on PyTorch-ROCm / MIOpen) is ~95 % of the step; SURVEY 8(d) ceiling = 232 k utt/s "
-                                     "per GPU for the direct-form sums (conv1_2 .. conv3_2 -- 89 % of the multiply-adds -- "
-                                     "run through Winograd F(2,3) along depth and issue 2/3 of theirs)"},
+                             "note": "whole step vs the dense f32 matrix peak of the N GPUs.  frac = utterances/s x the MFMA work "
+                                     "the network kernels ISSUE per utterance (sum of the roofline_network rows: every layer "
+                                     "is a libsvk f32-MFMA kernel); algorithmic_frac = utterances/s x SURVEY 8(d)'s 676.6 MFLOP "
+                                     "of direct-form sums (ceiling 232 k utt/s per GPU) -- conv1_2 .. conv4_2 run through "
+                                     "Winograd F(2,3) along depth and issue 2/3 of theirs"},
             "eer": {"eer": eer, "auc": auc, "eer_device": eer_dev, "auc_device": auc_dev, "pairs": int(labels.size),
                     "short_clips": bad},
         }
@@ -892,11 +954,9 @@ def main():
             # sample: whole speakers from the start of the corpus (the last utterance of each enrols, Q17)
             ns = min(args.cpu_sample, n_local)
             sample = pcm[:ns]
-            emb, inter = pipe.embed(sample, return_intermediates=True)
-            crops = np.zeros((ns, c.CUBE_CROPS), dtype=np.int32)
-            for d in inter:
-                crops[d["lo"]:d["hi"]] = d["crop_idx"].cpu().numpy()
-            del inter
+            # the PRODUCTION path (libsvk kernels end to end) on the sample, and the crop starts it drew for the oracle
+            crops = pipe.crops_and_cubes(sample, want_cubes=False)
+            emb = pipe.embed(sample, crop_idx=crops)
             state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             rec, ref_emb = run_cpu_baseline(sample.cpu().numpy(), crops, state, not args.no_preemph, pipe.normalize,
                                             pipe.use_vad)

@@ -1,7 +1,8 @@
 """C3D2 speaker-embedding network: the PyTorch module (what checkpoints load into, what training uses, the
-parity oracle of the libsvk kernels) and `FusedEmbedder`, the inference path: since round 2 its first two
-blocks (conv1_1 .. pool2) run in libsvk (`svk_c3d2_stage1`, `svk_c3d2_stage2`: csrc/c3d2.hip), conv3_1 ..
-FC5 on PyTorch-ROCm with `svk_bias_prelu` behind each convolution.
+parity oracle of the libsvk kernels) and `FusedEmbedder`, the inference path: since round 3 every layer runs in
+libsvk (`svk_c3d2_stage1`, `svk_c3d2_stage2`, `svk_c3d2_conv31/32`: csrc/c3d2.hip; `svk_c3d2_conv41/42`, `svk_c3d2_fc5`:
+csrc/c3d2_tail.hip); the same layers on PyTorch-ROCm (MIOpen / hipBLASLt, `svk_bias_prelu` behind each convolution)
+remain as the A/B path behind the SVK_C3D2_* switches and for models whose layers are not C3D2's.
 
 Mirrors `/root/reference/model.py:104-191`: same constructor arguments, same
 sub-module names (so a reference-format checkpoint's `state_dict` loads
@@ -426,26 +427,37 @@ class FusedEmbedder:
         self._fc5 = (frag, self.fc_b.contiguous())
         return self._fc5
 
-    @torch.no_grad()
-    def tail_from_conv32(self, y, n):
-        """conv4_1 -> conv4_2 -> FC5 in libsvk from conv3_2's CHUNKED output [n][8][8][45][8] (csrc/c3d2_tail.hip)."""
-        y = self.fused_tail.c3d2_conv41(y, self.conv41_tables())
-        y = self.fused_tail.c3d2_conv42(y, self.conv42_tables())
-        return self.fused_tail.c3d2_fc5(y, self.fc5_tables())
+    def tail_in_libsvk(self):
+        """True when conv3_1 .. FC5 all have libsvk kernels for this model (then `from_stage2` calls no framework op)."""
+        return bool(self.fused_tail is not None and self.conv31_kernel and self.conv32_kernel and self.conv4_kernels
+                    and self.conv31_tables() is not None and self.conv32_tables() is not None
+                    and self.conv41_tables() is not None and self.conv42_tables() is not None
+                    and self.fc5_tables() is not None)
 
     @torch.no_grad()
-    def from_stage2(self, z, n):
-        """Embeddings from the output of `svk_c3d2_stage2`: the activation after pool2, [n][12][15][7][32].  conv3_1 runs
-        in libsvk too (`svk_c3d2_conv31`) when the engine is there and SVK_C3D2_CONV31 != 0."""
+    def tail_from_conv32(self, y, n, timed=None):
+        """conv4_1 -> conv4_2 -> FC5 in libsvk from conv3_2's CHUNKED output [n][8][8][45][8] (csrc/c3d2_tail.hip)."""
+        timed = timed or (lambda name, fn: fn())
+        y = timed("conv4_1", lambda: self.fused_tail.c3d2_conv41(y, self.conv41_tables()))
+        y2 = timed("conv4_2", lambda: self.fused_tail.c3d2_conv42(y, self.conv42_tables()))
+        return timed("fc5", lambda: self.fused_tail.c3d2_fc5(y2, self.fc5_tables()))
+
+    @torch.no_grad()
+    def from_stage2(self, z, n, timed=None):
+        """Embeddings from the output of `svk_c3d2_stage2`: the activation after pool2, [n][12][15][7][32].  conv3_1 ..
+        FC5 run in libsvk too when the engine is there (SVK_C3D2_CONV31 / CONV32 / CONV4 = 0 hand layers back to
+        PyTorch-ROCm).  `timed(name, fn)`: the pipeline's HIP-event hook around each kernel (bench.py)."""
         t31 = self.conv31_tables() if (self.fused_tail is not None and self.conv31_kernel and z.is_cuda) else None
         if t31 is not None:
-            y = self.fused_tail.c3d2_conv31(z.view(n, 12, 15, 7, 32), t31)
+            timed_ = timed or (lambda name, fn: fn())
+            y = timed_("conv3_1", lambda: self.fused_tail.c3d2_conv31(z.view(n, 12, 15, 7, 32), t31))
             t32 = self.conv32_tables() if self.conv32_kernel else None
             if t32 is not None:
                 if (self.conv4_kernels and self.conv41_tables() is not None and self.conv42_tables() is not None
                         and self.fc5_tables() is not None):
                     # the whole rest of the network in libsvk: conv3_2 writes the chunked layout conv4_1 stages from
-                    return self.tail_from_conv32(self.fused_tail.c3d2_conv32(y, t32, chunked=True), n)
+                    yc = timed_("conv3_2", lambda: self.fused_tail.c3d2_conv32(y, t32, chunked=True))
+                    return self.tail_from_conv32(yc, n, timed)
                 y = self.fused_tail.c3d2_conv32(y, t32)
                 x = y.view(n, 8, 9, 5, 64).permute(0, 4, 1, 2, 3)           # (n, 64, 8, 9, 5), channels_last_3d memory
                 return self._run(x, start=6)

@@ -5,8 +5,9 @@ This is the batched, device-resident form of what the reference does one
 utterance at a time on the host:
   vad.py:135-168  ->  load_data.py:50-87  ->  utils.py:351-397  ->
   model.py:141-170  ->  evaluation.py:67-84.
-Every stage is a libsvk.so kernel except the last four convolutions and FC5 of the C3D2
-forward (PyTorch-ROCm / MIOpen; the first two blocks are `svk_c3d2_stage1` / `svk_c3d2_stage2`).
+Every stage is a libsvk.so kernel, the C3D2 forward included (`svk_c3d2_stage1`, `svk_c3d2_stage2`,
+`svk_c3d2_conv31/32/41/42`, `svk_c3d2_fc5`); PyTorch-ROCm serves as device memory, streams and the
+module checkpoints load into (its own forward is the A/B path behind the SVK_C3D2_* switches).
 """
 import numpy as np
 import torch
@@ -46,7 +47,8 @@ class VerificationPipeline:
         # conv1_2 and conv2_1 through Winograd's F(2, 3) along depth (2 / 3 of the multiply-adds);
         # SVK_C3D2_DEPTH_TRANSFORM=0 = direct sums
         self.depth_transform = os.environ.get("SVK_C3D2_DEPTH_TRANSFORM", "1") != "0"
-        # bench.py sets this to a list: HIP events (on the launch stream) around the first- and second-block kernels
+        # bench.py sets this to a list: one {kernel name: (start, end) HIP events on the launch stream, "cubes": n} per
+        # micro-batch, around every network kernel
         self.kernel_events = None
         self.model = model.to(self.eng.device).eval()
         self.fused_model, self.channels_last = fused_model, channels_last
@@ -123,6 +125,25 @@ class VerificationPipeline:
     def cubes(self, feat, crop_idx):
         return self.eng.cube_gather(feat, crop_idx, c.CUBE_FRAMES)
 
+    def crops_and_cubes(self, pcm, first_utt=0, want_cubes=True):
+        """The crop starts `embed` would draw for `pcm` ([n, 20] int32 on the host) and, with `want_cubes`, the
+        20 x 80 x 40 cubes themselves ([n, 1, 20, 80, 40], device) -- VAD, front end, CMVN, crop draw and gather only, no
+        network: what BatchNorm calibration and the parity legs feed to the CPU oracle."""
+        pcm = self.eng.to_device(pcm)
+        crops, cubes = [], []
+        for lo, hi in self.chunks(pcm.shape[0]):
+            voiced, vlen = self.voiced(pcm[lo:hi])
+            feat, n_frames = self.features(voiced, vlen)
+            if self.crop_rng == "device":
+                idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo, self.bad_clips)
+            else:
+                idx = self.draw_crops(n_frames.to("cpu").numpy())
+            if want_cubes:
+                cubes.append(self.cubes(feat, idx))
+            crops.append(idx.cpu().numpy() if hasattr(idx, "cpu") else np.asarray(idx))
+        crops = np.concatenate(crops).astype(np.int32) if crops else np.zeros((0, c.CUBE_CROPS), np.int32)
+        return (crops, torch.cat(cubes)) if want_cubes else crops
+
     def _find_mode(self):
         import contextlib
 
@@ -154,18 +175,25 @@ class VerificationPipeline:
             if tables2 is not None:
                 # ... and conv2_1, conv2_2, pool2 in two more (conv3_1, conv3_2 follow inside from_stage2): PyTorch-ROCm
                 # runs conv4_1 .. FC5
-                rec = self.kernel_events is not None
-                if rec:
-                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-                    ev[0].record()
-                y = self.eng.c3d2_stage1(feat, crop_idx, tables, folded=False, crop_frames=c.CUBE_FRAMES,
-                                         depth_transform=self.depth_transform)
-                if rec:
-                    ev[1].record()
-                z = self.eng.c3d2_stage2(y, tables2, depth_transform=self.depth_transform)
-                if rec:
-                    ev[2].record()
-                    self.kernel_events.append((ev, feat.shape[0]))
+                spans = {"cubes": feat.shape[0]} if self.kernel_events is not None else None
+
+                def timed(name, fn):
+                    if spans is None:
+                        return fn()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    out = fn()
+                    b.record()
+                    spans[name] = (a, b)
+                    return out
+                y = timed("stage1", lambda: self.eng.c3d2_stage1(feat, crop_idx, tables, folded=False, crop_frames=c.CUBE_FRAMES,
+                                                                  depth_transform=self.depth_transform))
+                z = timed("stage2", lambda: self.eng.c3d2_stage2(y, tables2, depth_transform=self.depth_transform))
+                if spans is not None:
+                    self.kernel_events.append(spans)
+                if self.embedder.tail_in_libsvk():
+                    # conv3_1 .. FC5 are libsvk kernels too: nothing of the host framework runs, no MIOpen find to scope
+                    return self.embedder.from_stage2(z, feat.shape[0], timed)
                 with self._find_mode():
                     return self.embedder.from_stage2(z, feat.shape[0])
             folded = self.embedder.row_fold is not None

@@ -22,13 +22,15 @@ OURS = ("frontend_kernel", "cmvn_kernel", "vad_kernel", "cube_gather_kernel", "c
         "inv_norm_kernel", "draw_crops_kernel", "cube_windows_kernel", "cube_windows_c3d2_kernel", "decimate_kernel", "resample_kernel",
         "c3d2_stage1w_kernel", "c3d2_stage1_kernel", "c3d2_conv21w_kernel", "c3d2_conv22w_kernel", "c3d2_conv31w_kernel", "c3d2_conv32w_kernel", "c3d2_conv21_kernel",
         "c3d2_conv22_kernel", "bias_prelu_kernel", "cmvnw_kernel", "spectrum_pow2_kernel",
-        "spectrum_dft_kernel", "spectrum_fft_kernel", "mel_features_kernel")
+        "spectrum_dft_kernel", "spectrum_fft_kernel", "mel_features_kernel", "c3d2_tail_kernel", "fc5_reduce_kernel", "fc5_kernel")
 
 
 def short(name):
     for k in OURS:
         if k in name:
             extra = ""
+            if k == "c3d2_tail_kernel":
+                extra = "<Conv41>" if "Conv41" in name else "<Conv42>"
             if "frontend_kernel" in name:
                 extra = "<int16,nfft1024>" if "<short, true" in name else "<int16,nfft512>" if "<short, false" in name \
                     else "<f32,nfft1024>" if "<float, true" in name else "<f32,nfft512>"
