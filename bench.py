@@ -64,7 +64,7 @@ NETWORK_KERNELS = (
     ("stage2", ("c3d2_conv21w_kernel", "c3d2_conv22w_kernel"), 46.44864 + 66.3552, 32256 + 43008),
     ("conv3_1", ("c3d2_conv31w_kernel",), 13.824, 9600),
     ("conv3_2", ("c3d2_conv32w_kernel",), 30.96576, 21504),
-    ("conv4_1", ("c3d2_tail_kernel<Conv41>",), 11.943936, 15552),
+    ("conv4_1", ("c3d2_tail_kernel<Conv41>",), 11.943936, 7776),            # 9 items x 4 phases x 24 steps x 18 x 8 waves / 16 cubes
     ("conv4_2", ("c3d2_tail_kernel<Conv42>",), 12.386304, 8064),
     ("fc5", ("fc5_kernel",), 0.589824, 144),
 )
@@ -89,6 +89,7 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel side benches (profiling runs)")
     ap.add_argument("--frontend-only", action="store_true", help="time BASELINE config 2 only (for rocprof)")
     ap.add_argument("--stages-only", action="store_true", help="time the stage-level kernels only (for rocprof)")
+    ap.add_argument("--ragged-only", action="store_true", help="the realistic-length workload only (4 .. 145 s clips)")
     ap.add_argument("--c3d2-only", action="store_true",
                     help="features of 1 024 clips once, then the network (seven libsvk kernels) K times (for rocprof --pmc)")
     ap.add_argument("--backend", default=os.environ.get("SVK_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
@@ -449,6 +450,77 @@ def ingest_bench(eng, torch, reps=10, n_clips=1024):
                          "bytes_per_utt": 480000}}
 
 
+def ragged_lengths(n, seed=7):
+    """VoxCeleb1-like utterance lengths in samples (README.md:4-7 / SURVEY 8f-2: 4 .. 145 s, median ~ 7-8 s):
+    4 s + a log-normal tail, clipped at 145 s, seeded."""
+    rng = np.random.default_rng(seed)
+    sec = np.minimum(4.0 + rng.lognormal(mean=np.log(3.2), sigma=0.85, size=n), 145.0)
+    sec[0], sec[1] = 145.0, 4.0                                  # both ends of the range are always present
+    return (sec * 16000).astype(np.int64)
+
+
+def ragged_bench(pipe, eng, torch, n_clips=2048, reps=3):
+    """The realistic-length workload (/root/reference/load_data.py:23-53 reads whole VoxCeleb files,
+    utils.py:170-173): `n_clips` clips of 4 .. 145 s through `embed_ragged_resident` (audio already in HBM, addressed by
+    offsets) and `embed_ragged` (a list of host arrays: packed per batch and uploaded).  The network costs the same per
+    clip whatever its length (20 crops of 80 frames); VAD + front end + CMVN scale with the audio -- their share of the
+    step is reported from HIP events."""
+    from speaker_verification_amd import synth
+    dev = eng.device
+    lens = ragged_lengths(n_clips)
+    slots = (lens + 7) // 8 * 8
+    offs = np.concatenate([[0], np.cumsum(slots)[:-1]]).astype(np.int64)
+    total = int(slots.sum())
+    # clip k = consecutive 3 s device clips of ONE synthetic speaker, cut to its length (speech bursts with gaps throughout)
+    base, _ = synth.corpus_device(1024, dev, first_clip=0, utts_per_speaker=UTTS_PER_SPK)
+    flat = base.reshape(-1)
+    buf = torch.zeros((total,), dtype=torch.int16, device=dev)
+    rng = np.random.default_rng(11)
+    for k in range(n_clips):
+        start = int(rng.integers(0, 1024 - 49)) * synth.CLIP_SAMPLES     # 49 segments cover 145 s
+        buf[offs[k]:offs[k] + lens[k]] = flat[start:start + int(lens[k])]
+    del base, flat
+    saved_mb = pipe.micro_batch
+    pipe.micro_batch = 1024
+    try:
+        emb = pipe.embed_ragged_resident(buf, offs, lens)                 # warm
+        torch.cuda.synchronize()
+        times, shares = [], []
+        for _ in range(reps):
+            spans = []
+            t0 = time.perf_counter()
+            emb = pipe.embed_ragged_resident(buf, offs, lens, spans=spans)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            front = sum(a.elapsed_time(b) for name, a, b in spans if name == "front")
+            net = sum(a.elapsed_time(b) for name, a, b in spans if name == "network")
+            shares.append((front, net))
+        t_res = float(np.median(times))
+        front_ms, net_ms = (float(np.median([x[i] for x in shares])) for i in (0, 1))
+        host_buf = buf.cpu().numpy()
+        clips = [host_buf[offs[k]:offs[k] + lens[k]] for k in range(n_clips)]
+        pipe.embed_ragged(clips[:64])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        emb_h = pipe.embed_ragged(clips)
+        torch.cuda.synchronize()
+        t_host = time.perf_counter() - t0
+        same = float((emb_h - emb).abs().max().item())
+    finally:
+        pipe.micro_batch = saved_mb
+    audio_s = float(lens.sum()) / 16000.0
+    return {"workload": "%d clips of 4 .. 145 s (seeded log-normal lengths: median %.1f s, mean %.1f s, %.0f s of audio, %.0f MB "
+                        "of int16 PCM), energy VAD -> lmfe -> CMVN -> crops -> C3D2, batches sorted by length"
+                        % (n_clips, float(np.median(lens)) / 16000, audio_s / n_clips, audio_s, total * 2 / 1e6),
+            "resident": {"utt_per_s": n_clips / t_res, "audio_seconds_per_s": audio_s / t_res, "ms": t_res * 1e3,
+                         "front_end_ms": front_ms, "network_ms": net_ms,
+                         "front_end_share": front_ms / max(front_ms + net_ms, 1e-9)},
+            "host_fed": {"utt_per_s": n_clips / t_host, "audio_seconds_per_s": audio_s / t_host, "ms": t_host * 1e3,
+                         "note": "a list of host NumPy clips: packed per batch into one array, uploaded (pageable), same kernels"},
+            "max_abs_diff_host_vs_resident": same, "short_clips": int(pipe.bad_clips.item()),
+            "fixed_3s_front_end_share_for_comparison": None}
+
+
 # --------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle ("port") in a fresh child process that never touches the GPU
 # --------------------------------------------------------------------------------------------------
@@ -680,6 +752,11 @@ def main():
                           "cosine_mfma": cosine_mfma_bench(eng, torch)}))
         return 0
 
+    if args.ragged_only:
+        pipe = VerificationPipeline(seeded_model(2024, n_labels=1211), use_vad=not args.no_vad, normalize=not args.no_cmvn,
+                                    preemph_cof=None if args.no_preemph else 0.98, crop_rng="device", micro_batch=1024)
+        print(json.dumps(ragged_bench(pipe, eng, torch)))
+        return 0
     if args.c3d2_only:
         pcm, _ = synth.corpus_device(1024, dev, first_clip=0, utts_per_speaker=UTTS_PER_SPK)
         pipe = VerificationPipeline(seeded_model(2024, n_labels=1211), use_vad=not args.no_vad, normalize=not args.no_cmvn,
@@ -825,10 +902,10 @@ def main():
             issued_gflop_per_utt = 0.0
             covered_ms = 0.0
             for name, symbols, mmac, mfma_design in NETWORK_KERNELS:
-                spans = [sp[name] for sp in kernel_events if name in sp]
-                if not spans:
+                evs = [sp[name] for sp in kernel_events if name in sp]
+                if not evs:
                     continue
-                ms = float(sum(a.elapsed_time(b) for a, b in spans))
+                ms = float(sum(a.elapsed_time(b) for a, b in evs))
                 mfma, src = 0.0, []
                 for sym in symbols:
                     got, where = pmc_counter(sym, "SQ_INSTS_MFMA")
@@ -844,7 +921,7 @@ def main():
                     "bound": "mfma", "achieved": tf_issued, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": tf_issued / F32_MATRIX_PEAK_TFLOPS, "algorithmic_tflops": tf_alg,
                     "algorithmic_frac": tf_alg / F32_MATRIX_PEAK_TFLOPS, "kernel": " + ".join(symbols),
-                    "avg_launch_ms": ms / len(spans), "cubes_per_launch": cubes_total / len(spans),
+                    "avg_launch_ms": ms / len(evs), "cubes_per_launch": cubes_total / len(evs),
                     "mfma_per_cube": mfma, "mfma_per_cube_by_construction": mfma_design, "mfma_source": src[0],
                     "direct_form_mmac_per_cube": mmac, "share_of_step": ms / args.steps / ms_per_step}
             t1, t1_src = pmc_traffic("c3d2_stage1w_kernel")
@@ -865,14 +942,14 @@ def main():
             network_rows["_covered_share_of_step"] = covered_ms / args.steps / ms_per_step
         elif kernel_events:
             # direct-form kernels (SVK_C3D2_DEPTH_TRANSFORM=0): issued = algorithmic up to tile padding
-            spans = [sp["stage1"] for sp in kernel_events if "stage1" in sp]
-            ms = float(sum(a.elapsed_time(b) for a, b in spans))
+            evs = [sp["stage1"] for sp in kernel_events if "stage1" in sp]
+            ms = float(sum(a.elapsed_time(b) for a, b in evs))
             cubes_total = float(sum(sp["cubes"] for sp in kernel_events))
             tf1 = cubes_total * STAGE1_GFLOP_PER_UTT / ms
             main_roofline = {"bound": "mfma", "achieved": tf1, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf1 / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
                              "kernel": "c3d2_stage1_kernel (cube + conv1_1 + conv1_2 + pool1, direct form)",
-                             "avg_launch_ms": ms / len(spans), "cubes_per_launch": cubes_total / len(spans),
+                             "avg_launch_ms": ms / len(evs), "cubes_per_launch": cubes_total / len(evs),
                              "share_of_step": ms / args.steps / ms_per_step}
         result = {
             "metric": "utterances/sec (MFCC->embed->cosine)", "value": value, "unit": "utterances/s",
@@ -950,6 +1027,10 @@ def main():
         result["cosine_mfma"] = cosine_mfma_bench(eng, torch)
         result["stage_kernels"] = stage_kernels_bench(eng, torch)
         result["ingest_resample"] = ingest_bench(eng, torch)
+        result["ragged"] = ragged_bench(pipe, eng, torch)
+        mb = result["micro_batch_breakdown"]["stages"]
+        result["ragged"]["fixed_3s_front_end_share_for_comparison"] = float(
+            sum(v["share"] for k, v in mb.items() if not k.startswith(("cube", "cosine"))))
         if args.cpu_sample > 0:
             # sample: whole speakers from the start of the corpus (the last utterance of each enrols, Q17)
             ns = min(args.cpu_sample, n_local)

@@ -335,7 +335,7 @@ class Engine:
         return power
 
     def vad_energy(self, pcm, threshold, fs=16000, frame_ms=30, padding_ms=300, lengths=None, compact=True,
-                   want_segments=False, frame_samples=None, ring_len=None, offsets=None):
+                   want_segments=False, frame_samples=None, ring_len=None, offsets=None, voiced_out=None):
         """pcm [n_utt, L] int16 (or, with `offsets` + `lengths`, a 1-D concatenation of ragged clips) ->
         dict(keep [n, F] u8, n_vad_frames [n] i32, voiced (same layout as pcm; a clip's samples past its
         voiced_len are unspecified) i16, voiced_len [n] i32, seg [n, F] i32)."""
@@ -363,7 +363,14 @@ class Engine:
         keep = torch.empty((n_utt, max_vf), dtype=torch.uint8, device=self.device)
         nvf = torch.empty((n_utt,), dtype=torch.int32, device=self.device)
         seg = torch.empty((n_utt, max_vf), dtype=torch.int32, device=self.device) if want_segments else None
-        voiced = torch.empty_like(x) if compact else None      # only [:voiced_len] of a clip is defined (no 98 MB memset)
+        # only [:voiced_len] of a clip is defined (no 98 MB memset); `voiced_out`: a caller-owned buffer of pcm's shape,
+        # reused across batches that address ONE resident concatenation through offsets
+        if compact and voiced_out is not None:
+            if voiced_out.shape != x.shape or voiced_out.dtype != torch.int16 or not voiced_out.is_contiguous():
+                raise ValueError("voiced_out must be a contiguous int16 tensor of pcm's shape")
+            voiced = voiced_out
+        else:
+            voiced = torch.empty_like(x) if compact else None
         vlen = torch.empty((n_utt,), dtype=torch.int32, device=self.device) if compact else None
         self._stream()
         check(self.lib.svk_vad_energy(self.ctx, self._ptr(x), self._ptr(offs), self._ptr(lens), stride, longest, n_utt,

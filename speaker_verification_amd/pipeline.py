@@ -290,26 +290,63 @@ class VerificationPipeline:
         side.wait_stream(main)
         return emb
 
-    def embed_ragged(self, clips, max_batch_samples=64 * 1024 * 1024, first_utt=0):
-        """Clips of DIFFERENT lengths (VoxCeleb1 utterances run from 4 to 145 s): `clips` is a list of 1-D
-        int16 arrays.  They are sorted by length, packed back to back (16-byte aligned) into batches of
-        at most `max_batch_samples` samples and `micro_batch` clips, and addressed through the
-        offsets / lengths form of the C-ABI, so a batch costs its own samples, not n x the longest
-        clip.  Embeddings come back in the order of `clips`.  Needs crop_rng='device'."""
-        if self.crop_rng != "device":
-            raise ValueError("embed_ragged needs crop_rng='device'")
-        order = sorted(range(len(clips)), key=lambda k: len(clips[k]))
-        emb = torch.empty((len(clips), 128), dtype=torch.float32, device=self.eng.device)
+    def _ragged_batches(self, lengths, max_batch_samples):
+        """Clip indices sorted by length and cut into batches of at most `micro_batch` clips and `max_batch_samples`
+        samples (16-byte-aligned clip slots): a batch costs its own samples, not n x the longest clip."""
+        order = sorted(range(len(lengths)), key=lambda k: int(lengths[k]))
         pos = 0
         while pos < len(order):
             batch, total = [], 0
             while pos < len(order) and len(batch) < self.micro_batch:
-                n = (len(clips[order[pos]]) + 7) // 8 * 8
+                n = (int(lengths[order[pos]]) + 7) // 8 * 8
                 if batch and total + n > max_batch_samples:
                     break
                 batch.append(order[pos])
                 total += n
                 pos += 1
+            yield batch, total
+
+    def _embed_ragged_batch(self, dev_buf, offs, lens, rows, first_utt, voiced_out=None, spans=None):
+        """One batch of clips addressed through offsets / lengths into `dev_buf` -> their embeddings (rows = the clips'
+        indices in the caller's list: they key the crop draw)."""
+        def timed(name, fn):
+            if spans is None:
+                return fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn()
+            b.record()
+            spans.append((name, a, b))
+            return out
+
+        def front():
+            buf, dev_lens = dev_buf, lens
+            if self.use_vad:
+                res = self.eng.vad_energy(dev_buf, self.vad_threshold, fs=c.SAMPLE_RATE, frame_ms=c.VAD_FRAME_MS,
+                                          padding_ms=c.VAD_PADDING_MS, lengths=lens, offsets=offs, compact=True,
+                                          voiced_out=voiced_out)
+                buf, dev_lens = res["voiced"], res["voiced_len"]
+            feat, n_frames, _ = self.eng.features(buf, self.spec, lengths=dev_lens, offsets=offs,
+                                                  max_frames=self.spec.num_frames(int(np.max(lens))))
+            if self.normalize:
+                self.eng.cmvn_(feat, n_frames, variance=True)
+            # the crop draw is keyed by the clip's index in the caller's list, whatever batch it landed in
+            idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, 0, self.bad_clips,
+                                      utt_index=rows + first_utt)
+            return feat, idx
+        feat, idx = timed("front", front)
+        return timed("network", lambda: self.embed_features(feat, idx))
+
+    def embed_ragged(self, clips, max_batch_samples=64 * 1024 * 1024, first_utt=0, spans=None):
+        """Clips of DIFFERENT lengths (VoxCeleb1 utterances run from 4 to 145 s): `clips` is a list of 1-D
+        int16 arrays on the HOST.  They are sorted by length, packed back to back (16-byte aligned) into batches of
+        at most `max_batch_samples` samples and `micro_batch` clips, uploaded, and addressed through the
+        offsets / lengths form of the C-ABI.  Embeddings come back in the order of `clips`.  Needs crop_rng='device'.
+        `spans`: a list that receives ("front" | "network", start, end) HIP events per batch (bench.py)."""
+        if self.crop_rng != "device":
+            raise ValueError("embed_ragged needs crop_rng='device'")
+        emb = torch.empty((len(clips), 128), dtype=torch.float32, device=self.eng.device)
+        for batch, total in self._ragged_batches([len(x) for x in clips], max_batch_samples):
             buf = np.zeros((total,), dtype=np.int16)
             offs, lens, at = [], [], 0
             for k in batch:
@@ -318,24 +355,33 @@ class VerificationPipeline:
                 offs.append(at)
                 lens.append(x.size)
                 at += (x.size + 7) // 8 * 8
-            offs = np.asarray(offs, dtype=np.int64)
-            lens = np.asarray(lens, dtype=np.int32)
-            dev_buf = self.eng.to_device(buf)
-            if self.use_vad:
-                res = self.eng.vad_energy(dev_buf, self.vad_threshold, fs=c.SAMPLE_RATE, frame_ms=c.VAD_FRAME_MS,
-                                          padding_ms=c.VAD_PADDING_MS, lengths=lens, offsets=offs, compact=True)
-                dev_buf, dev_lens = res["voiced"], res["voiced_len"]
-            else:
-                dev_lens = lens
-            feat, n_frames, _ = self.eng.features(dev_buf, self.spec, lengths=dev_lens, offsets=offs,
-                                                  max_frames=self.spec.num_frames(int(lens.max())))
-            if self.normalize:
-                self.eng.cmvn_(feat, n_frames, variance=True)
             rows = torch.as_tensor(np.asarray(batch, dtype=np.int64), device=self.eng.device)
-            # the crop draw is keyed by the clip's index in `clips`, whatever batch it landed in
-            idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, 0, self.bad_clips,
-                                      utt_index=rows + first_utt)
-            emb[rows] = self.embed_features(feat, idx)
+            emb[rows] = self._embed_ragged_batch(self.eng.to_device(buf), np.asarray(offs, dtype=np.int64),
+                                                 np.asarray(lens, dtype=np.int32), rows, first_utt, spans=spans)
+        return emb
+
+    def embed_ragged_resident(self, buf, offsets, lengths, max_batch_samples=64 * 1024 * 1024, first_utt=0, spans=None):
+        """`embed_ragged` for audio that is ALREADY in HBM: `buf` is one 1-D int16 device tensor holding every clip,
+        clip k at samples [offsets[k], offsets[k] + lengths[k]) (offsets multiples of 8: 16-byte aligned; host arrays).
+        Batches are lists of clip indices into that one buffer -- nothing is copied or packed; the VAD writes its voiced
+        samples into one scratch buffer of the same shape, reused by every batch."""
+        if self.crop_rng != "device":
+            raise ValueError("embed_ragged_resident needs crop_rng='device'")
+        offsets = np.asarray(offsets, dtype=np.int64)
+        lengths = np.asarray(lengths, dtype=np.int32)
+        if offsets.shape != lengths.shape or (offsets % 8).any():
+            raise ValueError("offsets / lengths must have one entry per clip, offsets multiples of 8 samples")
+        buf = self.eng.to_device(buf)
+        if buf.dim() != 1 or buf.dtype != torch.int16:
+            raise ValueError("buf must be a 1-D int16 tensor")
+        if len(lengths) and int((offsets + lengths).max()) > buf.numel():
+            raise ValueError("a clip reaches past the end of buf")
+        emb = torch.empty((len(lengths), 128), dtype=torch.float32, device=self.eng.device)
+        voiced = torch.empty_like(buf) if self.use_vad else None
+        for batch, _ in self._ragged_batches(lengths, max_batch_samples):
+            rows = torch.as_tensor(np.asarray(batch, dtype=np.int64), device=self.eng.device)
+            emb[rows] = self._embed_ragged_batch(buf, offsets[batch], lengths[batch], rows, first_utt, voiced_out=voiced,
+                                                 spans=spans)
         return emb
 
     def embed_host(self, pcm_host, first_utt=0):
