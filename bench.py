@@ -66,7 +66,7 @@ NETWORK_KERNELS = (
     ("conv3_2", ("c3d2_conv32w_kernel",), 30.96576, 21504),
     ("conv4_1", ("c3d2_tail_kernel<Conv41>",), 11.943936, 7776),            # 9 items x 4 phases x 24 steps x 18 x 8 waves / 16 cubes
     ("conv4_2", ("c3d2_tail_kernel<Conv42>",), 12.386304, 8064),
-    ("fc5", ("fc5_kernel",), 0.589824, 144),
+    ("fc5", ("fc5_kernel",), 0.589824, 576),                                   # 4 K ranges x 72 steps x 16 x 8 waves / 64 cubes
 )
 N_CORPUS = 148642                # VoxCeleb1 dev utterances (README.md:5-7) = BASELINE configs[4]
 N_TEST, N_TEST_SPK = 4874, 40    # VoxCeleb1 verification split (README.md:4-7)
@@ -902,6 +902,12 @@ def main():
             issued_gflop_per_utt = 0.0
             covered_ms = 0.0
             for name, symbols, mmac, mfma_design in NETWORK_KERNELS:
+                if name == "stage1" and getattr(pipe, "stage1_t_planes", False):
+                    # the t-plane experiment: 72 items x (240 conv1_1 + 9 x 144 conv1_2) MFMAs per cube
+                    symbols, mfma_design = ("c3d2_stage1t_kernel",), 72 * (240 + 9 * 144)
+                elif name == "stage1" and getattr(pipe, "stage1_merged", False):
+                    # round 3: 36 items x (400 conv1_1 + 18 tiles x 144 conv1_2): the remainder rows of two depth pairs share a tile
+                    symbols, mfma_design = ("c3d2_stage1w_kernel<merged>",), 36 * (400 + 18 * 144)
                 evs = [sp[name] for sp in kernel_events if name in sp]
                 if not evs:
                     continue
@@ -924,20 +930,21 @@ def main():
                     "avg_launch_ms": ms / len(evs), "cubes_per_launch": cubes_total / len(evs),
                     "mfma_per_cube": mfma, "mfma_per_cube_by_construction": mfma_design, "mfma_source": src[0],
                     "direct_form_mmac_per_cube": mmac, "share_of_step": ms / args.steps / ms_per_step}
-            t1, t1_src = pmc_traffic("c3d2_stage1w_kernel")
             r1 = network_rows["stage1"]
+            t1, t1_src = pmc_traffic(r1["kernel"])
             main_roofline = dict(r1)
             main_roofline.update({
                 "traffic": None if t1 is None else t1 * r1["cubes_per_launch"] / 1024.0, "traffic_source": t1_src,
                 "traffic_note": "PMC pass: 1 024 cubes per launch, scaled by cubes_per_launch / 1024; algorithmic bytes per cube: "
                                 "47 520 (features, re-read 36 x from L2) + 663 552 written",
-                "kernel": "c3d2_stage1w_kernel (cube + conv1_1 + conv1_2 via Winograd F(2,3) along depth + pool1, "
+                "kernel": r1["kernel"] + " (cube + conv1_1 + conv1_2 via Winograd F(2,3) along depth + pool1, "
                           "v_mfma_f32_16x16x4_f32)",
                 "note": "frac = issued MFMA work (SQ_INSTS_MFMA per cube x 2 048 FLOP x cubes per launch) / HIP-event launch "
                         "time / 157.3 TFLOP/s (MI355X_MICROARCH.md): the share of the f32 matrix pipe's issue slots.  "
                         "algorithmic_frac counts SURVEY 8(d)'s direct-form multiply-adds (conv1_1 12.44 M + conv1_2 143.33 M per "
-                        "cube) instead and exceeds it because conv1_2 issues 2/3 of its products (x 40/36 rows, five 8-row "
-                        "tiles) while conv1_1 recomputes the depth halo (20 depths for 18) with K padded 15 -> 16"})
+                        "cube) instead and exceeds it because conv1_2 issues 2/3 of its products while conv1_1 recomputes the "
+                        "depth halo per item (24 depths for 18 in the t-plane form, 20 in the round-2 form, which also issues "
+                        "40 rows of conv1_2 for every 36) with K padded 15 -> 16"})
             stage2_roofline = network_rows.get("stage2")
             network_rows["_covered_share_of_step"] = covered_ms / args.steps / ms_per_step
         elif kernel_events:

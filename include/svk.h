@@ -249,7 +249,9 @@ int svk_roc_eer(svk_ctx* ctx, const float* d_scores, const uint8_t* d_labels, in
  * `folded` bit 1 (value 2) = the caller asserts every PReLU slope lies in [0, 1] (then prelu(v) = max(v, slope v): two
  * instructions per value instead of four); bit 2 (value 4) = conv1_2 through Winograd's F(2, 3) along depth (every
  * C3D2 kernel is 3 taps deep: 2 / 3 of the multiply-adds; the transformed weights are derived in the kernel from the
- * same d_w2frag; the same sums in another association, ~1e-6 relative from the direct form); bit 0 picks the layout:
+ * same d_w2frag; the same sums in another association, ~1e-6 relative from the direct form); bit 3 (value 8) = the same
+ * transform with its input side applied ONCE, where conv1_1's output is produced (c3d2_stage1t_kernel: t planes in LDS,
+ * no vector work in conv1_2's loop; needs d_feat 16-byte aligned; takes precedence over bit 2); bit 0 picks the layout:
  *   folded = 0: [n_utt][16 d][36 h][18 w][16 c]
  *   folded = 1: [n_utt][16 d][18 h/2][18 w][2 (h & 1)][16 c]   (= a (n, 32, 16, 18, 18) channels-last tensor:
  *               the row-parity-in-channels form model.FusedEmbedder feeds conv2_1 / conv2_2)

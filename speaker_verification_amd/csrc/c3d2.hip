@@ -355,11 +355,47 @@ __device__ __forceinline__ void wino_input_pair(const f32x4 (&x)[4], int hf, f32
   t[3][hf] = pk_sub(xh[1], xh[3]);
 }
 
-template <bool SLOPE01>
+// One (merged tile, k) unit of the MERGE variant below: accumulator a_k of the tile made of rows 32 .. 35 of the depth pairs
+// 2 m and 2 m + 1 (lanes 0 .. 7 / 8 .. 15), k a compile-time constant: t_k needs two of the four depth planes -- two
+// ds_read_b128, two packed adds and four MFMAs per row tap.
+template <int K>
+__device__ __forceinline__ f32x4 stage1w_merged_unit(const float* const (&pbm)[5], const f32x4 (&G)[36]) {
+  constexpr int DA = K == 0 ? 0 : K == 2 ? 2 : 1, DB = K == 0 ? 2 : K == 1 ? 2 : K == 2 ? 1 : 3;   // t_K = x[DA] -/+ x[DB]
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;   // two chains: a dependent MFMA would wait 40 cycles for its predecessor
+  f32x4 xa = *reinterpret_cast<const f32x4*>(pbm[0] + 160 * WPIXF * DA), xb = *reinterpret_cast<const f32x4*>(pbm[0] + 160 * WPIXF * DB);
+#pragma unroll
+  for (int kh = 0; kh < 9; ++kh) {
+    const f32x2 alo = __builtin_shufflevector(xa, xa, 0, 1), ahi = __builtin_shufflevector(xa, xa, 2, 3);
+    const f32x2 blo = __builtin_shufflevector(xb, xb, 0, 1), bhi = __builtin_shufflevector(xb, xb, 2, 3);
+    const f32x2 tlo = K == 1 ? pk_add(alo, blo) : pk_sub(alo, blo), thi = K == 1 ? pk_add(ahi, bhi) : pk_sub(ahi, bhi);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kh + 1 < 9) {
+      const int off = 32 * (kh + 1) + 4 * ((kh + 1) >> 1);
+      xa = *reinterpret_cast<const f32x4*>(pbm[(kh + 1) >> 1] + 160 * WPIXF * DA + off);
+      xb = *reinterpret_cast<const f32x4*>(pbm[(kh + 1) >> 1] + 160 * WPIXF * DB + off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(tlo[0], G[9 * K + kh][0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tlo[1], G[9 * K + kh][1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(thi[0], G[9 * K + kh][2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(thi[1], G[9 * K + kh][3], acc1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc0 + acc1;
+}
+
+// MERGE (round 3, the default): 36 output rows are four 8-row tiles + 4 rows.  The round-2 kernel covered the remainder
+// with a fifth tile that repeated rows 28 .. 31 (40 rows issued for every 36: 720 MFMAs per SIMD and item); here the
+// remainders of two depth pairs make ONE tile (lanes 0 .. 7: pair 2 m, lanes 8 .. 15: pair 2 m + 1), and the two merged
+// tiles of an item are cut by accumulator into eight (tile m, k) units of 36 MFMAs, one per wave: every wave issues two
+// full tiles + one unit = 324 MFMAs (648 per SIMD, - 10 %), the units' accumulators meet in 8 KB of LDS and waves 0 and 4
+// finish the two tiles behind the item's last barrier.  The sums are those of the round-2 kernel, in the same order.
+template <bool SLOPE01, bool MERGE>
 __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem_c3d2[];
   float* act = smem_c3d2;               // [WACT_FLOATS]
   float* patch = act + WACT_FLOATS;     // [P_FLOATS]
+  float* const exch = patch + P_FLOATS; // MERGE: [2 m][4 k][64 lanes] f32x4
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: a scalar
   const int i = lane & 15, kk = lane >> 4;
   const int pair = wave & 3, part = wave >> 2;
@@ -458,8 +494,9 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       // (the SIMD's two waves do not share its issue slots evenly -- the older one, part 0, gets about two in three, and
       // s_setprio changes nothing, measured -- but the younger one fills what the older leaves: the phase lasts the SUM
       // of both waves' MFMA + VALU time whichever way the five tiles are split, so 3 + 2 it is)
-      const int tl0 = part ? 3 : 0, tl1 = part ? 5 : 3;
-      const int fetch_tl = part ? 4 : 0;
+      // MERGE: full tiles at rows 16 part, 16 part + 8 (tl = 2 part, 2 part + 1)
+      const int tl0 = MERGE ? 2 * part : (part ? 3 : 0), tl1 = MERGE ? 2 * part + 2 : (part ? 5 : 3);
+      const int fetch_tl = MERGE ? 3 * part : (part ? 4 : 0);
 #pragma unroll 1
       for (int tl = tl0; tl < tl1; ++tl) {
         // the next item's patch: twelve scattered 8-byte loads per row take the CU's address path ~2 000 cycles to accept;
@@ -511,7 +548,7 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
           __builtin_amdgcn_sched_barrier(0);
         }
         // rows 4 kk + r of the tile: output row h0 + 2 kk + (r >> 1), column r & 1: pool = max over r pairs
-        if (tl < 4 || kk >= 2) {
+        if (MERGE || tl < 4 || kk >= 2) {
           const f32x4 y0 = acc[0] + acc[1] + acc[2] + b2, y1 = acc[1] - acc[2] - acc[3] + b2;
           float* const o00 = obase + (int64_t)(h0 / 2) * p.s_hp;
           float* const o01 = o00 + p.s_par;
@@ -524,11 +561,46 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
         }
       }
     }
+    if (MERGE) {
+      // this wave's (merged tile m = part, k = pair) unit
+      int lane_m = lane;
+      asm volatile("" : "+v"(lane_m));   // (as in the finish block below)
+      const int i_m = lane_m & 15;
+      const int hlm = (i_m >> 1) & 3, wcm = i_m & 1;
+      const float* const mbase = act + 2 * (160 * WPIXF) * (2 * part + (i_m >> 3)) + 68 * hlm + 16 * wcm + 4 * (lane_m >> 4) + 72 * 32;
+      const float* pbm[5];
+#pragma unroll
+      for (int sft = 0; sft < 5; ++sft) pbm[sft] = mbase + 16 * ((hlm + sft) >> 2);
+      f32x4 au;
+      if (pair == 0) au = stage1w_merged_unit<0>(pbm, G);
+      else if (pair == 1) au = stage1w_merged_unit<1>(pbm, G);
+      else if (pair == 2) au = stage1w_merged_unit<2>(pbm, G);
+      else au = stage1w_merged_unit<3>(pbm, G);
+      *reinterpret_cast<f32x4*>(exch + ((part * 4 + pair) * 64 + lane) * 4) = au;
+    }
     SVK_STAMP(ts4);
     if (next < n_items) park_patch_w(patch, ph, ppiece, part, pre);
     SVK_STAMP(ts5);
     __syncthreads();  // the next patch is in place; act1 may be overwritten
     SVK_STAMP(ts6);
+    if (MERGE && pair == 0) {
+      // waves 0 and 4 finish merged tile m = part: rows 4 kk + r = (pair 2 m + (kk >> 1), output row 32 + 2 (kk & 1) + (r >> 1),
+      // column r & 1); the exchange buffer is written again behind the next item's first barrier
+      const int u = item / 36, rem = item - u * 36, q = rem / 18, j = rem - q * 18;
+      int lane_f = lane;
+      asm volatile("" : "+v"(lane_f));   // (keeps the address arithmetic below INSIDE the loop: hoisted, it costs registers this kernel spills)
+      const int i_f = lane_f & 15, kk_f = lane_f >> 4;
+      const float* xe = exch + (part * 4 * 64 + lane_f) * 4;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(xe), a1 = *reinterpret_cast<const f32x4*>(xe + 256),
+                  a2 = *reinterpret_cast<const f32x4*>(xe + 512), a3 = *reinterpret_cast<const f32x4*>(xe + 768);
+      const f32x4 y0 = a0 + a1 + a2 + b2, y1 = a1 - a2 - a3 + b2;
+      float* const o0 = p.out + (int64_t)u * p.s_n + (int64_t)(TD * q + 2 * (2 * part + (kk_f >> 1))) * p.s_d + (int64_t)j * p.s_w +
+                        (int64_t)(16 + (kk_f & 1)) * p.s_hp + i_f;
+      o0[0] = fmaxf(prelu_t<SLOPE01>(y0[0], sl2), prelu_t<SLOPE01>(y0[1], sl2));
+      o0[p.s_par] = fmaxf(prelu_t<SLOPE01>(y0[2], sl2), prelu_t<SLOPE01>(y0[3], sl2));
+      o0[p.s_d] = fmaxf(prelu_t<SLOPE01>(y1[0], sl2), prelu_t<SLOPE01>(y1[1], sl2));
+      o0[p.s_d + p.s_par] = fmaxf(prelu_t<SLOPE01>(y1[2], sl2), prelu_t<SLOPE01>(y1[3], sl2));
+    }
     SVK_STAMP_ADD(0, ts0, ts1);
     SVK_STAMP_ADD(1, ts1, ts2);
     SVK_STAMP_ADD(2, ts2, ts3);
@@ -542,12 +614,319 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
 #endif
 }
 
+
+// -----------------------------------------------------------------------------------------------------
+// Third form of the first block (round 3, the default): the depth transform's INPUT side is applied ONCE, where act1 is
+// produced, instead of at every fragment read.  c3d2_stage1w_kernel above spends 8 packed adds per 16 MFMAs turning x
+// fragments into t = (x0 - x2, x1 + x2, x2 - x1, x1 - x3) in front of every tap -- and an act1 value is read by ~4.5
+// taps; f32 VALU never overlaps f32 MFMA on this chip, so that was 7 % of the kernel, plus ~10 cycles per MFMA <-> VALU
+// switch.  Here conv1_1's epilogue holds the six act1 depths of a pixel in registers, forms the t planes of both depth
+// pairs and writes THOSE to LDS; conv1_2's loop is then ds_read_b128 + MFMA and nothing else.
+//   * t planes cost 8 planes per 2 pairs where x planes cost 6, and LDS holds 8: item = (cube, pooled column j, QUARTER q
+//     of the output depths) = 2 pairs; 72 items per cube.  conv1_1 recomputes the depth halo 6/4 (was 10/8): + 2.4 % MFMAs.
+//   * conv1_1 with the operands SWAPPED: M = channel (A = weights), N = pixel (B = patch values), so a lane ends up
+//     with FOUR CHANNELS of ONE pixel -- the six depths of that pixel are six accumulators of the same lane (the
+//     transform needs no lane movement) and a t value leaves as ONE ds_write_b128 (the old form wrote four ds_write_b32
+//     per tile).  K is permuted so that lane group kk < 3 reads the four contiguous column taps kw = 0 .. 3 of depth tap
+//     kk with ONE ds_read_b128 (patch rows hold columns 0..3 | 1..4: both 16-byte aligned) and group 3 reads a 'side'
+//     vector {kw = 4 of depth taps 0, 1, 2; 1.0} whose last element carries the bias: one ds_read_b128 per tile where the
+//     old form issued four ds_read_b32.
+//   * conv1_2 M tiles: 36 rows x 2 columns per pair = four 8-row tiles + 4 rows; the two pairs' 4-row remainders make
+//     ONE merged tile: 9 tiles x 144 MFMAs per item where the old form issued 2 x 5 (40 rows for every 36: - 10 %).
+//     Waves 0 .. 7 own the eight full tiles; the merged tile is split by k over waves 0 .. 3 (one per SIMD, 36 MFMAs each:
+//     every SIMD issues 324), their accumulators meet in LDS and wave 4 finishes it behind the item's last barrier.
+//   * t-plane rows are 40 floats: [column 0: 16 channels][8 pad][column 1: 16 channels].  With the true lane groups of
+//     ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... MI355X_MICROARCH.md, LDS) a tile's 16 pixels must sit
+//     in EVEN 16-byte slots, the lanes {0-3, 12-15} and {4-11} each covering all eight: slot = 4 hl + 6 wc (mod 16) does
+//     (the old padding made all 16 slots distinct, which collides across the kk = 0 / 1 halves of a group: the 49 %
+//     SQ_LDS_BANK_CONFLICT of profiles/r02_c3d2_stalls.txt).
+// -----------------------------------------------------------------------------------------------------
+constexpr int T_TD = 4, T_DIN = 6, T_PD = 8;              // output depths, act1 depths, patch depths per item
+constexpr int T_ROW = 40;                                  // floats per t-plane row: [c = 0: 16][pad 8][c = 1: 16]
+constexpr int T_PLANE = NFRAME * T_ROW;                    // 3 200 floats
+constexpr int T_PLANES_FLOATS = 8 * T_PLANE;               // [pair][k]
+constexpr int T_MAIN_FLOATS = T_PD * NFRAME * 8;           // [dd][h][cols 0..3 | cols 1..4]
+constexpr int T_SIDE_FLOATS = T_DIN * NFRAME * 2 * 4;      // [dd'][h][c][{col 4 + c at depth taps 0, 1, 2; 1.0}]
+constexpr int T_EXCH_FLOATS = 4 * 64 * 4;                  // the merged tile's four accumulators
+constexpr int T_LDS_FLOATS = T_PLANES_FLOATS + T_MAIN_FLOATS + T_SIDE_FLOATS + T_EXCH_FLOATS;
+constexpr int T_ITEMS = 18 * (OD / T_TD);                  // 72 items per cube
+constexpr int T_PAIRS_DH = T_PD * NFRAME;                  // 640 (patch depth, row) pairs per item
+
+struct PatchRegs {
+  f32x4 lo[2], hi[2];   // the 32-byte window of feature row (crop start + h) that holds columns 2 j .. 2 j + 5
+};
+
+template <bool SLOPE01>
+__global__ __launch_bounds__(512) void c3d2_stage1t_kernel(const Stage1Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_c3d2[];
+  float* const tpl = smem_c3d2;                       // [8 planes][80 rows][40]
+  float* const pmain = tpl + T_PLANES_FLOATS;         // [8 dd][80][8]
+  float* const pside = pmain + T_MAIN_FLOATS;         // [6 dd'][80][2][4]
+  float* const exch = pside + T_SIDE_FLOATS;          // [4 k][64][4]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  const int n_items = p.n_utt * T_ITEMS;
+
+  f32x4 G[36];   // [k][kh]: conv1_2's transformed weights, as in c3d2_stage1w_kernel
+#pragma unroll
+  for (int kh = 0; kh < 9; ++kh) {
+    const f32x4 g0 = p.w2frag[kh * 64 + lane], g1 = p.w2frag[(9 + kh) * 64 + lane], g2 = p.w2frag[(18 + kh) * 64 + lane];
+    G[kh] = g0;
+    G[9 + kh] = 0.5f * ((g0 + g2) + g1);
+    G[18 + kh] = 0.5f * ((g0 + g2) - g1);
+    G[27 + kh] = g2;
+  }
+  // conv1_1's A operand (weights; lane = (channel i, K group kk)): element e = tap (kd = kk, kw = e) for kk < 3, tap
+  // (kd = e, kw = 4) for kk = 3, e < 3, and the (BN-folded) bias for kk = 3, e = 3 -- read from the same w1frag table the
+  // other forms take ([4 jj][64]: tap 4 jj + kq of channel l & 15 in lane 16 kq + channel)
+  float wA[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int t = kk < 3 ? 5 * kk + e : 5 * e + 4;
+    wA[e] = (kk == 3 && e == 3) ? p.bias1[i] : p.w1frag[(t >> 2) * 64 + (t & 3) * 16 + i];
+  }
+  float sl1[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sl1[r] = p.slope1[4 * kk + r];
+  const float b2 = p.bias2[i], sl2 = p.slope2[i];
+
+  // the constant 1.0 of every side vector (never overwritten) + zeroed exchange
+  for (int e = threadIdx.x; e < T_DIN * NFRAME * 2; e += 512) pside[4 * e + 3] = 1.0f;
+
+  // ---- patch staging: (patch depth dd, row h) pairs q0 = thread and thread + 512 (< 640) ----
+  // (dd, h) of pair m are recomputed where they are needed: four registers this kernel does not have to spare
+  auto pair_dd = [&](int m) { const int q0 = threadIdx.x + 512 * m; return q0 < T_PAIRS_DH ? q0 / NFRAME : -1; };
+  auto pair_h = [&](int m) { const int q0 = threadIdx.x + 512 * m; return q0 - (q0 / NFRAME) * NFRAME; };
+  auto load_starts = [&](int item, int (&st)[2]) {
+    const int u = item / T_ITEMS, q = (item - u * T_ITEMS) / 18;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int dd = pair_dd(m);
+      st[m] = dd >= 0 ? p.crop[(int64_t)u * NCROP + T_TD * q + dd] : -1;
+    }
+  };
+  auto fetch_patch_t = [&](int item, const int (&st)[2], PatchRegs& pr) {
+    const int u = item / T_ITEMS, rem = item - u * T_ITEMS, j = rem % 18;
+    const float* base = p.feat + (int64_t)u * p.max_frames * NCOEF + ((2 * j) & ~3);   // 16-byte aligned window start
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      pr.lo[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      pr.hi[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int start = st[m], h = pair_h(m);   // (pairs past the 640th carry start = -1)
+      if ((unsigned)start < (unsigned)p.max_frames && h < p.max_frames - start) {
+        const float* s = base + (int64_t)(start + h) * NCOEF;
+        pr.lo[m] = *reinterpret_cast<const f32x4*>(s);
+        pr.hi[m] = *reinterpret_cast<const f32x4*>(s + 4);
+      }
+    }
+  };
+  auto park_patch_t = [&](int item, const PatchRegs& pr) {
+    const int u = item / T_ITEMS, rem = item - u * T_ITEMS, j = rem % 18;
+    const bool odd = (j & 1) != 0;                     // columns 2 j .. 2 j + 5 start at float 2 of the window when j is odd
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int dd = pair_dd(m), h = pair_h(m);
+      if (dd < 0) continue;
+      const f32x4 lo = pr.lo[m], hi = pr.hi[m];
+      const float v0 = odd ? lo[2] : lo[0], v1 = odd ? lo[3] : lo[1], v2 = odd ? hi[0] : lo[2], v3 = odd ? hi[1] : lo[3],
+                  v4 = odd ? hi[2] : hi[0], v5 = odd ? hi[3] : hi[1];
+      float* mrow = pmain + (dd * NFRAME + h) * 8;
+      *reinterpret_cast<f32x4*>(mrow) = (f32x4){v0, v1, v2, v3};
+      *reinterpret_cast<f32x4*>(mrow + 4) = (f32x4){v1, v2, v3, v4};
+      // column 4 + c of patch depth dd is depth tap e of act1 depth dd - e: ONE base (act1 depth dd - 2) + immediates
+      float* const sv = pside + ((dd - 2) * NFRAME + h) * 8;
+      if (dd <= 5) {
+        sv[2 * (NFRAME * 8)] = v4;
+        sv[2 * (NFRAME * 8) + 4] = v5;
+      }
+      if (dd >= 1 && dd <= 6) {
+        sv[NFRAME * 8 + 1] = v4;
+        sv[NFRAME * 8 + 5] = v5;
+      }
+      if (dd >= 2) {
+        sv[2] = v4;
+        sv[6] = v5;
+      }
+    }
+  };
+
+  PatchRegs pre;
+  int st_cur[2] = {-1, -1}, st_next[2] = {-1, -1};
+  int item = blockIdx.x;
+  if (item < n_items) {
+    load_starts(item, st_cur);
+    fetch_patch_t(item, st_cur, pre);
+    __syncthreads();                                   // the side vectors' constant is in place before the first park
+    park_patch_t(item, pre);
+    if (item + (int)gridDim.x < n_items) load_starts(item + gridDim.x, st_next);
+  }
+  __syncthreads();
+
+  const int full_pair = wave >> 2, full_h0 = 8 * (wave & 3);
+#ifdef SVK_TUNING
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  for (; item < n_items; item += gridDim.x) {
+    SVK_STAMP(ts0);
+    const int next = item + gridDim.x;
+    const int u = item / T_ITEMS, rem = item - u * T_ITEMS, q = rem / 18, j = rem - q * 18;
+
+    // ---- conv1_1 + PReLU + input transform: ten pixel sets (8 rows x 2 columns), set = wave, sets 8 and 9 on waves 4, 5 ----
+    // per-lane address parts (recomputed per item: registers are the scarce resource here)
+    const int c11_b = (kk < 3 ? (int)(pmain - smem_c3d2) + (kk * NFRAME + (i >> 1)) * 8 + 4 * (i & 1)
+                              : (int)(pside - smem_c3d2) + ((i >> 1) * 2 + (i & 1)) * 4);          // conv1_1 B operand, set 0, depth 0
+    const int c11_w = (i >> 1) * T_ROW + 24 * (i & 1) + 4 * kk;                                  // t-plane write, set 0
+#pragma unroll 1
+    for (int set = wave; set < 10; set += (wave == 4 || wave == 5) ? 4 : 16) {
+      const float* bp = smem_c3d2 + c11_b + set * 64;            // 8 rows further: 64 floats in both patch arrays
+      f32x4 xb[T_DIN];
+#pragma unroll
+      for (int d = 0; d < T_DIN; ++d) xb[d] = *reinterpret_cast<const f32x4*>(bp + d * (NFRAME * 8));
+      f32x4 x[T_DIN];
+#pragma unroll
+      for (int d = 0; d < T_DIN; ++d) x[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int d = 0; d < T_DIN; ++d) x[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[e], xb[d][e], x[d], 0, 0, 0);
+#pragma unroll
+      for (int d = 0; d < T_DIN; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[d][r] = prelu_t<SLOPE01>(x[d][r], sl1[r]);
+      float* tw = tpl + c11_w + set * (8 * T_ROW);
+#pragma unroll
+      for (int pr2 = 0; pr2 < 2; ++pr2) {
+        const f32x4 x0 = x[2 * pr2], x1 = x[2 * pr2 + 1], x2 = x[2 * pr2 + 2], x3 = x[2 * pr2 + 3];
+        float* tp = tw + pr2 * (4 * T_PLANE);
+        *reinterpret_cast<f32x4*>(tp) = x0 - x2;
+        *reinterpret_cast<f32x4*>(tp + T_PLANE) = x1 + x2;
+        *reinterpret_cast<f32x4*>(tp + 2 * T_PLANE) = x2 - x1;
+        *reinterpret_cast<f32x4*>(tp + 3 * T_PLANE) = x1 - x3;
+      }
+    }
+    SVK_STAMP(ts1);
+    __syncthreads();   // the t planes are complete; the patch arrays are free
+    SVK_STAMP(ts2);
+
+    // ---- the next item's patch: loads issued here, parked behind this item's matrix work ----
+    if (next < n_items) fetch_patch_t(next, st_next, pre);
+    if (next + (int)gridDim.x < n_items) load_starts(next + gridDim.x, st_cur);   // (st_cur is dead: re-used as 'the one after')
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- conv1_2: this wave's full tile (pair = wave >> 2, rows 8 (wave & 3) ..) ----
+    float* const obase = p.out + (int64_t)u * p.s_n + (int64_t)(T_TD * q) * p.s_d + (int64_t)j * p.s_w;
+    {
+      const float* ab = tpl + full_pair * (4 * T_PLANE) + (2 * (full_h0 + (i >> 1))) * T_ROW + 24 * (i & 1) + 4 * kk;   // tap 0, plane 0
+      f32x4 acc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = k == 1 ? (f32x4){b2, b2, b2, b2} : (f32x4){0.f, 0.f, 0.f, 0.f};   // a1 carries the bias
+      f32x4 a[4], an[2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const f32x4*>(ab + k * T_PLANE);
+#pragma unroll
+      for (int kh = 0; kh < 9; ++kh) {
+        // the next tap's fragments of planes 0, 1 are read in front of this tap's MFMAs into a second register pair;
+        // those of planes 2, 3 go straight into a[2], a[3] once this tap's last MFMA on them has issued (the e = 3 round
+        // runs k = 2, 3, 0, 1: eight and more MFMAs = 256 cycles pass before the next tap reaches them) -- a full second
+        // fragment set does not fit beside the 144 weight registers
+        if (kh + 1 < 9) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) an[k] = *reinterpret_cast<const f32x4*>(ab + k * T_PLANE + (kh + 1) * T_ROW);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][e], G[9 * k + kh][e], acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 2; k < 4; ++k) {
+          acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][3], G[9 * k + kh][3], acc[k], 0, 0, 0);
+          if (kh + 1 < 9) {
+            __builtin_amdgcn_sched_barrier(0);
+            a[k] = *reinterpret_cast<const f32x4*>(ab + k * T_PLANE + (kh + 1) * T_ROW);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][3], G[9 * k + kh][3], acc[k], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kh + 1 < 9) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) a[k] = an[k];
+        }
+      }
+      // rows 4 kk + r of the tile: output row full_h0 + 2 kk + (r >> 1), column r & 1: pool = max over the r pairs
+      const f32x4 y0 = acc[0] + acc[1] + acc[2], y1 = acc[1] - acc[2] - acc[3];
+      float* const o00 = obase + (int64_t)(2 * full_pair) * p.s_d + (int64_t)(full_h0 / 2) * p.s_hp;
+      float* const o01 = o00 + p.s_par;
+      float* const o10 = o00 + p.s_d;
+      float* const o11 = o10 + p.s_par;
+      const int olane = kk * (int)p.s_hp + i;
+      o00[olane] = fmaxf(prelu_t<SLOPE01>(y0[0], sl2), prelu_t<SLOPE01>(y0[1], sl2));
+      o01[olane] = fmaxf(prelu_t<SLOPE01>(y0[2], sl2), prelu_t<SLOPE01>(y0[3], sl2));
+      o10[olane] = fmaxf(prelu_t<SLOPE01>(y1[0], sl2), prelu_t<SLOPE01>(y1[1], sl2));
+      o11[olane] = fmaxf(prelu_t<SLOPE01>(y1[2], sl2), prelu_t<SLOPE01>(y1[3], sl2));
+    }
+    SVK_STAMP(ts3);
+    // ---- the merged tile (rows 32 .. 35 of both pairs): waves 0 .. 3 compute accumulator k = wave ----
+    if (wave < 4) {
+      const float* ab = tpl + (i >> 3) * (4 * T_PLANE) + (2 * (32 + ((i >> 1) & 3))) * T_ROW + 24 * (i & 1) + 4 * kk + wave * T_PLANE;
+      f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;   // two chains: back-to-back dependent MFMAs would wait 40 cycles each
+      f32x4 a = *reinterpret_cast<const f32x4*>(ab), an;
+#pragma unroll
+      for (int kh = 0; kh < 9; ++kh) {
+        if (kh + 1 < 9) an = *reinterpret_cast<const f32x4*>(ab + (kh + 1) * T_ROW);
+        const f32x4 g = wave == 0 ? G[kh] : wave == 1 ? G[9 + kh] : wave == 2 ? G[18 + kh] : G[27 + kh];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], g[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], g[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], g[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], g[3], acc1, 0, 0, 0);
+        if (kh + 1 < 9) a = an;
+      }
+      *reinterpret_cast<f32x4*>(exch + (wave * 64 + lane) * 4) = acc0 + acc1;
+    }
+    SVK_STAMP(ts4);
+    if (next < n_items) park_patch_t(next, pre);
+    SVK_STAMP(ts5);
+    __syncthreads();   // the next patch and the merged tile's accumulators are in place; the t planes may be overwritten
+    SVK_STAMP(ts6);
+    SVK_STAMP_ADD(0, ts0, ts1);  // conv1_1 phase
+    SVK_STAMP_ADD(1, ts1, ts2);  // barrier 1
+    SVK_STAMP_ADD(2, ts2, ts3);  // patch load issue + full tile + epilogue
+    SVK_STAMP_ADD(3, ts3, ts4);  // merged-tile quarter
+    SVK_STAMP_ADD(4, ts4, ts5);  // park
+    SVK_STAMP_ADD(5, ts5, ts6);  // barrier 2
+    if (wave == 4) {
+      // merged tile: rows 4 kk + r = (pair kk >> 1, output row 32 + 2 (kk & 1) + (r >> 1), column r & 1)
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(exch + lane * 4), a1 = *reinterpret_cast<const f32x4*>(exch + (64 + lane) * 4),
+                  a2 = *reinterpret_cast<const f32x4*>(exch + (128 + lane) * 4), a3 = *reinterpret_cast<const f32x4*>(exch + (192 + lane) * 4);
+      const f32x4 y0 = a0 + a1 + a2 + b2, y1 = a1 - a2 - a3 + b2;
+      float* const o0 = obase + (int64_t)(2 * (kk >> 1)) * p.s_d + (int64_t)(16 + (kk & 1)) * p.s_hp + i;
+      o0[0] = fmaxf(prelu_t<SLOPE01>(y0[0], sl2), prelu_t<SLOPE01>(y0[1], sl2));
+      o0[p.s_par] = fmaxf(prelu_t<SLOPE01>(y0[2], sl2), prelu_t<SLOPE01>(y0[3], sl2));
+      o0[p.s_d] = fmaxf(prelu_t<SLOPE01>(y1[0], sl2), prelu_t<SLOPE01>(y1[1], sl2));
+      o0[p.s_d + p.s_par] = fmaxf(prelu_t<SLOPE01>(y1[2], sl2), prelu_t<SLOPE01>(y1[3], sl2));
+    }
+    // the crop starts loaded into st_cur during this item belong to the item after next: rotate
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int t = st_next[m];
+      st_next[m] = st_cur[m];
+      st_cur[m] = t;
+    }
+  }
+#ifdef SVK_TUNING
+  if (p.stamps && lane == 0)
+    for (int k = 0; k < 6; ++k) p.stamps[((size_t)blockIdx.x * 8 + wave) * 6 + k] = stamp_acc[k];
+#endif
+}
+
 }  // namespace
 
 extern "C" {
 
 // (of the larger variant, the depth-transformed one)
-size_t svk_c3d2_stage1_lds_bytes(void) { return sizeof(float) * (size_t)(WACT_FLOATS + P_FLOATS); }
+size_t svk_c3d2_stage1_lds_bytes(void) { return sizeof(float) * (size_t)std::max(WACT_FLOATS + P_FLOATS + 2048, T_LDS_FLOATS); }
 
 int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const float* d_w1frag,
@@ -556,7 +935,8 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
   if (!ctx) return SVK_ERR_BAD_ARG;
   // (the slopes live on the device: whether all 32 lie in [0, 1] -- the two-instruction PReLU -- is the caller's
   // knowledge, passed in bit 1 of `folded`: 0 / 1 = layout with the general PReLU, 2 / 3 = the same with slopes in [0, 1])
-  const bool slope01 = (folded & 2) != 0, wino = (folded & 4) != 0;
+  const bool slope01 = (folded & 2) != 0, wino = (folded & 4) != 0, tform = (folded & 8) != 0;   // bit 3: c3d2_stage1t_kernel
+  const bool merge = (folded & 16) != 0;                                                         // bit 4: merged remainder tiles
   folded &= 1;
   SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 1, "shape");
   if (n_cols != NCOEF || n_crops != NCROP || crop_frames != NFRAME)
@@ -568,7 +948,8 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
               "NULL buffer");
   SVK_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_feat) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_w2frag) & 15) == 0,
               "d_feat must be 8-byte and d_w2frag 16-byte aligned");
-  SVK_REQUIRE(ctx, (int64_t)n_utt * 36 < ((int64_t)1 << 31), "too many cubes for one launch");
+  SVK_REQUIRE(ctx, (int64_t)n_utt * T_ITEMS < ((int64_t)1 << 31), "too many cubes for one launch");
+  SVK_REQUIRE(ctx, !tform || (reinterpret_cast<uintptr_t>(d_feat) & 15) == 0, "d_feat must be 16-byte aligned for the t-plane form");
   Stage1Params p;
   p.feat = d_feat;
   p.crop = d_crop_idx;
@@ -593,15 +974,17 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
     p.s_d = (int64_t)OH * OWP * 16;
   }
   p.s_n = (int64_t)OD * OH * OWP * 16;
-  const size_t lds = sizeof(float) * (size_t)((wino ? WACT_FLOATS : ACT_FLOATS) + P_FLOATS);
+  const size_t lds = sizeof(float) * (size_t)(tform ? T_LDS_FLOATS : (wino ? WACT_FLOATS + (merge ? 2048 : 0) : ACT_FLOATS) + P_FLOATS);
   if (lds > (size_t)ctx->lds_per_cu)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage1 needs %zu bytes of LDS per workgroup (device: %d)", lds,
                     ctx->lds_per_cu);
-  void (*kern)(const Stage1Params) = wino ? (slope01 ? c3d2_stage1w_kernel<true> : c3d2_stage1w_kernel<false>)
-                                          : (slope01 ? c3d2_stage1_kernel<true> : c3d2_stage1_kernel<false>);
-  const int n_waves = wino ? 8 : 4;
+  void (*kern)(const Stage1Params) = tform ? (slope01 ? c3d2_stage1t_kernel<true> : c3d2_stage1t_kernel<false>)
+                                     : wino ? (merge ? (slope01 ? c3d2_stage1w_kernel<true, true> : c3d2_stage1w_kernel<false, true>)
+                                                     : (slope01 ? c3d2_stage1w_kernel<true, false> : c3d2_stage1w_kernel<false, false>))
+                                            : (slope01 ? c3d2_stage1_kernel<true> : c3d2_stage1_kernel<false>);
+  const int n_waves = (wino || tform) ? 8 : 4;
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int64_t items = (int64_t)n_utt * 36;
+  const int64_t items = (int64_t)n_utt * (tform ? T_ITEMS : 36);
   const unsigned grid = (unsigned)std::min<int64_t>(items, ctx->num_cu);  // one persistent workgroup per CU
   p.stamps = nullptr;
 #ifdef SVK_TUNING
@@ -620,7 +1003,9 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
     std::vector<unsigned long long> h((size_t)grid * n_waves * 6);
     SVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SVK_HIP(ctx, hipMemcpy(h.data(), p.stamps, stamp_bytes, hipMemcpyDeviceToHost));
-    const char* names[6] = {"issue next patch loads", "conv1_1 phase", "barrier 1", "conv1_2 phase + epilogue", "park", "barrier 2"};
+    const char* names_w[6] = {"issue next patch loads", "conv1_1 phase", "barrier 1", "conv1_2 phase + epilogue", "park", "barrier 2"};
+    const char* names_t[6] = {"conv1_1 phase", "barrier 1", "patch loads + full tile + epilogue", "merged-tile quarter", "park", "barrier 2"};
+    const char** names = tform ? names_t : names_w;
     const double per = (double)items / grid;
     for (int w = 0; w < n_waves; ++w) {
       fprintf(stderr, "stage1 stamps wave %d (cycles per item):", w);

@@ -422,11 +422,14 @@ class Engine:
                                                crop_frames, kd, kw, group, self._ptr(out)), self.ctx)
         return out
 
-    def c3d2_stage1(self, feat, crop_idx, tables, folded=True, crop_frames=80, depth_transform=False):
+    def c3d2_stage1(self, feat, crop_idx, tables, folded=True, crop_frames=80, depth_transform=False, t_planes=False,
+                    merged_tiles=False):
         """svk_c3d2_stage1: feature rows + crop starts -> the activation after C3D2's first block (conv1_1,
         conv1_2, pool1 with their BN + PReLU): [n, 16, 18, 18, 2, 16] (row-folded) or [n, 16, 36, 18, 16] f32.
         `depth_transform`: conv1_2 through Winograd's F(2, 3) along depth (2 / 3 of the multiply-adds; the same sums
-        in another association, ~1e-6 relative from the direct form)."""
+        in another association, ~1e-6 relative from the direct form).  `t_planes` (implies the depth transform): the
+        round-3 kernel that applies the input transform once, where conv1_1's output is produced (c3d2_stage1t_kernel).
+        `merged_tiles` (with depth_transform): the 4-row remainders of two depth pairs share one M tile (- 10 % MFMAs)."""
         torch = _torch()
         feat = self.to_device(feat, torch.float32)
         idx = self.to_device(crop_idx, torch.int32)
@@ -438,7 +441,9 @@ class Engine:
         self._stream()
         check(self.lib.svk_c3d2_stage1(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), idx.shape[1], crop_frames,
                                        self._ptr(w1frag), self._ptr(bias1), self._ptr(slope1), self._ptr(w2frag), self._ptr(bias2),
-                                       self._ptr(slope2), int(bool(folded)) | (2 if slope01 else 0) | (4 if depth_transform else 0), self._ptr(out)),
+                                       self._ptr(slope2), int(bool(folded)) | (2 if slope01 else 0) |
+                                       (8 if t_planes else (4 | (16 if merged_tiles else 0)) if depth_transform else 0),
+                                       self._ptr(out)),
               self.ctx)
         return out
 

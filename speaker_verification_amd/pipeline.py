@@ -47,6 +47,12 @@ class VerificationPipeline:
         # conv1_2 and conv2_1 through Winograd's F(2, 3) along depth (2 / 3 of the multiply-adds);
         # SVK_C3D2_DEPTH_TRANSFORM=0 = direct sums
         self.depth_transform = os.environ.get("SVK_C3D2_DEPTH_TRANSFORM", "1") != "0"
+        # the first block's kernel form: "t" = input transform applied once at conv1_1's output (c3d2_stage1t_kernel, the
+        # default), "w" = at every fragment read (c3d2_stage1w_kernel, round 2)
+        form = os.environ.get("SVK_C3D2_STAGE1_FORM", "m")
+        self.stage1_t_planes = self.depth_transform and form == "t"
+        # "m" (default): the round-2 form with the remainder rows of two depth pairs merged into one tile; "w": round 2 as it was
+        self.stage1_merged = self.depth_transform and form == "m"
         # bench.py sets this to a list: one {kernel name: (start, end) HIP events on the launch stream, "cubes": n} per
         # micro-batch, around every network kernel
         self.kernel_events = None
@@ -187,7 +193,8 @@ class VerificationPipeline:
                     spans[name] = (a, b)
                     return out
                 y = timed("stage1", lambda: self.eng.c3d2_stage1(feat, crop_idx, tables, folded=False, crop_frames=c.CUBE_FRAMES,
-                                                                  depth_transform=self.depth_transform))
+                                                                  depth_transform=self.depth_transform,
+                                                                  t_planes=self.stage1_t_planes, merged_tiles=self.stage1_merged))
                 z = timed("stage2", lambda: self.eng.c3d2_stage2(y, tables2, depth_transform=self.depth_transform))
                 if spans is not None:
                     self.kernel_events.append(spans)
@@ -198,7 +205,8 @@ class VerificationPipeline:
                     return self.embedder.from_stage2(z, feat.shape[0])
             folded = self.embedder.row_fold is not None
             y = self.eng.c3d2_stage1(feat, crop_idx, tables, folded=folded, crop_frames=c.CUBE_FRAMES,
-                                     depth_transform=self.depth_transform)
+                                     depth_transform=self.depth_transform, t_planes=self.stage1_t_planes,
+                                     merged_tiles=self.stage1_merged)
             with self._find_mode():
                 return self.embedder.from_stage1(y, feat.shape[0])
         geo = self.embedder.first_layer_windows(c.CUBE_CROPS, feat.shape[2]) if self.embedder is not None else None

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""In-kernel phase stamps of the first block's t-plane form (c3d2_stage1t_kernel) and of the round-2 form beside it:
+cycles per item and wave, from a -DSVK_TUNING build (make -C speaker_verification_amd/csrc stamps)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch                                                                  # noqa: E402
+from speaker_verification_amd import _lib                                    # noqa: E402
+_lib.LIB_PATH = os.environ.get("SVK_TOOL_LIB", os.path.join(os.path.dirname(_lib.LIB_PATH), "..", "build_variants", "libsvk_stamps.so"))
+from speaker_verification_amd.engine import get_engine                       # noqa: E402
+from speaker_verification_amd.model import seeded_model                      # noqa: E402
+
+eng = get_engine(0)
+emb = seeded_model(1, n_labels=4).to(eng.device).eval().fused_inference(channels_last=True)
+t1 = emb.stage1_tables()
+n = 1024
+g = torch.Generator(device=eng.device)
+g.manual_seed(0)
+feat = torch.randn((n, 297, 40), device=eng.device, generator=g) * 2 - 6
+crops = torch.randint(0, 200, (n, 20), device=eng.device, dtype=torch.int32, generator=g)
+for kw in (dict(depth_transform=True), dict(depth_transform=True, merged_tiles=True), dict(t_planes=True)):
+    for _ in range(10):
+        eng.c3d2_stage1(feat, crops, t1, folded=False, **kw)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        eng.c3d2_stage1(feat, crops, t1, folded=False, **kw)
+    b.record()
+    torch.cuda.synchronize()
+    print("svk_c3d2_stage1 %s: %.3f ms per 1024 cubes (stamped build)" % (kw, a.elapsed_time(b) / 10), file=sys.stderr)
+os.environ["SVK_C3D2_STAMPS"] = "1"
+for kw in (dict(depth_transform=True), dict(depth_transform=True, merged_tiles=True), dict(t_planes=True)):
+    print("---- %s" % kw, file=sys.stderr)
+    eng.c3d2_stage1(feat, crops, t1, folded=False, **kw)
+    torch.cuda.synchronize()

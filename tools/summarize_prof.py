@@ -20,7 +20,7 @@ from collections import defaultdict
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OURS = ("frontend_kernel", "cmvn_kernel", "vad_kernel", "cube_gather_kernel", "cosine_kernel", "cosine_tiled_kernel",
         "inv_norm_kernel", "draw_crops_kernel", "cube_windows_kernel", "cube_windows_c3d2_kernel", "decimate_kernel", "resample_kernel",
-        "c3d2_stage1w_kernel", "c3d2_stage1_kernel", "c3d2_conv21w_kernel", "c3d2_conv22w_kernel", "c3d2_conv31w_kernel", "c3d2_conv32w_kernel", "c3d2_conv21_kernel",
+        "c3d2_stage1t_kernel", "c3d2_stage1w_kernel", "c3d2_stage1_kernel", "c3d2_conv21w_kernel", "c3d2_conv22w_kernel", "c3d2_conv31w_kernel", "c3d2_conv32w_kernel", "c3d2_conv21_kernel",
         "c3d2_conv22_kernel", "bias_prelu_kernel", "cmvnw_kernel", "spectrum_pow2_kernel",
         "spectrum_dft_kernel", "spectrum_fft_kernel", "mel_features_kernel", "c3d2_tail_kernel", "fc5_reduce_kernel", "fc5_kernel")
 
@@ -29,6 +29,8 @@ def short(name):
     for k in OURS:
         if k in name:
             extra = ""
+            if k == "c3d2_stage1w_kernel" and ("<true, true>" in name or "<false, true>" in name):
+                extra = "<merged>"
             if k == "c3d2_tail_kernel":
                 extra = "<Conv41>" if "Conv41" in name else "<Conv42>"
             if "frontend_kernel" in name:
@@ -55,7 +57,9 @@ def main():
         print("wrote", f"profiles/{tag}_bench_kernel_stats.csv", len(keep) - 1, "kernels")
     summary = defaultdict(lambda: defaultdict(list))
     meta = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_c3d2", "pmc_write_c3d2", "pmc_sq_c3d2"):
+    # (c3d2_1 .. c3d2_3: the three stall-composition passes over `bench.py --c3d2-only`; they carry SQ_INSTS_MFMA, which
+    # bench.py's roofline fractions are built on)
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_c3d2", "pmc_write_c3d2", "pmc_sq_c3d2", "c3d2_1", "c3d2_2", "c3d2_3"):
         paths = sorted(glob.glob(os.path.join(REPO, "gpurun_out", sub, "**", "*_counter_collection.csv"),
                                  recursive=True), key=os.path.getmtime)
         for path in paths[-1:]:                             # newest run only
@@ -64,7 +68,7 @@ def main():
                 if not k:
                     continue
                 summary[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-                summary[k].setdefault("duration_ns_" + sub.replace("_c3d2", ""), []).append(
+                summary[k].setdefault("duration_ns_" + (sub.replace("_c3d2", "") if sub.startswith("pmc") else "pmc_sq"), []).append(
                     int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
                 meta[k] = {"grid_size": int(row["Grid_Size"]), "workgroup_size": int(row["Workgroup_Size"]),
                            "vgpr": int(row["VGPR_Count"]), "accum_vgpr": int(row["Accum_VGPR_Count"]),
