@@ -430,6 +430,8 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
   __syncthreads();
 #ifdef SVK_TUNING
   unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+  // the clock the chip holds under this kernel's load: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime) over the loop
+  const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   for (; item < n_items; item += gridDim.x) {
     SVK_STAMP(ts0);
@@ -609,8 +611,14 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
     SVK_STAMP_ADD(5, ts5, ts6);
   }
 #ifdef SVK_TUNING
-  if (p.stamps && lane == 0)
+  if (p.stamps && lane == 0) {
     for (int k = 0; k < 6; ++k) p.stamps[((size_t)blockIdx.x * 8 + wave) * 6 + k] = stamp_acc[k];
+    if (wave == 0) {
+      unsigned long long* clk = p.stamps + (size_t)gridDim.x * 8 * 6 + (size_t)blockIdx.x * 2;
+      clk[0] = __builtin_amdgcn_s_memtime() - clk_c0;
+      clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+  }
 #endif
 }
 
@@ -989,18 +997,19 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
   p.stamps = nullptr;
 #ifdef SVK_TUNING
   const bool want_stamps = getenv("SVK_C3D2_STAMPS") != nullptr;
-  const size_t stamp_bytes = (size_t)grid * n_waves * 6 * sizeof(unsigned long long);
+  const size_t stamp_bytes = ((size_t)grid * n_waves * 6 + (size_t)grid * 2) * sizeof(unsigned long long);
   if (want_stamps) {
     const int rc = svk_ensure_work(ctx, stamp_bytes);
     if (rc != SVK_OK) return rc;
     p.stamps = reinterpret_cast<unsigned long long*>(ctx->work);
+    SVK_HIP(ctx, hipMemsetAsync(p.stamps, 0, stamp_bytes, ctx->stream));
   }
 #endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * n_waves), lds, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
 #ifdef SVK_TUNING
   if (want_stamps) {  // phase cycles (s_memtime, 100 MHz-independent shader clock), averaged over workgroups, per wave
-    std::vector<unsigned long long> h((size_t)grid * n_waves * 6);
+    std::vector<unsigned long long> h((size_t)grid * n_waves * 6 + (size_t)grid * 2);
     SVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SVK_HIP(ctx, hipMemcpy(h.data(), p.stamps, stamp_bytes, hipMemcpyDeviceToHost));
     const char* names_w[6] = {"issue next patch loads", "conv1_1 phase", "barrier 1", "conv1_2 phase + epilogue", "park", "barrier 2"};
@@ -1015,6 +1024,18 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
         fprintf(stderr, "  %s %.0f", names[k], sum / grid / per);
       }
       fprintf(stderr, "\n");
+    }
+    if (wino && !tform) {   // in-kernel clock: median over workgroups of shader cycles per 100 MHz reference tick
+      std::vector<double> mhz;
+      for (unsigned b = 0; b < grid; ++b) {
+        const unsigned long long c = h[(size_t)grid * n_waves * 6 + 2 * b], r = h[(size_t)grid * n_waves * 6 + 2 * b + 1];
+        if (r) mhz.push_back(100.0 * (double)c / (double)r);
+      }
+      if (!mhz.empty()) {
+        std::sort(mhz.begin(), mhz.end());
+        fprintf(stderr, "stage1 in-kernel clock: median %.0f MHz (min %.0f, max %.0f) over %zu workgroups; the 157.3 TFLOP/s peak assumes 2400\n",
+                mhz[mhz.size() / 2], mhz.front(), mhz.back(), mhz.size());
+      }
     }
   }
 #endif
