@@ -492,11 +492,15 @@ def ragged_bench(pipe, eng, torch, n_clips=2048, reps=3):
             emb = pipe.embed_ragged_resident(buf, offs, lens, spans=spans)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
-            front = sum(a.elapsed_time(b) for name, a, b in spans if name == "front")
-            net = sum(a.elapsed_time(b) for name, a, b in spans if name == "network")
-            shares.append((front, net))
+            by = {}
+            for name, a, b in spans:
+                by[name] = by.get(name, 0.0) + a.elapsed_time(b)
+            shares.append(by)
         t_res = float(np.median(times))
-        front_ms, net_ms = (float(np.median([x[i] for x in shares])) for i in (0, 1))
+        stage_ms = {k: float(np.median([x.get(k, 0.0) for x in shares])) for k in ("vad", "frontend", "cmvn", "crops", "network")}
+        front_ms = sum(v for k, v in stage_ms.items() if k != "network")
+        net_ms = stage_ms["network"]
+        n_batches = sum(1 for name, _, _ in spans if name == "network")
         host_buf = buf.cpu().numpy()
         clips = [host_buf[offs[k]:offs[k] + lens[k]] for k in range(n_clips)]
         pipe.embed_ragged(clips[:64])
@@ -513,7 +517,7 @@ def ragged_bench(pipe, eng, torch, n_clips=2048, reps=3):
                         "of int16 PCM), energy VAD -> lmfe -> CMVN -> crops -> C3D2, batches sorted by length"
                         % (n_clips, float(np.median(lens)) / 16000, audio_s / n_clips, audio_s, total * 2 / 1e6),
             "resident": {"utt_per_s": n_clips / t_res, "audio_seconds_per_s": audio_s / t_res, "ms": t_res * 1e3,
-                         "front_end_ms": front_ms, "network_ms": net_ms,
+                         "front_end_ms": front_ms, "network_ms": net_ms, "stage_ms": stage_ms, "batches": n_batches,
                          "front_end_share": front_ms / max(front_ms + net_ms, 1e-9)},
             "host_fed": {"utt_per_s": n_clips / t_host, "audio_seconds_per_s": audio_s / t_host, "ms": t_host * 1e3,
                          "note": "a list of host NumPy clips: packed per batch into one array, uploaded (pageable), same kernels"},

@@ -8,6 +8,8 @@
 #include <algorithm>
 
 #include "fft_wave.h"
+#include <cstdlib>
+
 #include "svk_internal.h"
 
 using namespace svk_fft;
@@ -298,6 +300,94 @@ __global__ __launch_bounds__(256) void cmvn_kernel(float* __restrict__ feat, int
         base[o] = (float)(((double)base[o] - mean) * inv);
       }
     __syncthreads();
+  }
+}
+
+// ---- CMVN for LONG clips (VoxCeleb utterances run to 145 s = 14 500 frames): with one workgroup per clip a batch of a
+// few long clips leaves the chip to a handful of workgroups that each walk megabytes three times (measured: 1.07 ms for
+// 14 clips of 31 .. 145 s).  Three small kernels cut a clip into chunks of CMVN_CHUNK frames instead: per-chunk column
+// sums and sums of squares in float64, a per-clip reduction over the chunks IN ORDER (bitwise repeatable; no atomics)
+// to mean and 1 / (std + 2^-30), and the normalisation.  var = E[x^2] - mean^2 in float64: for features of magnitude
+// <= 10^2 and f32 inputs the cancellation costs < 1e-12 relative -- far below the float32 the result is stored in. ----
+constexpr int CMVN_CHUNK = 256;
+
+__global__ __launch_bounds__(256) void cmvn_partial_kernel(const float* __restrict__ feat, int max_frames, int ncols,
+                                                           const int32_t* __restrict__ n_frames, int n_chunks,
+                                                           double* __restrict__ part /* [utt][chunk][2][ncols] */) {
+  __shared__ double red[2][256];
+  const int utt = blockIdx.y, chunk = blockIdx.x;
+  int T = n_frames ? n_frames[utt] : max_frames;
+  T = T < max_frames ? T : max_frames;
+  const int t0 = chunk * CMVN_CHUNK, t1 = min(T, t0 + CMVN_CHUNK);
+  const float* base = feat + (int64_t)utt * max_frames * ncols;
+  double* out = part + ((int64_t)utt * n_chunks + chunk) * 2 * ncols;
+  for (int c0 = 0; c0 < ncols; c0 += 256) {
+    const int cb = min(256, ncols - c0), R = 256 / cb;
+    const int tc = threadIdx.x % cb, tr = threadIdx.x / cb;
+    double s = 0.0, q = 0.0;
+    if (tr < R)
+      for (int t = t0 + tr; t < t1; t += R) {
+        const double v = (double)base[(int64_t)t * ncols + c0 + tc];
+        s += v;
+        q += v * v;
+      }
+    red[0][threadIdx.x] = tr < R ? s : 0.0;
+    red[1][threadIdx.x] = tr < R ? q : 0.0;
+    __syncthreads();
+    if (tr == 0) {
+      double ss = 0.0, qq = 0.0;
+      for (int r = 0; r < R; ++r) {
+        ss += red[0][r * cb + tc];
+        qq += red[1][r * cb + tc];
+      }
+      out[c0 + tc] = ss;
+      out[ncols + c0 + tc] = qq;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void cmvn_stats_kernel(const double* __restrict__ part, int max_frames, int ncols,
+                                                         const int32_t* __restrict__ n_frames, int n_chunks, int variance,
+                                                         double* __restrict__ stats /* [utt][2][ncols]: mean, inv */) {
+  const int utt = blockIdx.x;
+  int T = n_frames ? n_frames[utt] : max_frames;
+  T = T < max_frames ? T : max_frames;
+  if (T <= 0) return;
+  const int used = (T + CMVN_CHUNK - 1) / CMVN_CHUNK;
+  for (int c = threadIdx.x; c < ncols; c += 256) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < used; ++k) {        // fixed order: repeatable
+      const double* pk = part + ((int64_t)utt * n_chunks + k) * 2 * ncols;
+      s += pk[c];
+      q += pk[ncols + c];
+    }
+    const double mean = s / (double)T;
+    double inv = 1.0;
+    if (variance) {
+      double var = q / (double)T - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      inv = 1.0 / (sqrt(var) + 9.313225746154785e-10);   // + 2^-30, processing.py:250,266
+    }
+    stats[((int64_t)utt * 2) * ncols + c] = mean;
+    stats[((int64_t)utt * 2 + 1) * ncols + c] = inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void cmvn_apply_kernel(float* __restrict__ feat, int max_frames, int ncols,
+                                                         const int32_t* __restrict__ n_frames,
+                                                         const double* __restrict__ stats) {
+  const int utt = blockIdx.y, chunk = blockIdx.x;
+  int T = n_frames ? n_frames[utt] : max_frames;
+  T = T < max_frames ? T : max_frames;
+  const int t0 = chunk * CMVN_CHUNK, t1 = min(T, t0 + CMVN_CHUNK);
+  if (t0 >= t1) return;
+  float* base = feat + ((int64_t)utt * max_frames + t0) * ncols;
+  const double* st = stats + (int64_t)utt * 2 * ncols;
+  const int n = (t1 - t0) * ncols;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int c = e % ncols;
+    base[e] = (float)(((double)base[e] - st[c]) * st[ncols + c]);
   }
 }
 
@@ -961,6 +1051,28 @@ int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int
   SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 0 && n_cols >= 0, "negative shape");
   if (n_utt == 0 || max_frames == 0 || n_cols == 0) return SVK_OK;
   SVK_REQUIRE(ctx, d_feat, "NULL buffer");
+  // long clips: chunks of a clip go to separate workgroups (see cmvn_partial_kernel); SVK_CMVN_SPLIT=0 / 1 forces a path
+  const char* force = getenv("SVK_CMVN_SPLIT");
+  const bool split = force ? force[0] == '1' : max_frames > 1024;
+  if (split && n_utt <= 65535) {
+    const int n_chunks = (max_frames + CMVN_CHUNK - 1) / CMVN_CHUNK;
+    const size_t part_bytes = sizeof(double) * (size_t)n_utt * n_chunks * 2 * n_cols;
+    const size_t stats_bytes = sizeof(double) * (size_t)n_utt * 2 * n_cols;
+    const int rc = svk_ensure_work(ctx, part_bytes + stats_bytes);
+    if (rc != SVK_OK) return rc;
+    double* part = reinterpret_cast<double*>(ctx->work);
+    double* stats = part + (size_t)n_utt * n_chunks * 2 * n_cols;
+    hipLaunchKernelGGL(cmvn_partial_kernel, dim3(n_chunks, n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols,
+                       d_n_frames, n_chunks, part);
+    SVK_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(cmvn_stats_kernel, dim3(n_utt), dim3(256), 0, ctx->stream, part, max_frames, n_cols, d_n_frames, n_chunks,
+                       variance, stats);
+    SVK_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(cmvn_apply_kernel, dim3(n_chunks, n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols,
+                       d_n_frames, stats);
+    SVK_LAUNCH_CHECK(ctx);
+    return SVK_OK;
+  }
   hipLaunchKernelGGL(cmvn_kernel, dim3(n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols, d_n_frames,
                      variance);
   SVK_LAUNCH_CHECK(ctx);

@@ -10,6 +10,8 @@
 //     records keep / segment / packed position per frame.
 // Phase 3 (all waves): kept frames are copied to the front of the clip's output slot.
 // HBM-bound: 2 bytes read per sample (+2 written when compacting).
+#include <cstdlib>
+
 #include "svk_internal.h"
 
 namespace {
@@ -199,6 +201,296 @@ __global__ __launch_bounds__(VAD_THREADS) void vad_kernel(const int16_t* __restr
   }
 }
 
+// ---- LONG clips (VoxCeleb utterances run to 145 s = 4 833 frames): one workgroup per clip leaves a batch of a few long
+// clips to a few workgroups that each stream megabytes and then walk thousands of frames (measured: 1.57 ms for 14 clips
+// of 31 .. 145 s).  The same three phases as three kernels: the frame energies and the compaction copy are cut into
+// chunks of VAD_CHUNK frames over the whole grid; only the hysteresis stays one wave per clip (it is sequential by
+// definition; ~30 scalar instructions per frame).  Flags and packed positions travel through the handle's workspace.
+// Usual geometry only (frame = one 16-byte vector per lane); anything else keeps the one-kernel path.  Bit-exact: the
+// same integer rule, the same walk. ----
+constexpr int VAD_CHUNK = 32;   // frames per workgroup: 4 waves x 8 frames in flight
+
+__global__ __launch_bounds__(VAD_THREADS) void vad_flags_kernel(const int16_t* __restrict__ pcm, const int64_t* __restrict__ offsets,
+                                                                const int32_t* __restrict__ lengths, int64_t clip_stride, int clip_len,
+                                                                int fsamp, long long threshold, int max_vf, uint8_t* __restrict__ flag_g) {
+  const int utt = blockIdx.y;
+  const int64_t off = offsets ? offsets[utt] : (int64_t)utt * clip_stride;
+  const int len = lengths ? lengths[utt] : clip_len;
+  int nf = len > 0 ? (int)((2LL * len - 1) / (2LL * fsamp)) : 0;
+  if (nf > max_vf) nf = max_vf;
+  const int f_lo = blockIdx.x * VAD_CHUNK;
+  if (f_lo >= nf) return;
+  const int16_t* x = pcm + off;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec_f = fsamp >> 3;
+  uint8_t* fl = flag_g + (int64_t)utt * max_vf;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    i16x8 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = f_lo + wave + 4 * u;
+      const bool on = f < nf && lane < nvec_f;
+      v[u] = *reinterpret_cast<const i16x8*>(x + (on ? (int64_t)f * fsamp + 8 * lane : 0));
+      if (!on) v[u] = (i16x8)(short)0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = f_lo + wave + 4 * u;
+      if (f >= nf) break;  // wave-uniform
+      long long acc = 0;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2)
+        acc += (long long)((unsigned)((int)v[u][e] * (int)v[u][e]) + (unsigned)((int)v[u][e + 1] * (int)v[u][e + 1]));
+      acc = wave_sum(acc);
+      if (lane == 0) fl[f] = acc > threshold * (long long)fsamp ? 1 : 0;
+    }
+  } else {   // a clip that does not start on a 16-byte boundary: element loads
+    for (int f = f_lo + wave; f < min(nf, f_lo + VAD_CHUNK); f += 4) {
+      const int16_t* fr = x + (int64_t)f * fsamp;
+      long long acc = 0;
+      for (int i = lane; i < fsamp; i += 64) acc += (long long)((int)fr[i] * (int)fr[i]);
+      acc = wave_sum(acc);
+      if (lane == 0) fl[f] = acc > threshold * (long long)fsamp ? 1 : 0;
+    }
+  }
+}
+
+// The hysteresis of vad.py:60-129 for one clip by one wave, WITHOUT walking the frames one by one.  Between two events the
+// collector's state is fully described by (triggered, s = the frame at which its ring was last cleared): at frame f the
+// ring holds the frames [max(s, f - ring_len + 1), f], so with P = prefix sums of the flags every lane can evaluate "does
+// the collector fire at MY frame" (voiced count > thresh when idle, unvoiced count > thresh when triggered) for 64 frames
+// at once; the first lane that fires is the next event, everything before it is bulk-marked, and the scan resumes behind
+// it with the new state.  Cost ~ (frames / 64 + events) wave steps instead of frames x ~40 scalar instructions (a 145 s
+// clip: 4 833 frames, ~0.9 ms walked one by one).  Same decisions, same order: bit-exact with vad_kernel's phase 2.
+// One wave; `flags(f)` reads frame f's flag; P: int32[nf + 1] and segm: int16[nf] scratch in LDS; returns the number of kept
+// frames; on return segm[f] = segment of a kept frame or -1, and P is free again.
+template <class FlagFn>
+__device__ __forceinline__ int vad_walk_wave(int nf, int ring_len, int ring_thresh, int lane, FlagFn flags, int32_t* P, int16_t* segm) {
+  int run = 0;
+  if (lane == 0) P[0] = 0;
+  for (int f0 = 0; f0 < nf; f0 += 64) {
+    const int f = f0 + lane;
+    const unsigned long long m = __ballot(f < nf && flags(f));
+    if (f < nf) {
+      P[f + 1] = run + __popcll(m & ((2ull << lane) - 1ull));
+      segm[f] = -1;
+    }
+    run += __popcll(m);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // one wave: LDS operations of a wave execute in order
+  __builtin_amdgcn_wave_barrier();
+  bool triggered = false;
+  int s = 0, seg = 0;
+  int f0 = 0;                                  // scan position: frames < f0 are decided
+  while (f0 < nf) {
+    const int f = f0 + lane;
+    bool fire = false;
+    if (f < nf) {
+      const int lo = max(s, f - ring_len + 1);
+      const int voiced = P[f + 1] - P[lo];
+      fire = triggered ? (f - lo + 1 - voiced) > ring_thresh : voiced > ring_thresh;
+    }
+    const unsigned long long fm = __ballot(fire);
+    const int last = min(nf, f0 + 64) - 1;     // last frame of this window
+    if (fm == 0ull) {
+      if (triggered)
+        for (int g = f0 + lane; g <= last; g += 64) segm[g] = (int16_t)seg;
+      f0 = last + 1;
+      continue;
+    }
+    const int e = f0 + __ffsll((long long)fm) - 1;   // the event frame (wave-uniform)
+    if (!triggered) {
+      // trigger: the whole ring is emitted (vad.py:105-106), then the collector keeps frames until it releases
+      const int lo = max(s, e - ring_len + 1);
+      for (int g = lo + lane; g <= e; g += 64) segm[g] = (int16_t)seg;
+      triggered = true;
+    } else {
+      // release: frames up to and including the event frame were kept (vad.py:111-123)
+      for (int g = f0 + lane; g <= e; g += 64) segm[g] = (int16_t)seg;
+      triggered = false;
+      ++seg;
+    }
+    s = e + 1;
+    f0 = e + 1;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  int kept = 0;
+  for (int g0 = 0; g0 < nf; g0 += 64) {
+    const int g = g0 + lane;
+    kept += __popcll(__ballot(g < nf && segm[g] >= 0));
+  }
+  return kept;
+}
+
+__global__ __launch_bounds__(64) void vad_walk_kernel(const int32_t* __restrict__ lengths, int clip_len, int fsamp, int ring_len,
+                                                      int ring_thresh, int max_vf, const uint8_t* __restrict__ flag_g,
+                                                      int32_t* __restrict__ pos_g, uint8_t* __restrict__ keep_out,
+                                                      int32_t* __restrict__ seg_out, int32_t* __restrict__ nvf_out,
+                                                      int32_t* __restrict__ voiced_len) {
+  __shared__ int32_t P[MAX_VAD_FRAMES + 1];   // P[f] = flags set in frames [0, f)
+  __shared__ int16_t segm[MAX_VAD_FRAMES];    // segment of a kept frame, -1 otherwise
+  const int utt = blockIdx.x, lane = threadIdx.x;
+  const int len = lengths ? lengths[utt] : clip_len;
+  int nf = len > 0 ? (int)((2LL * len - 1) / (2LL * fsamp)) : 0;
+  if (nf > max_vf) nf = max_vf;
+  const uint8_t* fl = flag_g + (int64_t)utt * max_vf;
+  vad_walk_wave(nf, ring_len, ring_thresh, lane, [&](int f) { return fl[f] != 0; }, P, segm);
+  // packed positions = exclusive prefix count of the kept frames
+  int kept = 0;
+  for (int g0 = 0; g0 < max_vf; g0 += 64) {
+    const int g = g0 + lane;
+    const bool k = g < nf && segm[g] >= 0;
+    const unsigned long long km = __ballot(k);
+    if (g < max_vf) {
+      const int pf = k ? kept + __popcll(km & ((1ull << lane) - 1ull)) : -1;
+      if (g < nf) pos_g[(int64_t)utt * max_vf + g] = pf;
+      keep_out[(int64_t)utt * max_vf + g] = k ? 1 : 0;
+      if (seg_out) seg_out[(int64_t)utt * max_vf + g] = g < nf ? (int32_t)segm[g] : -1;
+    }
+    kept += __popcll(km);
+  }
+  if (lane == 0) {
+    if (nvf_out) nvf_out[utt] = nf;
+    if (voiced_len) voiced_len[utt] = kept * fsamp;
+  }
+}
+
+// The one-kernel path for clips of at most VAD_SMALL frames (15 s of 30 ms frames: every 3 s benchmark clip): vad_kernel's
+// phases 1 and 3 with the wave-parallel walk in between and 6 KB of LDS instead of 40 (more workgroups per CU).
+constexpr int VAD_SMALL = 512;
+
+__global__ __launch_bounds__(VAD_THREADS) void vad_small_kernel(const int16_t* __restrict__ pcm, const int64_t* __restrict__ offsets,
+                                                                const int32_t* __restrict__ lengths, int64_t clip_stride,
+                                                                int clip_len, int fsamp, int ring_len, int ring_thresh,
+                                                                long long threshold, int max_vf, uint8_t* __restrict__ keep_out,
+                                                                int32_t* __restrict__ seg_out, int32_t* __restrict__ nvf_out,
+                                                                int16_t* __restrict__ voiced, int32_t* __restrict__ voiced_len) {
+  __shared__ uint8_t flag[VAD_SMALL];
+  __shared__ int32_t P[VAD_SMALL + 1];
+  __shared__ int16_t segm[VAD_SMALL];
+  __shared__ int16_t pos[VAD_SMALL];
+  const int utt = blockIdx.x;
+  const int64_t off = offsets ? offsets[utt] : (int64_t)utt * clip_stride;
+  const int len = lengths ? lengths[utt] : clip_len;
+  int nf = len > 0 ? (int)((2LL * len - 1) / (2LL * fsamp)) : 0;
+  if (nf > max_vf) nf = max_vf;                       // (max_vf <= VAD_SMALL: the host checks)
+  const int16_t* x = pcm + off;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = VAD_THREADS / 64;
+  const int nvec_f = fsamp >> 3;                      // usual geometry only (the host checks): a frame = one vector per lane
+  const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  constexpr int VU = 8;
+  for (int f0 = wave; aligned && f0 < nf; f0 += NW * VU) {
+    i16x8 v[VU];
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int f = f0 + NW * u;
+      const bool on = f < nf && lane < nvec_f;
+      v[u] = *reinterpret_cast<const i16x8*>(x + (on ? (int64_t)f * fsamp + 8 * lane : 0));
+      if (!on) v[u] = (i16x8)(short)0;
+    }
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int f = f0 + NW * u;
+      if (f >= nf) break;  // wave-uniform
+      long long acc = 0;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2)
+        acc += (long long)((unsigned)((int)v[u][e] * (int)v[u][e]) + (unsigned)((int)v[u][e + 1] * (int)v[u][e + 1]));
+      acc = wave_sum(acc);
+      if (lane == 0) flag[f] = acc > threshold * (long long)fsamp ? 1 : 0;
+    }
+  }
+  for (int f = wave; !aligned && f < nf; f += NW) {
+    const int16_t* fr = x + (int64_t)f * fsamp;
+    long long acc = 0;
+    for (int i = lane; i < fsamp; i += 64) acc += (long long)((int)fr[i] * (int)fr[i]);
+    acc = wave_sum(acc);
+    if (lane == 0) flag[f] = acc > threshold * (long long)fsamp ? 1 : 0;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    vad_walk_wave(nf, ring_len, ring_thresh, lane, [&](int f) { return flag[f] != 0; }, P, segm);
+    int kept = 0;
+    for (int g0 = 0; g0 < max_vf; g0 += 64) {
+      const int g = g0 + lane;
+      const bool k = g < nf && segm[g] >= 0;
+      const unsigned long long km = __ballot(k);
+      if (g < max_vf) {
+        if (g < nf) pos[g] = (int16_t)(k ? kept + __popcll(km & ((1ull << lane) - 1ull)) : -1);
+        keep_out[(int64_t)utt * max_vf + g] = k ? 1 : 0;
+        if (seg_out) seg_out[(int64_t)utt * max_vf + g] = g < nf ? (int32_t)segm[g] : -1;
+      }
+      kept += __popcll(km);
+    }
+    if (lane == 0) {
+      if (nvf_out) nvf_out[utt] = nf;
+      if (voiced_len) voiced_len[utt] = kept * fsamp;
+    }
+  }
+  __syncthreads();
+  if (voiced) {
+    int16_t* dst = voiced + off;
+    const bool vec_copy = aligned && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (int f0 = wave; vec_copy && f0 < nf; f0 += NW * VU) {  // eight frames' loads first, then their stores
+      i16x8 v[VU];
+      int pf[VU];
+#pragma unroll
+      for (int u = 0; u < VU; ++u) {
+        const int f = f0 + NW * u;
+        pf[u] = f < nf ? (int)pos[f] : -1;
+        if (pf[u] >= 0 && lane < nvec_f) v[u] = *reinterpret_cast<const i16x8*>(x + (int64_t)f * fsamp + 8 * lane);
+      }
+#pragma unroll
+      for (int u = 0; u < VU; ++u)
+        if (pf[u] >= 0 && lane < nvec_f) *reinterpret_cast<i16x8*>(dst + (int64_t)pf[u] * fsamp + 8 * lane) = v[u];
+    }
+    for (int f = wave; !vec_copy && f < nf; f += NW) {
+      const int pf = pos[f];
+      if (pf < 0) continue;
+      for (int i = lane; i < fsamp; i += 64) dst[(int64_t)pf * fsamp + i] = x[(int64_t)f * fsamp + i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(VAD_THREADS) void vad_copy_kernel(const int16_t* __restrict__ pcm, const int64_t* __restrict__ offsets,
+                                                               const int32_t* __restrict__ lengths, int64_t clip_stride, int clip_len,
+                                                               int fsamp, int max_vf, const int32_t* __restrict__ pos_g,
+                                                               int16_t* __restrict__ voiced) {
+  const int utt = blockIdx.y;
+  const int64_t off = offsets ? offsets[utt] : (int64_t)utt * clip_stride;
+  const int len = lengths ? lengths[utt] : clip_len;
+  int nf = len > 0 ? (int)((2LL * len - 1) / (2LL * fsamp)) : 0;
+  if (nf > max_vf) nf = max_vf;
+  const int f_lo = blockIdx.x * VAD_CHUNK;
+  if (f_lo >= nf) return;
+  const int16_t* x = pcm + off;
+  int16_t* dst = voiced + off;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec_f = fsamp >> 3;
+  const int32_t* pp = pos_g + (int64_t)utt * max_vf;
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+    i16x8 v[8];
+    int pf[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = f_lo + wave + 4 * u;
+      pf[u] = f < nf ? pp[f] : -1;
+      if (pf[u] >= 0 && lane < nvec_f) v[u] = *reinterpret_cast<const i16x8*>(x + (int64_t)f * fsamp + 8 * lane);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (pf[u] >= 0 && lane < nvec_f) *reinterpret_cast<i16x8*>(dst + (int64_t)pf[u] * fsamp + 8 * lane) = v[u];
+  } else {
+    for (int f = f_lo + wave; f < min(nf, f_lo + VAD_CHUNK); f += 4) {
+      const int pf = pp[f];
+      if (pf < 0) continue;
+      for (int i = lane; i < fsamp; i += 64) dst[(int64_t)pf * fsamp + i] = x[(int64_t)f * fsamp + i];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t* d_offsets, const int32_t* d_lengths,
@@ -216,6 +508,38 @@ extern "C" int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t*
   if (max_vad_frames > MAX_VAD_FRAMES)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "at most %d VAD frames per clip, got %d", MAX_VAD_FRAMES,
                     max_vad_frames);
+  // long clips: the three phases as three kernels cut into frame chunks (see vad_flags_kernel); SVK_VAD_SPLIT=0 / 1 forces a path
+  const char* force = getenv("SVK_VAD_SPLIT");
+  const bool usual = (frame_samples & 7) == 0 && (frame_samples >> 3) <= 64;
+  const bool split = usual && n_utt <= 65535 && (force ? force[0] == '1' : max_vad_frames > 512);
+  if (split && max_vad_frames > 0) {
+    const size_t flag_bytes = ((size_t)n_utt * max_vad_frames + 15) & ~(size_t)15;
+    const size_t pos_bytes = sizeof(int32_t) * (size_t)n_utt * max_vad_frames;
+    const int rc = svk_ensure_work(ctx, flag_bytes + pos_bytes);
+    if (rc != SVK_OK) return rc;
+    uint8_t* flag_g = reinterpret_cast<uint8_t*>(ctx->work);
+    int32_t* pos_g = reinterpret_cast<int32_t*>(flag_g + flag_bytes);
+    const dim3 grid((max_vad_frames + VAD_CHUNK - 1) / VAD_CHUNK, n_utt);
+    hipLaunchKernelGGL(vad_flags_kernel, grid, dim3(VAD_THREADS), 0, ctx->stream, d_pcm, d_offsets, d_lengths, clip_stride, clip_len,
+                       frame_samples, (long long)threshold, max_vad_frames, flag_g);
+    SVK_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(vad_walk_kernel, dim3(n_utt), dim3(64), 0, ctx->stream, d_lengths, clip_len, frame_samples, ring_len,
+                       ring_thresh, max_vad_frames, flag_g, pos_g, d_keep, d_seg, d_n_vad_frames, d_voiced_len);
+    SVK_LAUNCH_CHECK(ctx);
+    if (d_voiced) {
+      hipLaunchKernelGGL(vad_copy_kernel, grid, dim3(VAD_THREADS), 0, ctx->stream, d_pcm, d_offsets, d_lengths, clip_stride, clip_len,
+                         frame_samples, max_vad_frames, pos_g, d_voiced);
+      SVK_LAUNCH_CHECK(ctx);
+    }
+    return SVK_OK;
+  }
+  if (usual && max_vad_frames <= VAD_SMALL && !(force && force[0] == '2')) {   // (SVK_VAD_SPLIT=2 forces the general one-kernel path)
+    hipLaunchKernelGGL(vad_small_kernel, dim3(n_utt), dim3(VAD_THREADS), 0, ctx->stream, d_pcm, d_offsets, d_lengths, clip_stride,
+                       clip_len, frame_samples, ring_len, ring_thresh, (long long)threshold, max_vad_frames, d_keep, d_seg,
+                       d_n_vad_frames, d_voiced, d_voiced_len);
+    SVK_LAUNCH_CHECK(ctx);
+    return SVK_OK;
+  }
   hipLaunchKernelGGL(vad_kernel, dim3(n_utt), dim3(VAD_THREADS), 0, ctx->stream, d_pcm, d_offsets, d_lengths, clip_stride,
                      clip_len, frame_samples, ring_len, ring_thresh, (long long)threshold, max_vad_frames, d_keep,
                      d_seg, d_n_vad_frames, d_voiced, d_voiced_len);

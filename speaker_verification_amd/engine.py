@@ -176,7 +176,8 @@ class Engine:
                 raise ValueError("offsets need lengths")
             offsets = self.to_device(offsets, torch.int64)
             n_utt, stride, length = offsets.numel(), 0, 0
-            longest = int(lengths.max().item()) if n_utt else 0
+            # (a device-side max would be a host round trip per batch: only when the caller did not size the output)
+            longest = (int(lengths.max().item()) if n_utt else 0) if max_frames is None else 0
         else:
             if pcm.dim() == 1:
                 pcm = pcm[None]
@@ -352,7 +353,12 @@ class Engine:
                 raise ValueError("offsets need lengths")
             offs = self.to_device(offsets, torch.int64)
             n_utt, stride = offs.numel(), 0
-            longest = int(lens.max().item()) if n_utt else 0
+            if not n_utt:
+                longest = 0
+            elif isinstance(lengths, np.ndarray):          # host lengths: no device round trip
+                longest = int(lengths.max())
+            else:
+                longest = int(lens.max().item())
         else:
             offs = None
             if x.dim() == 1:

@@ -302,7 +302,7 @@ class VerificationPipeline:
         """Clip indices sorted by length and cut into batches of at most `micro_batch` clips and `max_batch_samples`
         samples (16-byte-aligned clip slots): a batch costs its own samples, not n x the longest clip."""
         order = sorted(range(len(lengths)), key=lambda k: int(lengths[k]))
-        pos = 0
+        pos, out = 0, []
         while pos < len(order):
             batch, total = [], 0
             while pos < len(order) and len(batch) < self.micro_batch:
@@ -312,7 +312,13 @@ class VerificationPipeline:
                 batch.append(order[pos])
                 total += n
                 pos += 1
-            yield batch, total
+            out.append((batch, total))
+        # the longest clips would otherwise end up as a batch of a handful: seven network launches and a dozen-workgroup
+        # front end for a few clips.  A last batch of fewer than 64 clips joins its predecessor (at most 1.5 x the cap).
+        if len(out) >= 2 and len(out[-1][0]) < 64 and out[-2][1] + out[-1][1] <= max_batch_samples * 3 // 2:
+            tail = out.pop()
+            out[-1] = (out[-1][0] + tail[0], out[-1][1] + tail[1])
+        return out
 
     def _embed_ragged_batch(self, dev_buf, offs, lens, rows, first_utt, voiced_out=None, spans=None):
         """One batch of clips addressed through offsets / lengths into `dev_buf` -> their embeddings (rows = the clips'
@@ -327,22 +333,19 @@ class VerificationPipeline:
             spans.append((name, a, b))
             return out
 
-        def front():
-            buf, dev_lens = dev_buf, lens
-            if self.use_vad:
-                res = self.eng.vad_energy(dev_buf, self.vad_threshold, fs=c.SAMPLE_RATE, frame_ms=c.VAD_FRAME_MS,
-                                          padding_ms=c.VAD_PADDING_MS, lengths=lens, offsets=offs, compact=True,
-                                          voiced_out=voiced_out)
-                buf, dev_lens = res["voiced"], res["voiced_len"]
-            feat, n_frames, _ = self.eng.features(buf, self.spec, lengths=dev_lens, offsets=offs,
-                                                  max_frames=self.spec.num_frames(int(np.max(lens))))
-            if self.normalize:
-                self.eng.cmvn_(feat, n_frames, variance=True)
-            # the crop draw is keyed by the clip's index in the caller's list, whatever batch it landed in
-            idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, 0, self.bad_clips,
-                                      utt_index=rows + first_utt)
-            return feat, idx
-        feat, idx = timed("front", front)
+        buf, dev_lens = dev_buf, lens
+        if self.use_vad:
+            res = timed("vad", lambda: self.eng.vad_energy(dev_buf, self.vad_threshold, fs=c.SAMPLE_RATE, frame_ms=c.VAD_FRAME_MS,
+                                                           padding_ms=c.VAD_PADDING_MS, lengths=lens, offsets=offs, compact=True,
+                                                           voiced_out=voiced_out))
+            buf, dev_lens = res["voiced"], res["voiced_len"]
+        feat, n_frames, _ = timed("frontend", lambda: self.eng.features(buf, self.spec, lengths=dev_lens, offsets=offs,
+                                                                         max_frames=self.spec.num_frames(int(np.max(lens)))))
+        if self.normalize:
+            timed("cmvn", lambda: self.eng.cmvn_(feat, n_frames, variance=True))
+        # the crop draw is keyed by the clip's index in the caller's list, whatever batch it landed in
+        idx = timed("crops", lambda: self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, 0, self.bad_clips,
+                                                         utt_index=rows + first_utt))
         return timed("network", lambda: self.embed_features(feat, idx))
 
     def embed_ragged(self, clips, max_batch_samples=64 * 1024 * 1024, first_utt=0, spans=None):
@@ -350,7 +353,7 @@ class VerificationPipeline:
         int16 arrays on the HOST.  They are sorted by length, packed back to back (16-byte aligned) into batches of
         at most `max_batch_samples` samples and `micro_batch` clips, uploaded, and addressed through the
         offsets / lengths form of the C-ABI.  Embeddings come back in the order of `clips`.  Needs crop_rng='device'.
-        `spans`: a list that receives ("front" | "network", start, end) HIP events per batch (bench.py)."""
+        `spans`: a list that receives ("vad" | "frontend" | "cmvn" | "crops" | "network", start, end) HIP events per batch (bench.py)."""
         if self.crop_rng != "device":
             raise ValueError("embed_ragged needs crop_rng='device'")
         emb = torch.empty((len(clips), 128), dtype=torch.float32, device=self.eng.device)

@@ -28,6 +28,21 @@ def eng():
     return get_engine(0)
 
 
+@pytest.fixture(params=["default path", "long-clip path forced", "general one-kernel path forced"])
+def clip_paths(request, monkeypatch):
+    """svk_vad_energy / svk_cmvn pick a multi-kernel path for long clips (chunks of a clip on separate workgroups) and
+    svk_vad_energy a small-LDS kernel for clips of at most 512 frames; the tests that take this fixture run with the
+    library's own choice, with the long-clip path forced onto short clips, and with the general one-workgroup-per-clip
+    kernels (sequential hysteresis walk; what unusual frame geometries still take)."""
+    if request.param == "long-clip path forced":
+        monkeypatch.setenv("SVK_VAD_SPLIT", "1")
+        monkeypatch.setenv("SVK_CMVN_SPLIT", "1")
+    elif request.param == "general one-kernel path forced":
+        monkeypatch.setenv("SVK_VAD_SPLIT", "2")
+        monkeypatch.setenv("SVK_CMVN_SPLIT", "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def sp():
     from speaker_verification_amd import speechpy
@@ -252,6 +267,39 @@ def test_ragged_embeddings_of_very_long_clips(eng):
         pipe.embed_ragged_resident(buf, offs + 1, np.array(lens))       # offsets must be 16-byte aligned
 
 
+def test_long_clip_paths_equal_the_one_kernel_paths(eng, monkeypatch):
+    """The multi-kernel VAD (bit for bit) and CMVN (float64 sums in another order: 1e-6) against the one-workgroup-per-clip
+    kernels on clips of 145 s, 40 s, 3 s and 0.5 s, addressed by offsets and as a padded matrix; VAD also against the oracle."""
+    lens = [145 * 16000 + 5, 40 * 16000, 48000, 8000]
+    clips = [np.concatenate([synth.speaker_clip(50 + k, u) for u in range(-(-n // 48000))])[:n] for k, n in enumerate(lens)]
+    slots = [(n + 7) // 8 * 8 for n in lens]
+    offs = np.concatenate([[0], np.cumsum(slots)[:-1]]).astype(np.int64)
+    buf = np.zeros(sum(slots), dtype=np.int16)
+    for k, x in enumerate(clips):
+        buf[offs[k]:offs[k] + x.size] = x
+    out = {}
+    for mode in ("0", "1"):     # (SVK_VAD_SPLIT=0: clips this long take the general one-kernel path)
+        monkeypatch.setenv("SVK_VAD_SPLIT", mode)
+        monkeypatch.setenv("SVK_CMVN_SPLIT", mode)
+        res = eng.vad_energy(buf, c.VAD_ENERGY_THRESHOLD, lengths=np.array(lens, dtype=np.int32), offsets=offs, want_segments=True)
+        vlen = res["voiced_len"].cpu().numpy()
+        voiced = res["voiced"].cpu().numpy()
+        feat = torch.randn((4, 14600, 40), device=eng.device, generator=torch.Generator(device=eng.device).manual_seed(1)) * 3 - 7
+        nf = np.array([14499, 3999, 297, 0], dtype=np.int32)
+        eng.cmvn_(feat, nf, variance=True)
+        out[mode] = (res["keep"].cpu().numpy(), res["seg"].cpu().numpy(), res["n_vad_frames"].cpu().numpy(), vlen,
+                     [voiced[offs[k]:offs[k] + vlen[k]] for k in range(4)], feat.cpu().numpy())
+    for a, b in zip(out["0"][:4], out["1"][:4]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(out["0"][4], out["1"][4]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(out["1"][5], out["0"][5], rtol=0, atol=2e-6)
+    for k in (0, 3):
+        keep, seg, v = vad_ref.vad_energy(clips[k], 16000, c.VAD_FRAME_MS, c.VAD_PADDING_MS, c.VAD_ENERGY_THRESHOLD)
+        np.testing.assert_array_equal(out["1"][0][k, :keep.size].astype(bool), keep)
+        np.testing.assert_array_equal(out["1"][4][k], v)
+
+
 def test_full_size_batch_properties(eng):
     """BASELINE config 2 shape (1 024 x 3 s): determinism, row independence, no NaN."""
     from speaker_verification_amd.speechpy import feature
@@ -319,7 +367,7 @@ def test_reference_own_tests(sp):
             assert hasattr(mod, name)
 
 
-def test_postprocessing(sp, golden):
+def test_postprocessing(sp, golden, clip_paths):
     g = golden["speechpy"]
     base = g["mfcc_A"]
     np.testing.assert_allclose(sp.processing.cmvn(base, False), g["cmvn_mean"], rtol=1e-5, atol=1e-5)
@@ -358,7 +406,7 @@ def test_cmvnw_derivative_batched(eng):
     assert lp.max() == 0.0
 
 
-def test_cmvn_batched_ragged(eng):
+def test_cmvn_batched_ragged(eng, clip_paths):
     rng = np.random.default_rng(3)
     feat = rng.standard_normal((5, 60, 13)).astype(np.float32) * 3 + 1
     nf = np.array([60, 1, 17, 0, 59], dtype=np.int32)
@@ -372,7 +420,7 @@ def test_cmvn_batched_ragged(eng):
 
 
 # ---- VAD: bit-exact ---------------------------------------------------------------------------------
-def test_vad_bit_exact(eng, golden):
+def test_vad_bit_exact(eng, golden, clip_paths):
     g = golden["vad"]
     thr = int(g["threshold"][0])
     clips = [synth.speaker_clip(s, u) for s, u in ((0, 0), (1, 4), (7, 2), (3, 3), (9, 1))]
@@ -396,7 +444,7 @@ def test_vad_bit_exact(eng, golden):
     np.testing.assert_array_equal(seg[2], g["spk_7_2_seg"])
 
 
-def test_vad_edge_lengths_and_long_clip(eng, golden):
+def test_vad_edge_lengths_and_long_clip(eng, golden, clip_paths):
     g = golden["vad"]
     thr = int(g["threshold"][0])
     long = synth.speaker_clip(5, 0, 112000)
@@ -470,7 +518,7 @@ def test_pipeline_properties_at_batch_scale(eng):
     assert int(res["voiced_len"].min()) > 81 * 160 + 400             # every clip keeps enough for a cube
 
 
-def test_ragged_pipeline_and_vad_offsets(eng):
+def test_ragged_pipeline_and_vad_offsets(eng, clip_paths):
     """Clips of different lengths packed back to back (offsets / lengths form of the C-ABI): VAD masks
     equal the oracle's per clip, and embed_ragged equals embedding every clip on its own."""
     from speaker_verification_amd.model import seeded_model
@@ -1084,7 +1132,7 @@ def test_pipeline_reads_int16_like_librosa(eng):
     np.testing.assert_allclose(en[0].cpu().numpy(), ref.mfe(pcm[0] / 32768.0, 16000)[1], rtol=1e-4)
 
 
-def test_vad_rings_longer_than_64_frames(eng, golden):
+def test_vad_rings_longer_than_64_frames(eng, golden, clip_paths):
     """10 ms frames with 1 s of padding = a ring of 100 frames (vad.py:81): keep / segment masks equal the
     reference's own collector (golden) and the packed samples equal the oracle's, bit for bit."""
     from speaker_verification_amd import vad
