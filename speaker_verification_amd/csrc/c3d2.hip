@@ -1025,6 +1025,17 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
       }
       fprintf(stderr, "\n");
     }
+    {   // spread over workgroups of the loop's total cycles (wave 0)
+      std::vector<double> tot;
+      for (unsigned b = 0; b < grid; ++b) {
+        double t = 0;
+        for (int k = 0; k < 6; ++k) t += (double)h[((size_t)b * n_waves) * 6 + k];
+        tot.push_back(t);
+      }
+      std::sort(tot.begin(), tot.end());
+      fprintf(stderr, "stage1 loop cycles per workgroup: min %.0f  median %.0f  p90 %.0f  max %.0f\n", tot.front(), tot[tot.size() / 2],
+              tot[tot.size() * 9 / 10], tot.back());
+    }
     if (wino && !tform) {   // in-kernel clock: median over workgroups of shader cycles per 100 MHz reference tick
       std::vector<double> mhz;
       for (unsigned b = 0; b < grid; ++b) {
@@ -1071,6 +1082,7 @@ struct Conv21Params {
   const float* slope;   // [32]
   float* out;           // [n][14][36][15][32]
   int32_t n_utt;
+  unsigned* queue;      // work-item counter (zeroed by the host before the launch), or NULL = static round-robin
 };
 
 __global__ __launch_bounds__(256, 2) void c3d2_conv21_kernel(const Conv21Params p) {
@@ -1191,7 +1203,15 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
   }
   constexpr int BLOCKS = S2_H / C21W_TH;   // 9 row blocks per cube
   const int n_items = p.n_utt * BLOCKS;
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+  // Work items come from a device-wide counter, not from a fixed stride: of the two workgroups that share a CU the older
+  // one gets about two MFMA issue slots in three, so with equal shares it finished 20 % early and its partner ran the
+  // tail alone, latency-exposed (in-kernel stamps: 1.43 M vs 1.76 M loop cycles).  The next index is requested at the
+  // top of an item (it returns during the staging) and published through LDS with the staging barrier.
+  __shared__ int q_next;
+  int item = blockIdx.x;
+  while (item < n_items) {
+    unsigned q_ticket = 0;
+    if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
     const int u = item / BLOCKS, hb = (item - u * BLOCKS) * C21W_TH;
     // stage [16 d][4 rows][18 w][16 c]: 18 16-byte pieces per thread, six in flight at a time
     const float* src = p.in + (int64_t)u * (S2_D * S2_H * S2_W * 16);
@@ -1214,7 +1234,9 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
         *reinterpret_cast<f32x4*>(reg + 16 * pix + 4 * (pix >> 2) + 4 * piece) = sv[k];
       }
     }
+    if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + (int)gridDim.x : item + (int)gridDim.x;
     __syncthreads();
+    const int item_next = q_next;
     // M tiles = (pair P, row hl): 16 pixels w' = 0 .. 15 (15 is a dummy), tile = 4 P + hl
 #pragma unroll 1
     for (int tile = wave; tile < 7 * C21W_TH; tile += 4) {
@@ -1282,6 +1304,7 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
       }
     }
     __syncthreads();
+    item = item_next;
   }
 }
 
@@ -1298,6 +1321,7 @@ struct Conv22Params {
   float* out;           // [n][12][15][7][32]
   int32_t n_utt;
   unsigned long long* stamps;   // tuning builds only: [grid][4 waves][4] summed phase cycles
+  unsigned* queue;              // work-item counter (zeroed before the launch), or NULL
 };
 
 __global__ __launch_bounds__(256, 2) void c3d2_conv22_kernel(const Conv22Params p) {
@@ -1434,7 +1458,16 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
   const float* const a0 = reg + 68 * i + 4 * kk + 16 * ch;   // row 2 i of column 0 of plane 0, this lane's K piece
   constexpr int PER_CUBE = O2_W * (O2_D / C22W_TD);           // 7 x 3 items
   const int n_items = p.n_utt * PER_CUBE;
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+#ifdef SVK_TUNING
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  __shared__ int q_next;   // dynamic work items: see c3d2_conv21w_kernel
+  int item = blockIdx.x;
+  while (item < n_items) {
+    SVK_STAMP(ts0);
+    unsigned q_ticket = 0;
+    if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
     const int u = item / PER_CUBE, rem = item - u * PER_CUBE, q = rem / O2_W, j = rem - q * O2_W;
     // stage [6 d][36 h][2 w][32 c] of the input as pixels p = (dl * 2 + w) * 36 + h (h fastest): 13.5 16-byte pieces per
     // thread, seven in flight at a time
@@ -1458,7 +1491,11 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
         if (e < C22W_PIX * 8) *reinterpret_cast<f32x4*>(reg + 32 * pix + 4 * (pix >> 1) + 4 * piece) = sv[k];
       }
     }
+    SVK_STAMP(ts1);
+    if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + (int)gridDim.x : item + (int)gridDim.x;
     __syncthreads();
+    SVK_STAMP(ts2);
+    const int item_next = q_next;
     f32x4 own[2][2];   // [column][y]: the partial sums of the pair this wave finishes
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -1514,7 +1551,13 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
         }
       }
     }
+    SVK_STAMP(ts3);
     __syncthreads();   // the partner's partial sums are in LDS; nobody reads the input region any more
+    SVK_STAMP(ts4);
+    SVK_STAMP_ADD(0, ts0, ts1);  // staging
+    SVK_STAMP_ADD(1, ts1, ts2);  // barrier 1
+    SVK_STAMP_ADD(2, ts2, ts3);  // 2 passes x 2 tiles of 8 taps x 16 MFMAs + transforms + exchange writes
+    SVK_STAMP_ADD(3, ts3, ts4);  // barrier 2 (the epilogue that follows is counted with the next item's staging)
     {
       const float* xi = exch + ((((nt * 2 + ch) * 2) * 2) * 64 + lane) * 4;   // pair ch, written by wave (nt, 1 - ch)
 #pragma unroll
@@ -1531,7 +1574,17 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
         }
       }
     }
+    item = item_next;
   }
+#ifdef SVK_TUNING
+  if (p.stamps && lane == 0) {
+    for (int k = 0; k < 2; ++k) p.stamps[((size_t)blockIdx.x * 4 + wave) * 4 + k] = stamp_acc[k];
+    p.stamps[((size_t)blockIdx.x * 4 + wave) * 4 + 2] = stamp_acc[2] + stamp_acc[3];   // (MFMA passes + barrier 2 in one slot;
+    // slot 3 of wave 0 / 1 carries the clock pair: shader cycles and 100 MHz ticks over the loop)
+    p.stamps[((size_t)blockIdx.x * 4 + wave) * 4 + 3] = wave == 0 ? __builtin_amdgcn_s_memtime() - clk_c0
+                                                                    : wave == 1 ? __builtin_amdgcn_s_memrealtime() - clk_r0 : 0ull;
+  }
+#endif
 }
 
 // ---- conv3_1 (32 -> 64, kernel (3,1,3)) + BN + PReLU (model.py:126-128, :159-161), depth-transformed like the kernels
@@ -1552,6 +1605,7 @@ struct Conv31Params {
   const float* slope;   // [64]
   float* out;           // [n][10][15][5][64]
   int32_t n_utt;
+  unsigned* queue;      // work-item counter (zeroed before the launch), or NULL
 };
 
 template <bool SLOPE01>
@@ -1577,7 +1631,11 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
   const int mi = i < 15 ? i : 14;
   const float* const a0 = reg + C31_PIXF * ((mi / 5) * 7 + mi % 5) + 4 * kk;
   const int n_items = p.n_utt * 5;
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+  __shared__ int q_next;   // dynamic work items: see c3d2_conv21w_kernel (three workgroups share a CU here)
+  int item = blockIdx.x;
+  while (item < n_items) {
+    unsigned q_ticket = 0;
+    if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
     const int u = item / 5, rb = item - u * 5;
     // stage [12 d][3 rows][7 w][32 c]: per depth 672 contiguous floats = 168 sixteen-byte pieces; 2 016 in all, eight
     // per thread, four in flight at a time (168 VGPRs at three workgroups per CU)
@@ -1598,7 +1656,9 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
         if (e < 2016) *reinterpret_cast<f32x4*>(reg + C31_PIXF * (d * 21 + (r >> 3)) + 4 * (r & 7)) = sv[k];
       }
     }
+    if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + (int)gridDim.x : item + (int)gridDim.x;
     __syncthreads();
+    const int item_next = q_next;
 #pragma unroll 1
     for (int P = 0; P < 5; ++P) {
       const float* ap = a0 + 2 * C31_PLANE * P;
@@ -1649,6 +1709,7 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
       }
     }
     __syncthreads();
+    item = item_next;
   }
 }
 
@@ -1832,8 +1893,13 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
               "buffers must be 16-byte aligned");
   SVK_REQUIRE(ctx, (int64_t)n_utt * 21 < ((int64_t)1 << 31), "too many cubes for one launch");
   {
-    Conv21Params p{d_in, reinterpret_cast<const f32x4*>(d_w21frag), d_bias21, d_slope21, d_act2, n_utt};
+    // work-item counters of the kernels that share a CU between workgroups (slots of the handle's 256-byte scratch; svk_log_power
+    // owns the first word): zeroed in stream order before the launches
+    static const bool static_items = getenv("SVK_C3D2_STATIC_ITEMS") != nullptr;
+    unsigned* const queues = static_items ? nullptr : reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 64);
+    if (queues) SVK_HIP(ctx, hipMemsetAsync(queues, 0, 16, ctx->stream));
     const bool wino = (flags & 1) != 0;   // conv2_1 through the depth transform
+    Conv21Params p{d_in, reinterpret_cast<const f32x4*>(d_w21frag), d_bias21, d_slope21, d_act2, n_utt, wino ? queues : nullptr};
     void (*kern)(const Conv21Params) = !wino ? c3d2_conv21_kernel
                                        : (flags & 2) ? c3d2_conv21w_kernel<true> : c3d2_conv21w_kernel<false>;
     const size_t lds = sizeof(float) * (size_t)(wino ? C21W_LDS_FLOATS : C21_LDS_FLOATS);
@@ -1851,7 +1917,9 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     SVK_LAUNCH_CHECK(ctx);
   }
   {
-    Conv22Params p{d_act2, reinterpret_cast<const f32x4*>(d_w22frag), d_bias22, d_slope22, d_out, n_utt, nullptr};
+    static const bool static_items22 = getenv("SVK_C3D2_STATIC_ITEMS") != nullptr;
+    Conv22Params p{d_act2, reinterpret_cast<const f32x4*>(d_w22frag), d_bias22, d_slope22, d_out, n_utt, nullptr,
+                   (flags & 4) && !static_items22 ? reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 68) : nullptr};
     if (flags & 4) {   // conv2_2 through the depth transform
       void (*kern)(const Conv22Params) = (flags & 2) ? c3d2_conv22w_kernel<true> : c3d2_conv22w_kernel<false>;
       const size_t lds = sizeof(float) * (size_t)C22W_LDS_FLOATS;
@@ -1864,9 +1932,54 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess ||
           per_cu < 1)
         per_cu = 2;
-      hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(256), lds,
-                         ctx->stream, p);
+      const unsigned gridw = (unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu);
+#ifdef SVK_TUNING
+      const bool want_stamps_w = getenv("SVK_C3D2_STAMPS") != nullptr;
+      const size_t stamp_bytes_w = (size_t)gridw * 4 * 4 * sizeof(unsigned long long);
+      if (want_stamps_w) {
+        const int rc = svk_ensure_work(ctx, stamp_bytes_w);
+        if (rc != SVK_OK) return rc;
+        p.stamps = reinterpret_cast<unsigned long long*>(ctx->work);
+      }
+#endif
+      hipLaunchKernelGGL(kern, dim3(gridw), dim3(256), lds, ctx->stream, p);
       SVK_LAUNCH_CHECK(ctx);
+#ifdef SVK_TUNING
+      if (want_stamps_w) {
+        std::vector<unsigned long long> h((size_t)gridw * 16);
+        SVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SVK_HIP(ctx, hipMemcpy(h.data(), p.stamps, stamp_bytes_w, hipMemcpyDeviceToHost));
+        const char* names[4] = {"staging (+ previous epilogue)", "barrier 1", "MFMA passes + exchange + barrier 2", ""};
+        const double per = (double)items / gridw;
+        {
+          std::vector<double> mhz;
+          for (unsigned b = 0; b < gridw; ++b) {
+            const unsigned long long c = h[((size_t)b * 4 + 0) * 4 + 3], r = h[((size_t)b * 4 + 1) * 4 + 3];
+            if (r) mhz.push_back(100.0 * (double)c / (double)r);
+          }
+          if (!mhz.empty()) {
+            std::sort(mhz.begin(), mhz.end());
+            fprintf(stderr, "conv22w in-kernel clock: median %.0f MHz (min %.0f, max %.0f)\n", mhz[mhz.size() / 2], mhz.front(), mhz.back());
+          }
+        }
+        {   // spread over workgroups of the loop's total cycles (wave 0): static item assignment makes the slowest one the kernel's time
+          std::vector<double> tot;
+          for (unsigned b = 0; b < gridw; ++b) tot.push_back((double)(h[(size_t)b * 16 + 0] + h[(size_t)b * 16 + 1] + h[(size_t)b * 16 + 2]));
+          std::sort(tot.begin(), tot.end());
+          fprintf(stderr, "conv22w loop cycles per workgroup: min %.0f  median %.0f  p90 %.0f  max %.0f\n", tot.front(), tot[tot.size() / 2],
+                  tot[tot.size() * 9 / 10], tot.back());
+        }
+        for (int w = 0; w < 4; ++w) {
+          fprintf(stderr, "conv22w stamps wave %d (cycles per item, %d workgroups per CU):", w, per_cu);
+          for (int k = 0; k < 3; ++k) {
+            double sum = 0;
+            for (unsigned b = 0; b < gridw; ++b) sum += (double)h[((size_t)b * 4 + w) * 4 + k];
+            fprintf(stderr, "  %s %.0f", names[k], sum / gridw / per);
+          }
+          fprintf(stderr, "\n");
+        }
+      }
+#endif
       return SVK_OK;
     }
     const size_t lds = sizeof(float) * (size_t)C22_LDS_FLOATS;
@@ -1923,7 +2036,10 @@ extern "C" int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_wfrag)) & 15) == 0,
               "buffers must be 16-byte aligned");
   SVK_REQUIRE(ctx, (int64_t)n_utt * 5 < ((int64_t)1 << 31), "too many cubes for one launch");
-  Conv31Params p{d_in, reinterpret_cast<const f32x4*>(d_wfrag), d_bias, d_slope, d_out, n_utt};
+  static const bool static_items31 = getenv("SVK_C3D2_STATIC_ITEMS") != nullptr;
+  unsigned* const queue31 = static_items31 ? nullptr : reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 80);
+  if (queue31) SVK_HIP(ctx, hipMemsetAsync(queue31, 0, 4, ctx->stream));
+  Conv31Params p{d_in, reinterpret_cast<const f32x4*>(d_wfrag), d_bias, d_slope, d_out, n_utt, queue31};
   void (*kern)(const Conv31Params) = (flags & 2) ? c3d2_conv31w_kernel<true> : c3d2_conv31w_kernel<false>;
   const size_t lds = sizeof(float) * (size_t)C31_LDS_FLOATS;
   if (lds > (size_t)ctx->lds_per_cu)

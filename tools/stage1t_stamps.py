@@ -37,3 +37,13 @@ for kw in (dict(depth_transform=True), dict(depth_transform=True, merged_tiles=T
     os.environ["SVK_C3D2_STAMPS"] = "1"
     eng.c3d2_stage1(feat, crops, t1, folded=False, **kw)
     torch.cuda.synchronize()
+
+# second block: conv2_2's phases (conv22w stamps)
+t2 = emb.stage2_tables()
+y = eng.c3d2_stage1(feat, crops, t1, folded=False, depth_transform=True, merged_tiles=True)
+os.environ.pop("SVK_C3D2_STAMPS", None)
+for _ in range(700):                           # ~1 s of back-to-back launches
+    eng.c3d2_stage2(y, t2, depth_transform=True)
+os.environ["SVK_C3D2_STAMPS"] = "1"
+eng.c3d2_stage2(y, t2, depth_transform=True)
+torch.cuda.synchronize()
