@@ -176,11 +176,10 @@ class VerificationPipeline:
         tables = self.embedder.stage1_tables() if (self.embedder is not None and self.stage1_kernel) else None
         if tables is not None and feat.shape[2] == c.NUM_COEF and crop_idx.shape[1] == c.CUBE_CROPS:
             # conv1_1 .. pool1 in one libsvk kernel (csrc/c3d2.hip): the cube and conv1_1's 3.3 MB-per-cube output
-            # never reach HBM; PyTorch-ROCm runs the remaining six convolutions and the FC layer
+            # never reach HBM
             tables2 = self.embedder.stage2_tables() if self.stage2_kernel else None
             if tables2 is not None:
-                # ... and conv2_1, conv2_2, pool2 in two more (conv3_1, conv3_2 follow inside from_stage2): PyTorch-ROCm
-                # runs conv4_1 .. FC5
+                # ... and conv2_1, conv2_2, pool2 in two more; conv3_1 .. FC5 follow inside from_stage2 (libsvk too)
                 spans = {"cubes": feat.shape[0]} if self.kernel_events is not None else None
 
                 def timed(name, fn):
