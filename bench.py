@@ -913,6 +913,9 @@ def main():
                 elif name == "stage1" and getattr(pipe, "stage1_merged", False):
                     # round 3: 36 items x (400 conv1_1 + 18 tiles x 144 conv1_2): the remainder rows of two depth pairs share a tile
                     symbols, mfma_design = ("c3d2_stage1w_kernel<merged>",), 36 * (400 + 18 * 144)
+                if name == "conv3_2" and getattr(pipe.embedder, "conv32t_kernel", False):
+                    # conv3_2 in the last block's shape: 20 items x 8 chunks x 28 steps x 18 MFMAs x 4 waves per 16 cubes, no padding
+                    symbols, mfma_design = ("c3d2_tail_kernel<Conv32T>",), 20160
                 evs = [sp[name] for sp in kernel_events if name in sp]
                 if not evs:
                     continue

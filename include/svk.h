@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 104 /* 0.1.3: svk_c3d2_conv41 / conv42 / fc5 */
+#define SVK_VERSION 105 /* 0.1.4: + svk_c3d2_conv32t */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -297,6 +297,8 @@ int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float*
  *   d_out   [n_utt][8][9][5][64]     channels last                                                                    */
 int svk_c3d2_conv32(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);
+/* (flags bit 3 of svk_c3d2_conv31: write d_out chunked and column-major, [n_utt][10 d][8 chunks of 8 channels][5 w][15 h][8] --
+ * the layout svk_c3d2_conv32t stages from)                                                                              */
 /* (flags bit 3 of svk_c3d2_conv32: write d_out CHUNKED, [n_utt][8 d][8 chunks of 8 channels][45 = 9 h x 5 w][8] -- the
  * layout svk_c3d2_conv41 stages from: a chunk of a plane is contiguous)                                              */
 
@@ -319,6 +321,12 @@ int svk_c3d2_conv32(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float*
  *                    added in a fixed order: bitwise repeatable);  d_out [n_utt][128]                                  */
 int svk_c3d2_conv41(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);
+/* conv3_2 in the shape of the last block (the default since round 3; svk_c3d2_conv32 above is the round-2 kernel, kept for A/B):
+ *   d_in    [n_utt][10][8][5][15][8] = svk_c3d2_conv31's output with flags bit 3
+ *   d_wfrag [4 nt][8 chunks][7 kh][4 k][64][2] (host-transformed G, as for svk_c3d2_conv41);  d_bias / d_slope [64]
+ *   d_out   [n_utt][8][8][45][8]     = what svk_c3d2_conv41 takes                                                       */
+int svk_c3d2_conv32t(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
+                     const float* d_slope, int32_t flags, float* d_out);
 int svk_c3d2_conv42(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);
 size_t svk_c3d2_fc5_workspace_floats(int32_t n_utt);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsvk.so")
 
 SVK_OK = 0
-VERSION = 104                      # include/svk.h SVK_VERSION
+VERSION = 105                      # include/svk.h SVK_VERSION
 SVK_ERR_BAD_ARG, SVK_ERR_UNSUPPORTED, SVK_ERR_HIP, SVK_ERR_NO_DEVICE, SVK_ERR_OOM, SVK_ERR_RCCL = -1, -2, -3, -4, -5, -6
 OUT_MFE, OUT_LMFE, OUT_MFCC = 0, 1, 2
 PCM_I16, PCM_F32 = 0, 1
@@ -80,6 +80,7 @@ SIGNATURES = {
     "svk_c3d2_stage2": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "svk_c3d2_conv31": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_conv32": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "svk_c3d2_conv32t": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_conv41": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_conv42": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_fc5_workspace_floats": (C.c_size_t, [_i32]),

@@ -1603,12 +1603,13 @@ struct Conv31Params {
   const f32x4* wfrag;   // [4 nt][9 taps][2 chunks][64]: e: W[16 nt + (l & 15)][16 chunk + 4 (l >> 4) + e][kd][kw], tap = 3 kd + kw
   const float* bias;    // [64]
   const float* slope;   // [64]
-  float* out;           // [n][10][15][5][64]
+  float* out;           // [n][10][15][5][64], or chunked and column-major: [n][10][8 chunks][5 w][15 h][8] (what svk_c3d2_conv32t stages)
   int32_t n_utt;
   unsigned* queue;      // work-item counter (zeroed before the launch), or NULL
+  int32_t chunked;
 };
 
-template <bool SLOPE01>
+template <bool SLOPE01, bool CHUNKED>
 __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem_c31[];
   float* reg = smem_c31;
@@ -1689,8 +1690,10 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
         __builtin_amdgcn_sched_barrier(0);
       }
       // rows 4 kk + r = position m -> (row 3 rb + m / 5, column m % 5); column i = channel 16 nt + i; depths 2 P, 2 P + 1
-      float* const o = p.out + (((int64_t)u * 10 + 2 * P) * 15 + 3 * rb) * (5 * 64) + 16 * nt;   // wave-uniform
-      const int olane = 4 * kk * 64 + i;
+      float* const o = CHUNKED ? p.out + (((int64_t)u * 10 + 2 * P) * 8 + 2 * nt) * (5 * 15 * 8)
+                               : p.out + (((int64_t)u * 10 + 2 * P) * 15 + 3 * rb) * (5 * 64) + 16 * nt;   // wave-uniform
+      const int olane = CHUNKED ? (i >> 3) * (5 * 15 * 8) + (i & 7) + 3 * rb * 8 : 4 * kk * 64 + i;
+      constexpr int ostep = CHUNKED ? 8 * 5 * 15 * 8 : 15 * 5 * 64;   // one output depth further
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const f32x2 c0 = hf ? __builtin_shufflevector(acc[0], acc[0], 2, 3) : __builtin_shufflevector(acc[0], acc[0], 0, 1);
@@ -1702,8 +1705,16 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
         for (int q = 0; q < 2; ++q) {
           const int m = 4 * kk + 2 * hf + q;
           if (m < 15) {
-            o[olane + (2 * hf + q) * 64] = prelu_t<SLOPE01>(y0[q], sl);    // positions are contiguous: (row, column) = m
-            o[15 * 5 * 64 + olane + (2 * hf + q) * 64] = prelu_t<SLOPE01>(y1[q], sl);
+            // channels last: positions are contiguous, (row, column) = m; chunked: column m % 5 outermost, then row m / 5:
+            // (m % 5) * 15 + m / 5 for m = 4 kk + r as byte kk of a per-r constant (a division per store cost 10 % of the kernel)
+            int kk_e = kk;
+            if (CHUNKED) asm volatile("" : "+v"(kk_e));   // (keeps the eight per-lane offsets out of registers this kernel spills)
+            auto cpos = [](int m2) { return (m2 % 5) * 15 + m2 / 5; };
+            const unsigned tab = (unsigned)cpos(2 * hf + q) | ((unsigned)cpos(4 + 2 * hf + q) << 8) |
+                                 ((unsigned)cpos(8 + 2 * hf + q) << 16) | ((unsigned)cpos(12 + 2 * hf + q < 15 ? 12 + 2 * hf + q : 0) << 24);
+            const int opos = CHUNKED ? (int)((tab >> (8 * kk_e)) & 255u) * 8 : (2 * hf + q) * 64;
+            o[olane + opos] = prelu_t<SLOPE01>(y0[q], sl);
+            o[ostep + olane + opos] = prelu_t<SLOPE01>(y1[q], sl);
           }
         }
       }
@@ -2039,8 +2050,9 @@ extern "C" int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   static const bool static_items31 = getenv("SVK_C3D2_STATIC_ITEMS") != nullptr;
   unsigned* const queue31 = static_items31 ? nullptr : reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 80);
   if (queue31) SVK_HIP(ctx, hipMemsetAsync(queue31, 0, 4, ctx->stream));
-  Conv31Params p{d_in, reinterpret_cast<const f32x4*>(d_wfrag), d_bias, d_slope, d_out, n_utt, queue31};
-  void (*kern)(const Conv31Params) = (flags & 2) ? c3d2_conv31w_kernel<true> : c3d2_conv31w_kernel<false>;
+  Conv31Params p{d_in, reinterpret_cast<const f32x4*>(d_wfrag), d_bias, d_slope, d_out, n_utt, queue31, (flags & 8) ? 1 : 0};
+  void (*kern)(const Conv31Params) = (flags & 8) ? ((flags & 2) ? c3d2_conv31w_kernel<true, true> : c3d2_conv31w_kernel<false, true>)
+                                                 : ((flags & 2) ? c3d2_conv31w_kernel<true, false> : c3d2_conv31w_kernel<false, false>);
   const size_t lds = sizeof(float) * (size_t)C31_LDS_FLOATS;
   if (lds > (size_t)ctx->lds_per_cu)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_conv31 needs %zu bytes of LDS per workgroup (device: %d)", lds,

@@ -29,6 +29,7 @@
 // LDS: a cube's chunk sits at a stride = 4 (mod 64) floats: the 32 lanes of a ds_read_b64 group (16 cubes x 2 K pairs)
 // then fall into 32 different 8-byte slots -- conflict-free by the lane-group table of MI355X_MICROARCH.md (LDS).
 #include <algorithm>
+#include <cstdlib>
 
 #include "svk_internal.h"
 
@@ -45,7 +46,6 @@ __device__ __forceinline__ float prelu_t(float v, float slope) {
 
 constexpr int GROUP = 16;   // cubes per work item = rows of an M tile
 constexpr int NT = 9;       // M tiles (output positions) per work item
-constexpr int TAIL_THREADS = 512;
 
 // conv4_1: input [n][8 d][8 chunks][45 = 9 h x 5 w][8] (svk_c3d2_conv32 with the chunked-output flag), output
 // [n][6 d][16 chunks][27 = 9 h x 3 w][8].  Item = (group, pair P of 3, row block rb of 3): rows 3 rb .. 3 rb + 2, taps along w.
@@ -55,9 +55,10 @@ struct Conv41 {
   static constexpr int D_OUT = 6, PIX_OUT = 27;
   static constexpr int SC = 2;                         // chunks per phase (between two barriers)
   static constexpr int PAIRS = 3, BLOCKS = 3;
+  static constexpr int NWAVES = 8;                     // N tiles = waves per workgroup (128 output channels), one workgroup per CU
   __device__ static constexpr int pix0(int p) { return 5 * (p / 3) + p % 3; }   // tile p = (row hl, column w') -> staged pixel
   __device__ static int in_pix_start(int blk) { return 15 * blk; }
-  __device__ static int out_pix_start(int blk) { return 9 * blk; }
+  __device__ static int out_pix(int t, int blk) { return 9 * blk + t; }          // output pixel of tile t
 };
 // conv4_2: input = conv4_1's output, output [n][4 d][16 chunks][9 = 3 h x 3 w][8].  Item = (group, pair P of 2), taps along h.
 struct Conv42 {
@@ -66,9 +67,27 @@ struct Conv42 {
   static constexpr int D_OUT = 4, PIX_OUT = 9;
   static constexpr int SC = 1;
   static constexpr int PAIRS = 2, BLOCKS = 1;
+  static constexpr int NWAVES = 8;
   __device__ static constexpr int pix0(int p) { return p; }
   __device__ static int in_pix_start(int) { return 0; }
-  __device__ static int out_pix_start(int) { return 0; }
+  __device__ static int out_pix(int t, int) { return t; }
+};
+// conv3_2 (64 -> 64, kernel (3,7,1); model.py:129-131, :162-164) in the same shape: input = svk_c3d2_conv31's output in its
+// chunked, column-major form [n][10 d][8 chunks][5 w][15 h][8] (flags bit 3 there), output [n][8 d][8 chunks][45 = 9 h x 5 w][8]
+// = what conv4_1 stages from.  Item = (group, pair P of 4, column w of 5): 9 output rows = 9 tiles, taps along h = a shift of one
+// staged pixel.  N = 64: four waves per workgroup, TWO workgroups per CU (66 KB of LDS each).  Against the round-2 kernel
+// (c3d2_conv32w_kernel: transform per fragment read, 45 positions padded to 48, 41 % LDS bank conflicts): no VALU in the
+// loop, no padding.
+struct Conv32T {
+  static constexpr int TAPS = 7, TAP_PIX = 1;
+  static constexpr int D_IN = 10, NCHUNK = 8, PIX_IN = 75, PIXN = 15;
+  static constexpr int D_OUT = 8, PIX_OUT = 45;
+  static constexpr int SC = 1;
+  static constexpr int PAIRS = 4, BLOCKS = 5;
+  static constexpr int NWAVES = 4;
+  __device__ static constexpr int pix0(int p) { return p; }
+  __device__ static int in_pix_start(int blk) { return 15 * blk; }
+  __device__ static int out_pix(int t, int blk) { return 5 * t + blk; }
 };
 
 template <class L>
@@ -77,13 +96,15 @@ struct TailGeom {
   static constexpr int CS = 4 * PLANE + ((4 - (4 * PLANE) % 64) + 64) % 64;   // cube stride = 4 (mod 64) floats
   static constexpr int SUB = GROUP * CS;                                      // floats per staged chunk
   static constexpr int BUF = L::SC * SUB;                                     // floats per LDS buffer
+  static constexpr int THREADS = 64 * L::NWAVES;
+  static constexpr int OUT_CHUNKS = 2 * L::NWAVES;                            // 8-channel chunks of the output
   static constexpr int UNITS = L::SC * GROUP * L::PIXN * 2;                   // 16-byte (cube, pixel, half chunk) pieces per phase
-  static constexpr int ROUNDS = (UNITS + TAIL_THREADS - 1) / TAIL_THREADS;
+  static constexpr int ROUNDS = (UNITS + THREADS - 1) / THREADS;
   static constexpr int NPH = L::NCHUNK / L::SC;                               // phases per item
   static constexpr int STEPS = L::SC * L::TAPS * 4;                           // (chunk, tap, k) steps per phase
   static constexpr int ITEMS_PER_GROUP = L::PAIRS * L::BLOCKS;
   static constexpr int64_t IN_CUBE = (int64_t)L::D_IN * L::NCHUNK * L::PIX_IN * 8;
-  static constexpr int64_t OUT_CUBE = (int64_t)L::D_OUT * 16 * L::PIX_OUT * 8;
+  static constexpr int64_t OUT_CUBE = (int64_t)L::D_OUT * OUT_CHUNKS * L::PIX_OUT * 8;
   static_assert(CS % 64 == 4, "cube stride");
   static_assert(ROUNDS == 2, "the staging schedule below is written for two rounds");
   static_assert(SUB * 4 <= 65532, "fragment offsets inside a staged chunk must fit the DS instruction's 16-bit field");
@@ -91,17 +112,20 @@ struct TailGeom {
 
 struct TailParams {
   const float* in;
-  const f32x2* wfrag;   // [8 nt][NCHUNK][TAPS][4 k][64 lanes]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: G_k[co][8 chunk + 2 kk + e][tap]
-  const float* bias;    // [128]
-  const float* slope;   // [128]
+  const f32x2* wfrag;   // [nt][NCHUNK][TAPS][4 k][64 lanes]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: G_k[co][8 chunk + 2 kk + e][tap]
+  const float* bias;    // [16 x N tiles]
+  const float* slope;
   float* out;
   int32_t n_utt;
+  unsigned* queue;      // work-item counter (zeroed before the launch) where workgroups share a CU, or NULL = fixed stride
 };
 
 template <class L, bool SLOPE01>
-__global__ __launch_bounds__(TAIL_THREADS) void c3d2_tail_kernel(const TailParams p) {
+__global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const TailParams p) {
   using G = TailGeom<L>;
+  constexpr int TAIL_THREADS = G::THREADS;
   extern __shared__ __attribute__((aligned(16))) float smem_tail[];
+  __shared__ int q_next;
   const int lane = threadIdx.x & 63, nt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
   const float b = p.bias[16 * nt + i], sl = p.slope[16 * nt + i];
@@ -165,7 +189,17 @@ __global__ __launch_bounds__(TAIL_THREADS) void c3d2_tail_kernel(const TailParam
   f32x4 acc[NT][4];
   int buf_sel = 0;
   f32x2 b0 = wb[0], b1 = wb[64];
-  for (; item < n_items; item += gridDim.x) {
+  // the item after this one: a fixed stride, or (workgroups sharing a CU: see c3d2_conv21w_kernel) a ticket of the device-wide
+  // counter drawn one item ahead -- the staging of an item's last phase already needs to know its successor
+  int item_next = item + (int)gridDim.x;
+  if (p.queue) {
+    if (threadIdx.x == 0) q_next = (int)atomicAdd(p.queue, 1u) + (int)gridDim.x;
+    __syncthreads();
+    item_next = q_next;
+  }
+  while (item < n_items) {
+    unsigned q_ticket = 0;
+    if (p.queue && threadIdx.x == 0) q_ticket = atomicAdd(p.queue, 1u);   // for the item after next; published below
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -174,7 +208,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void c3d2_tail_kernel(const TailParam
     for (int ph = 0; ph < G::NPH; ++ph) {
       // what the NEXT phase stages (the next item's first phase behind this item's last)
       const bool last_ph = ph + 1 == G::NPH;
-      const int n_item = last_ph ? item + (int)gridDim.x : item, n_ph = last_ph ? 0 : ph + 1;
+      const int n_item = last_ph ? item_next : item, n_ph = last_ph ? 0 : ph + 1;
       const bool have_next = n_item < n_items;
       const float* nsrc = p.in;
       int nlim = 0;
@@ -223,6 +257,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void c3d2_tail_kernel(const TailParam
       __syncthreads();   // the next chunk is parked; this one may be overwritten by the phase after next
       buf_sel ^= 1;
     }
+    int item_after = item_next + (int)gridDim.x;
+    if (p.queue) {
+      // (the phase loop above ended with a barrier: q_next's previous value has been read by every thread)
+      if (threadIdx.x == 0) q_next = (int)q_ticket + (int)gridDim.x;
+    }
     // ---- output transform, PReLU, stores: rows 4 kk + r = cube, column i = channel 16 nt + i ----
     {
       const int g = item / G::ITEMS_PER_GROUP, rem = item - g * G::ITEMS_PER_GROUP;
@@ -230,19 +269,27 @@ __global__ __launch_bounds__(TAIL_THREADS) void c3d2_tail_kernel(const TailParam
       const int n_here = min(GROUP, p.n_utt - GROUP * g);
       // chunked output: [cube][depth][chunk = 2 nt + (i >> 3)][pixel][i & 7]
       float* const o = p.out + (int64_t)g * GROUP * G::OUT_CUBE +
-                       ((int64_t)(2 * P) * 16 + 2 * nt) * (L::PIX_OUT * 8) + L::out_pix_start(blk) * 8;   // wave-uniform
+                       ((int64_t)(2 * P) * G::OUT_CHUNKS + 2 * nt) * (L::PIX_OUT * 8);   // wave-uniform
       const int olane = 4 * kk * (int)G::OUT_CUBE + (i >> 3) * (L::PIX_OUT * 8) + (i & 7);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const f32x4 y0 = acc[t][0] + acc[t][1] + acc[t][2], y1 = acc[t][1] - acc[t][2] - acc[t][3];
+        const int opix = L::out_pix(t, blk) * 8;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (4 * kk + r < n_here) {
-            o[olane + r * (int)G::OUT_CUBE + t * 8] = prelu_t<SLOPE01>(y0[r], sl);
-            o[olane + r * (int)G::OUT_CUBE + t * 8 + 16 * L::PIX_OUT * 8] = prelu_t<SLOPE01>(y1[r], sl);
+            o[olane + r * (int)G::OUT_CUBE + opix] = prelu_t<SLOPE01>(y0[r], sl);
+            o[olane + r * (int)G::OUT_CUBE + opix + G::OUT_CHUNKS * L::PIX_OUT * 8] = prelu_t<SLOPE01>(y1[r], sl);
           }
         }
       }
+    }
+    item = item_next;
+    if (p.queue) {
+      __syncthreads();               // q_next (written before the epilogue) is visible
+      item_next = q_next;
+    } else {
+      item_next = item_after;
     }
   }
 }
@@ -261,11 +308,22 @@ int launch_tail(svk_ctx* ctx, const char* name, const float* d_in, int32_t n_utt
   const size_t lds = sizeof(float) * (size_t)(2 * G::BUF);
   if (lds > (size_t)ctx->lds_per_cu)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS per workgroup (device: %d)", name, lds, ctx->lds_per_cu);
-  TailParams p{d_in, reinterpret_cast<const f32x2*>(d_wfrag), d_bias, d_slope, d_out, n_utt};
   void (*kern)(const TailParams) = (flags & 2) ? c3d2_tail_kernel<L, true> : c3d2_tail_kernel<L, false>;
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t items = (int64_t)((n_utt + GROUP - 1) / GROUP) * G::ITEMS_PER_GROUP;
-  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, ctx->num_cu)), dim3(TAIL_THREADS), lds, ctx->stream, p);
+  int per_cu = 1;
+  if (L::NWAVES < 8) {   // four-wave workgroups share a CU
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), G::THREADS, lds) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    per_cu = std::min(per_cu, 2);
+  }
+  unsigned* queue = nullptr;
+  if (per_cu > 1 && !getenv("SVK_C3D2_STATIC_ITEMS")) {   // a slot of the handle's 256-byte scratch, zeroed in stream order
+    queue = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 96);
+    SVK_HIP(ctx, hipMemsetAsync(queue, 0, 4, ctx->stream));
+  }
+  TailParams p{d_in, reinterpret_cast<const f32x2*>(d_wfrag), d_bias, d_slope, d_out, n_utt, queue};
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(G::THREADS), lds, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }
@@ -277,6 +335,7 @@ int launch_tail(svk_ctx* ctx, const char* name, const float* d_in, int32_t n_utt
 // 1 152: partial sums [4 d][n][128], added in the fixed order d = 0 .. 3 by fc5_reduce_kernel (no atomics: the embeddings
 // stay bitwise repeatable).  Wave = N tile; A rows staged through two LDS buffers of 64 x 128 floats (row stride 136 = 8
 // mod 64: conflict-free ds_read_b128 by the lane-group table), B fragments [d][nt][72][64 lanes][4] straight from global. ----
+constexpr int TAIL_THREADS = 512;
 constexpr int FC_K = 4608, FC_KD = 1152, FC_CUBES = 64, FC_CH = 128, FC_ROW = 136;
 
 struct Fc5Params {
@@ -383,6 +442,11 @@ extern "C" int svk_c3d2_fc5(svk_ctx* ctx, const float* d_in, int32_t n_utt, cons
                      0, ctx->stream, d_work, d_bias, d_out, n_vec, (int64_t)n_utt * 128);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
+}
+
+extern "C" int svk_c3d2_conv32t(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
+                                const float* d_slope, int32_t flags, float* d_out) {
+  return launch_tail<Conv32T>(ctx, "svk_c3d2_conv32t", d_in, n_utt, d_wfrag, d_bias, d_slope, flags, d_out);
 }
 
 extern "C" int svk_c3d2_conv41(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,

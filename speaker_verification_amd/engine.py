@@ -471,18 +471,26 @@ class Engine:
                                        self._ptr(act2), self._ptr(out)), self.ctx)
         return out
 
-    def c3d2_conv31(self, act, tables):
+    def c3d2_conv31(self, act, tables, chunked=False):
         """svk_c3d2_conv31: [n, 12, 15, 7, 32] (svk_c3d2_stage2's output) -> conv3_1 + BN + PReLU -> [n, 10, 15, 5, 64]
-        f32, channels last (Winograd F(2, 3) along depth)."""
+        f32, channels last (Winograd F(2, 3) along depth); with `chunked` [n, 10 d, 8 chunks, 5 w, 15 h, 8]: what
+        svk_c3d2_conv32t stages from."""
         torch = _torch()
         n = act.shape[0]
         wfrag, bias, slope = tables[:3]
         slope01 = bool(tables[3]) if len(tables) > 3 else False
-        out = torch.empty((n, 10, 15, 5, 64), dtype=torch.float32, device=self.device)
+        out = torch.empty((n, 10, 8, 5, 15, 8) if chunked else (n, 10, 15, 5, 64), dtype=torch.float32, device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_conv31(self.ctx, self._ptr(act), n, self._ptr(wfrag), self._ptr(bias), self._ptr(slope),
-                                       2 if slope01 else 0, self._ptr(out)), self.ctx)
+                                       (2 if slope01 else 0) | (8 if chunked else 0), self._ptr(out)), self.ctx)
         return out
+
+    def c3d2_conv32t(self, act, tables):
+        """svk_c3d2_conv32t: chunked, column-major [n, 10, 8, 5, 15, 8] (svk_c3d2_conv31 with chunked=True) -> conv3_2 + BN
+        + PReLU -> chunked [n, 8 d, 8 chunks, 45 = 9 h x 5 w, 8] (the shape of the last block: M tile = one position of 16 cubes)."""
+        if tuple(act.shape[1:]) != (10, 8, 5, 15, 8) or not act.is_contiguous():
+            raise ValueError("c3d2_conv32t wants the chunked activation [n, 10, 8, 5, 15, 8]")
+        return self._c3d2_tail_conv(self.lib.svk_c3d2_conv32t, act, tables, (8, 8, 45, 8))
 
     def c3d2_conv32(self, act, tables, chunked=False):
         """svk_c3d2_conv32: [n, 10, 15, 5, 64] (svk_c3d2_conv31's output) -> conv3_2 + BN + PReLU -> [n, 8, 9, 5, 64]

@@ -117,6 +117,7 @@ class FusedEmbedder:
             self.conv31_kernel = False       # conv3_1 in libsvk behind svk_c3d2_stage2 (SVK_C3D2_CONV31=0 disables)
             self.conv32_kernel = False       # ... and conv3_2 behind it (SVK_C3D2_CONV32=0 disables)
             self.conv4_kernels = False       # ... and conv4_1, conv4_2, FC5 (SVK_C3D2_CONV4=0 hands them back to PyTorch-ROCm)
+            self.conv32t_kernel = False      # conv3_2 in the last block's shape (SVK_C3D2_CONV32T=0: the round-2 kernel)
             if channels_last and self.fc_w.is_cuda:
                 import os
                 if os.environ.get("SVK_C3D2_TAIL", "1") != "0":
@@ -125,6 +126,7 @@ class FusedEmbedder:
                     self.conv31_kernel = os.environ.get("SVK_C3D2_CONV31", "1") != "0"
                     self.conv32_kernel = self.conv31_kernel and os.environ.get("SVK_C3D2_CONV32", "1") != "0"
                     self.conv4_kernels = self.conv32_kernel and os.environ.get("SVK_C3D2_CONV4", "1") != "0"
+                    self.conv32t_kernel = self.conv4_kernels and os.environ.get("SVK_C3D2_CONV32T", "1") != "0"
             # First layer as patch-matrix x weight GEMM.  MIOpen has no direct kernel for a 1-channel
             # Conv3d and falls back to im2col + per-group GEMM + layout transposes (6.5 ms per 978
             # cubes).  Here ONE strided copy gathers, for every group of G adjacent output columns, the
@@ -390,6 +392,13 @@ class FusedEmbedder:
         slope = sl.expand(co).contiguous() if sl.numel() == 1 else sl.contiguous()
         return (frag.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
 
+    def conv32t_tables(self):
+        """`svk_c3d2_conv32t` (conv3_2: 64 -> 64, k(3,7,1)) in the last block's operand format (host-transformed)."""
+        hit = getattr(self, "_conv32t", False)
+        if hit is False:
+            hit = self._conv32t = self._tail_conv_tables(5, (64, 64, 3, 7, 1), "h")
+        return hit
+
     def conv41_tables(self):
         """`svk_c3d2_conv41` (conv4_1: 64 -> 128, k(3,1,3), stride 1, no pool), BN folded, depth-transformed by the host."""
         hit = getattr(self, "_conv41", False)
@@ -450,6 +459,11 @@ class FusedEmbedder:
         t31 = self.conv31_tables() if (self.fused_tail is not None and self.conv31_kernel and z.is_cuda) else None
         if t31 is not None:
             timed_ = timed or (lambda name, fn: fn())
+            if self.conv32t_kernel and self.tail_in_libsvk() and self.conv32t_tables() is not None:
+                # conv3_2 in the last block's shape (the default): conv3_1 writes the chunked, column-major layout it stages from
+                y = timed_("conv3_1", lambda: self.fused_tail.c3d2_conv31(z.view(n, 12, 15, 7, 32), t31, chunked=True))
+                yc = timed_("conv3_2", lambda: self.fused_tail.c3d2_conv32t(y, self.conv32t_tables()))
+                return self.tail_from_conv32(yc, n, timed)
             y = timed_("conv3_1", lambda: self.fused_tail.c3d2_conv31(z.view(n, 12, 15, 7, 32), t31))
             t32 = self.conv32_tables() if self.conv32_kernel else None
             if t32 is not None:

@@ -32,7 +32,7 @@ def short(name):
             if k == "c3d2_stage1w_kernel" and ("<true, true>" in name or "<false, true>" in name):
                 extra = "<merged>"
             if k == "c3d2_tail_kernel":
-                extra = "<Conv41>" if "Conv41" in name else "<Conv42>"
+                extra = "<Conv41>" if "Conv41" in name else "<Conv42>" if "Conv42" in name else "<Conv32T>"
             if "frontend_kernel" in name:
                 extra = "<int16,nfft1024>" if "<short, true" in name else "<int16,nfft512>" if "<short, false" in name \
                     else "<f32,nfft1024>" if "<float, true" in name else "<f32,nfft512>"
