@@ -5,22 +5,25 @@
 # Separate rocprofv3 runs: kernel trace + stats on the end-to-end bench, one --pmc pass per counter
 # group on `bench.py --frontend-only` (never --pmc together with other trace domains).
 set -e
+# every profiler pass is bounded: one that hangs (seen once: a --pmc pass stuck right after HSA initialisation, nothing of ours
+# running) is cut after four minutes instead of starving the whole call of output
+rp() { timeout -k 10 240 rocprofv3 "$@" || echo "profiler pass failed or timed out: rc=$?"; }
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 echo "[1/6] kernel trace + stats of the end-to-end bench"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bench -- python3 $root/bench.py --steps 3 --warmup 1 --no-extras > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
+rp --kernel-trace --stats --output-format csv -d $out/prof_bench -- python3 $root/bench.py --steps 3 --warmup 1 --no-extras > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
 echo "[2/6] HBM read / write counters"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --frontend-only > $out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py --frontend-only > $out/pmc_write.log 2>&1
+rp --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --frontend-only > $out/pmc_fetch.log 2>&1
+rp --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py --frontend-only > $out/pmc_write.log 2>&1
 echo "[3/6] SQ counters"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_sq -- python3 $root/bench.py --frontend-only > $out/pmc_sq.log 2>&1
+rp --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_sq -- python3 $root/bench.py --frontend-only > $out/pmc_sq.log 2>&1
 echo "[4/6] stall composition"
 bash $root/tools/pmc_stalls.sh final
 cd /tmp
 echo "[5/6] the network kernels (all seven libsvk kernels): HBM counters + stall composition over bench.py --c3d2-only"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_c3d2 -- python3 $root/bench.py --c3d2-only > $out/pmc_fetch_c3d2.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_c3d2 -- python3 $root/bench.py --c3d2-only > $out/pmc_write_c3d2.log 2>&1
+rp --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_c3d2 -- python3 $root/bench.py --c3d2-only > $out/pmc_fetch_c3d2.log 2>&1
+rp --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_c3d2 -- python3 $root/bench.py --c3d2-only > $out/pmc_write_c3d2.log 2>&1
 bash $root/tools/pmc_stalls.sh c3d2 bench.py --c3d2-only
 cd /tmp
 echo "[6/6] the bench itself + the stage-level kernels"
