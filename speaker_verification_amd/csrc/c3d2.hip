@@ -1,12 +1,16 @@
 // The C3D2 embedding network's first three blocks (model.py:110-131, :141-164) on v_mfma_f32_16x16x4_f32.
 //   c3d2_stage1_kernel            cube + conv1_1 + conv1_2 + pool1, direct form (described right below)
-//   c3d2_stage1w_kernel           the same with conv1_2 through Winograd's F(2, 3) along depth -- the default
+//   c3d2_stage1w_kernel<., MERGE> the same with conv1_2 through Winograd's F(2, 3) along depth; MERGE = the round-3 default
+//                                 (the 4-row remainders of two depth pairs share one M tile)
+//   c3d2_stage1t_kernel           experiment: input transform applied once at conv1_1's output (measured slower; DESIGN appendix)
 //   c3d2_conv21_kernel / conv21w  conv2_1, direct / depth-transformed
 //   c3d2_conv22_kernel / conv22w  conv2_2 + pool2, direct / depth-transformed
 //   c3d2_conv31w_kernel           conv3_1, depth-transformed
-//   c3d2_conv32w_kernel           conv3_2, depth-transformed, K split over the waves of a workgroup
-//   bias_prelu_kernel             + bias, PReLU behind the convolutions PyTorch-ROCm still runs (conv4_1, conv4_2)
-// BatchNorm (eval mode) is folded into weights and biases by the host (model.FusedEmbedder).
+//   c3d2_conv32w_kernel           conv3_2, depth-transformed, K split over the waves of a workgroup (round 2; the default is
+//                                 c3d2_tail_kernel<Conv32T> of c3d2_tail.hip, where conv4_1, conv4_2 and FC5 live too)
+//   bias_prelu_kernel             + bias, PReLU behind a convolution the host framework ran (the PyTorch-ROCm A/B path only)
+// BatchNorm (eval mode) is folded into weights and biases by the host (model.FusedEmbedder).  The kernels that share a CU
+// between workgroups (conv21w, conv22w, conv31w) draw their work items from a device-wide counter.
 //
 // The first block of the C3D2 embedding network as ONE gfx950 kernel:
 //   feature rows + crop starts -> cube (utils.py:351-379) -> conv1_1 (1 -> 16, k(3,1,5)) + BN + PReLU

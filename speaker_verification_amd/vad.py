@@ -148,3 +148,54 @@ def energy_vad_batch(pcm, threshold=c.VAD_ENERGY_THRESHOLD, sample_rate=c.SAMPLE
     return get_engine().vad_energy(pcm, threshold, fs=sample_rate, frame_ms=frame_duration_ms,
                                    padding_ms=padding_duration_ms, lengths=lengths, compact=compact,
                                    want_segments=want_segments)
+
+
+def main(id_list=None, chunked_list='100_speakers_100_samples_chunked_ids.txt', threshold=c.VAD_ENERGY_THRESHOLD, batch=512):
+    """vad.py:135-168, the file-driven chunker: every WAV named in the id list (`c.ROOT/100_first_ids_100_samples.txt`,
+    the list the reference's second assignment leaves in effect) is read from `c.DATA_ORIGIN/wav/`, cut into its voiced
+    segments (30 ms frames, 300 ms of padding) and written as `c.DATA_ORIGIN/wav_chunked/<name>_<i>.wav`; the new
+    relative names go to `chunked_list` in the working directory.  The reference walks file by file and frame by frame
+    through webrtcvad; here `batch` files share ONE ragged launch of the energy VAD (offsets / lengths into one buffer)
+    and the host only slices the segments out.  Returns the list of written names."""
+    import os
+    id_list = id_list or os.path.join(c.ROOT, '100_first_ids_100_samples.txt')
+    train_files = [str(f) for f in np.atleast_1d(np.genfromtxt(id_list, dtype='str'))]
+    to_path = os.path.join(c.DATA_ORIGIN, 'wav_chunked')
+    from_path = os.path.join(c.DATA_ORIGIN, 'wav')
+    os.makedirs(to_path, exist_ok=True)
+    train_list = []
+    eng = get_engine()
+    for lo in range(0, len(train_files), batch):
+        names = train_files[lo:lo + batch]
+        audio = [read_wave(os.path.join(from_path, f)) for f in names]
+        for rate in sorted({r for _, r in audio}):                    # one launch per sample rate present
+            idx = [k for k, (_, r) in enumerate(audio) if r == rate]
+            pcm = [np.frombuffer(audio[k][0], dtype=np.int16) for k in idx]
+            lens = np.array([x.size for x in pcm], dtype=np.int32)
+            slots = (lens.astype(np.int64) + 7) // 8 * 8
+            offs = np.concatenate([[0], np.cumsum(slots)[:-1]]).astype(np.int64)
+            buf = np.zeros((int(slots.sum()) if len(idx) else 0,), dtype=np.int16)
+            for x, o in zip(pcm, offs):
+                buf[o:o + x.size] = x
+            res = eng.vad_energy(buf, threshold, fs=rate, frame_ms=c.VAD_FRAME_MS, padding_ms=c.VAD_PADDING_MS,
+                                 lengths=lens, offsets=offs, compact=False, want_segments=True)
+            seg = res["seg"].to("cpu").numpy()
+            n = res["frame_samples"]
+            for row, k in enumerate(idx):
+                nseg = int(seg[row].max()) + 1
+                for i in range(nseg):
+                    frames = np.nonzero(seg[row] == i)[0]
+                    segment = b"".join(pcm[row][f * n:(f + 1) * n].tobytes() for f in frames)
+                    dest_path = os.path.join(to_path, names[k]).replace('.wav', '_{}.wav'.format(i))
+                    train_list.append(dest_path.replace(to_path + '/', ''))
+                    os.makedirs(os.path.dirname(dest_path), exist_ok=True)
+                    write_wave(dest_path, segment, rate)
+    # (file order inside a batch follows the sample rates present; the reference's list is in file order)
+    order = {f: k for k, f in enumerate(train_files)}
+    train_list.sort(key=lambda name: (order[name.rsplit('_', 1)[0] + '.wav'], int(name.rsplit('_', 1)[1][:-4])))
+    np.savetxt(chunked_list, train_list, fmt='%s')
+    return train_list
+
+
+if __name__ == '__main__':
+    main()

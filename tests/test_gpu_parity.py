@@ -300,6 +300,39 @@ def test_long_clip_paths_equal_the_one_kernel_paths(eng, monkeypatch):
         np.testing.assert_array_equal(out["1"][4][k], v)
 
 
+def test_vad_main_chunks_a_file_tree(eng, tmp_path, monkeypatch):
+    """vad.main() (vad.py:135-168): id list -> voiced segments as `wav_chunked/<name>_<i>.wav` + the new id list, against
+    the oracle's collector file by file (the reference's own collector is pinned to that oracle by the golden VAD cases)."""
+    import wave
+    from speaker_verification_amd import constants, vad
+    root, data = tmp_path / "root", tmp_path / "data"
+    (data / "wav" / "id10001" / "rec").mkdir(parents=True)
+    (data / "wav" / "id10002" / "rec").mkdir(parents=True)
+    root.mkdir()
+    clips = {"id10001/rec/00001.wav": (synth.speaker_clip(3, 0, 64000), 16000), "id10001/rec/00002.wav": (synth.speaker_clip(3, 1, 90001), 16000),
+             "id10002/rec/00001.wav": (synth.speaker_clip(4, 0, 40000, fs=8000), 8000), "id10002/rec/00002.wav": (synth.noise_clip(5, 20000, 50.0), 16000)}
+    for name, (pcm, rate) in clips.items():
+        vad.write_wave(str(data / "wav" / name), pcm.tobytes(), rate)
+    np.savetxt(root / "100_first_ids_100_samples.txt", np.array(list(clips)), fmt="%s")
+    monkeypatch.setattr(constants, "ROOT", str(root))
+    monkeypatch.setattr(constants, "DATA_ORIGIN", str(data))
+    monkeypatch.chdir(tmp_path)
+    written = vad.main()
+    assert [ln.strip() for ln in open(tmp_path / "100_speakers_100_samples_chunked_ids.txt")] == written
+    want_names = []
+    for name, (pcm, rate) in clips.items():
+        keep, seg, _ = vad_ref.vad_energy(pcm, rate, c.VAD_FRAME_MS, c.VAD_PADDING_MS, c.VAD_ENERGY_THRESHOLD)
+        n = int(rate * 0.03)
+        for i in range(int(seg.max()) + 1 if seg.size else 0):
+            out = name.replace(".wav", "_%d.wav" % i)
+            want_names.append(out)
+            with wave.open(str(data / "wav_chunked" / out), "rb") as wf:
+                assert wf.getframerate() == rate and wf.getnchannels() == 1
+                got = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16)
+            np.testing.assert_array_equal(got, np.concatenate([pcm[f * n:(f + 1) * n] for f in np.nonzero(seg == i)[0]]))
+    assert written == want_names and len(written) >= 3                     # the quiet noise clip yields no segment
+
+
 def test_full_size_batch_properties(eng):
     """BASELINE config 2 shape (1 024 x 3 s): determinism, row independence, no NaN."""
     from speaker_verification_amd.speechpy import feature
