@@ -169,3 +169,58 @@ def test_indexed_labels_never_unpickle(tmp_path):
     os.remove(root + "/50_first_ids.txt")
     with pytest.raises(FileNotFoundError, match="pickle"):
         load_indexed_labels(root + "/50_first_ids.npy")
+
+
+def test_ragged_batches_sort_cap_and_merge_the_tail():
+    """`VerificationPipeline._ragged_batches` (host logic of embed_ragged / embed_ragged_resident): clips sorted by length,
+    batches capped by clip count and by 16-byte-aligned samples, and a last batch of a handful of (long) clips joined to its
+    predecessor instead of running the network on a few cubes."""
+    import types
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    fn = VerificationPipeline._ragged_batches
+    me = types.SimpleNamespace(micro_batch=100)
+    lens = [1000] * 270 + [50_000] * 3
+    out = fn(me, lens, max_batch_samples=200_000)
+    flat = [k for b, _ in out for k in b]
+    assert sorted(flat) == list(range(len(lens)))                        # every clip exactly once
+    assert [lens[k] for k in flat] == sorted(lens)                       # ascending length
+    assert len(out[0][0]) == 100 and out[0][1] == 100 * 1000             # clip-count cap; 1000 is a multiple of 8
+    # greedy: 100 + 100 + (70 short + 2 long = 170 000 samples) + (1 long); the last, a single clip, joins its predecessor
+    assert [len(b) for b, _ in out] == [100, 100, 73]
+    assert out[2][1] == 70 * 1000 + 3 * 50_000
+    # the sample cap; a short tail joins its predecessor up to 1.5 x the cap together, not beyond
+    assert [len(b) for b, _ in fn(me, [60_000] * 5, max_batch_samples=130_000)] == [2, 3]
+    assert [len(b) for b, _ in fn(me, [100_000] * 3, max_batch_samples=120_000)] == [1, 1, 1]
+    out = fn(me, [7], max_batch_samples=10)                               # one short clip: one batch, slot rounded up to 8
+    assert out == [([0], 8)]
+    assert fn(me, [], 10) == []
+
+
+def test_tail_operand_tables_against_naive_indexing():
+    """The host tables of svk_c3d2_conv41 / conv42 / conv32t / fc5 (model.FusedEmbedder): depth-transformed weights in the MFMA
+    lane order of include/svk.h, FC5's columns permuted to conv4_2's chunked output order -- against element-wise indexing."""
+    import random
+    import torch
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    m = seeded_model(3, 8)
+    m.load_state_dict(perturb_inference_state(m.state_dict(), 4))
+    e = m.fused_inference(channels_last=True)
+    rnd = random.Random(1)
+    for name, li, axis in (("conv41", 6, "w"), ("conv42", 7, "h"), ("conv32t", 5, "h")):
+        frag = getattr(e, name + "_tables")()[0]
+        w = e.stages[li][0]
+        g0, g1, g2 = w[:, :, 0], w[:, :, 1], w[:, :, 2]
+        g = torch.stack((g0, 0.5 * ((g0 + g2) + g1), 0.5 * ((g0 + g2) - g1), g2))        # [k][co][ci][kh][kw]
+        g = g[:, :, :, :, 0] if axis == "h" else g[:, :, :, 0, :]
+        assert tuple(frag.shape) == (w.shape[0] // 16, w.shape[1] // 8, g.shape[3], 4, 64, 2)
+        for _ in range(500):
+            nt, ch, tap = rnd.randrange(frag.shape[0]), rnd.randrange(frag.shape[1]), rnd.randrange(frag.shape[2])
+            k, lane, el = rnd.randrange(4), rnd.randrange(64), rnd.randrange(2)
+            assert frag[nt, ch, tap, k, lane, el] == g[k, 16 * nt + (lane & 15), 8 * ch + 2 * (lane >> 4) + el, tap]
+    frag, bias = e.fc5_tables()
+    assert tuple(frag.shape) == (4, 8, 72, 64, 4) and torch.equal(bias, e.fc_b)
+    for _ in range(500):
+        d, nt, st, lane, el = rnd.randrange(4), rnd.randrange(8), rnd.randrange(72), rnd.randrange(64), rnd.randrange(4)
+        K = 1152 * d + 16 * st + 4 * (lane >> 4) + el               # ((d * 16 + chunk) * 9 + pixel) * 8 + c8
+        c8, pix, chunk = K % 8, (K // 8) % 9, (K // 72) % 16
+        assert frag[d, nt, st, lane, el] == e.fc_w[16 * nt + (lane & 15), (8 * chunk + c8) * 36 + d * 9 + pix]
