@@ -30,6 +30,7 @@
 // then fall into 32 different 8-byte slots -- conflict-free by the lane-group table of MI355X_MICROARCH.md (LDS).
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "svk_internal.h"
 
@@ -118,7 +119,16 @@ struct TailParams {
   float* out;
   int32_t n_utt;
   unsigned* queue;      // work-item counter (zeroed before the launch) where workgroups share a CU, or NULL = fixed stride
+  unsigned long long* stamps;   // tuning builds only (-DSVK_TUNING): [grid][waves][4] summed cycles
 };
+
+#ifdef SVK_TUNING
+#define TAIL_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define TAIL_STAMP_ADD(slot, a, b) do { stamp_acc[slot] += (b) - (a); } while (0)
+#else
+#define TAIL_STAMP(var) do { } while (0)
+#define TAIL_STAMP_ADD(slot, a, b) do { } while (0)
+#endif
 
 template <class L, bool SLOPE01>
 __global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const TailParams p) {
@@ -197,6 +207,9 @@ __global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const Tail
     __syncthreads();
     item_next = q_next;
   }
+#ifdef SVK_TUNING
+  unsigned long long stamp_acc[4] = {0, 0, 0, 0};
+#endif
   while (item < n_items) {
     unsigned q_ticket = 0;
     if (p.queue && threadIdx.x == 0) q_ticket = atomicAdd(p.queue, 1u);   // for the item after next; published below
@@ -206,6 +219,7 @@ __global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const Tail
       for (int k = 0; k < 4; ++k) acc[t][k] = k == 1 ? (f32x4){b, b, b, b} : (f32x4){0.f, 0.f, 0.f, 0.f};   // a1 carries the bias
 #pragma unroll 1
     for (int ph = 0; ph < G::NPH; ++ph) {
+      TAIL_STAMP(tp0);
       // what the NEXT phase stages (the next item's first phase behind this item's last)
       const bool last_ph = ph + 1 == G::NPH;
       const int n_item = last_ph ? item_next : item, n_ph = last_ph ? 0 : ph + 1;
@@ -254,9 +268,14 @@ __global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const Tail
         b0 = b1;
         b1 = b2;
       }
+      TAIL_STAMP(tp1);
       __syncthreads();   // the next chunk is parked; this one may be overwritten by the phase after next
+      TAIL_STAMP(tp2);
+      TAIL_STAMP_ADD(0, tp0, tp1);   // a phase: steps of 18 MFMAs + the next chunk's staging
+      TAIL_STAMP_ADD(1, tp1, tp2);   // its barrier
       buf_sel ^= 1;
     }
+    TAIL_STAMP(te0);
     int item_after = item_next + (int)gridDim.x;
     if (p.queue) {
       // (the phase loop above ended with a barrier: q_next's previous value has been read by every thread)
@@ -291,7 +310,16 @@ __global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const Tail
     } else {
       item_next = item_after;
     }
+    TAIL_STAMP(te1);
+    TAIL_STAMP_ADD(2, te0, te1);     // output transform, PReLU, stores (+ the queue barrier)
+#ifdef SVK_TUNING
+    stamp_acc[3] += 1;               // items this workgroup processed
+#endif
   }
+#ifdef SVK_TUNING
+  if (p.stamps && lane == 0)
+    for (int k = 0; k < 4; ++k) p.stamps[((size_t)blockIdx.x * L::NWAVES + nt) * 4 + k] = stamp_acc[k];
+#endif
 }
 
 template <class L>
@@ -322,9 +350,36 @@ int launch_tail(svk_ctx* ctx, const char* name, const float* d_in, int32_t n_utt
     queue = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 96);
     SVK_HIP(ctx, hipMemsetAsync(queue, 0, 4, ctx->stream));
   }
-  TailParams p{d_in, reinterpret_cast<const f32x2*>(d_wfrag), d_bias, d_slope, d_out, n_utt, queue};
-  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(G::THREADS), lds, ctx->stream, p);
+  TailParams p{d_in, reinterpret_cast<const f32x2*>(d_wfrag), d_bias, d_slope, d_out, n_utt, queue, nullptr};
+  const unsigned grid = (unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu);
+#ifdef SVK_TUNING
+  const bool want_stamps = getenv("SVK_C3D2_STAMPS") != nullptr;
+  const size_t stamp_bytes = (size_t)grid * L::NWAVES * 4 * sizeof(unsigned long long);
+  if (want_stamps) {
+    const int rc = svk_ensure_work(ctx, stamp_bytes);
+    if (rc != SVK_OK) return rc;
+    p.stamps = reinterpret_cast<unsigned long long*>(ctx->work);
+    SVK_HIP(ctx, hipMemsetAsync(p.stamps, 0, stamp_bytes, ctx->stream));
+  }
+#endif
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), lds, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
+#ifdef SVK_TUNING
+  if (want_stamps) {   // cycles per ITEM (s_memtime), averaged over workgroups, wave 0 and the last wave
+    std::vector<unsigned long long> h((size_t)grid * L::NWAVES * 4);
+    SVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SVK_HIP(ctx, hipMemcpy(h.data(), p.stamps, stamp_bytes, hipMemcpyDeviceToHost));
+    for (int w : {0, L::NWAVES - 1}) {
+      double s0 = 0, s1 = 0, s2 = 0, n = 0;
+      for (unsigned b = 0; b < grid; ++b) {
+        const unsigned long long* e = &h[((size_t)b * L::NWAVES + w) * 4];
+        s0 += (double)e[0]; s1 += (double)e[1]; s2 += (double)e[2]; n += (double)e[3];
+      }
+      fprintf(stderr, "%s stamps wave %d (cycles per item; %d phases of %d steps x 18 MFMAs = %d MFMA cycles per wave): phases %.0f  barriers %.0f  epilogue %.0f\n",
+              name, w, G::NPH, G::STEPS, G::NPH * G::STEPS * 18 * 32, s0 / n, s1 / n, s2 / n);
+    }
+  }
+#endif
   return SVK_OK;
 }
 

@@ -47,3 +47,17 @@ for _ in range(700):                           # ~1 s of back-to-back launches
 os.environ["SVK_C3D2_STAMPS"] = "1"
 eng.c3d2_stage2(y, t2, depth_transform=True)
 torch.cuda.synchronize()
+
+# the last block's kernels (and conv3_2 in their shape): phases / barriers / epilogue per item, 4 018 cubes
+n4 = 4018
+os.environ.pop("SVK_C3D2_STAMPS", None)
+x32 = torch.randn((n4, 10, 8, 5, 15, 8), device=eng.device)
+x41 = torch.randn((n4, 8, 8, 45, 8), device=eng.device)
+x42 = torch.randn((n4, 6, 16, 27, 8), device=eng.device)
+for fn, x, t in ((eng.c3d2_conv32t, x32, emb.conv32t_tables()), (eng.c3d2_conv41, x41, emb.conv41_tables()), (eng.c3d2_conv42, x42, emb.conv42_tables())):
+    os.environ.pop("SVK_C3D2_STAMPS", None)
+    for _ in range(20):
+        fn(x, t)
+    os.environ["SVK_C3D2_STAMPS"] = "1"
+    fn(x, t)
+    torch.cuda.synchronize()
