@@ -1007,7 +1007,10 @@ def main():
                                      "of direct-form sums (ceiling 232 k utt/s per GPU) -- conv1_2 .. conv4_2 run through "
                                      "Winograd F(2,3) along depth and issue 2/3 of theirs"},
             "eer": {"eer": eer, "auc": auc, "eer_device": eer_dev, "auc_device": auc_dev, "pairs": int(labels.size),
-                    "short_clips": bad},
+                    "short_clips": bad,
+                    "note": "random-init C3D2 (no checkpoint ships offline): an EER near 0.5 is that of an untrained network.  The "
+                            "statement is numerical -- host sklearn path = svk_roc_eer = CPU oracle on the same scores, and GPU = "
+                            "CPU EER from PCM on the parity sample -- not an operating point of a trained model"},
         }
 
     if rank == 0 and world == 1 and not args.no_extras:
