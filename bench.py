@@ -497,10 +497,10 @@ def ragged_bench(pipe, eng, torch, n_clips=2048, reps=3):
                 by[name] = by.get(name, 0.0) + a.elapsed_time(b)
             shares.append(by)
         t_res = float(np.median(times))
-        stage_ms = {k: float(np.median([x.get(k, 0.0) for x in shares])) for k in ("vad", "frontend", "cmvn", "crops", "network")}
+        stage_ms = {k: float(np.median([x.get(k, 0.0) for x in shares])) for k in ("vad", "frontend", "cmvn", "crops", "gather", "network")}
         front_ms = sum(v for k, v in stage_ms.items() if k != "network")
         net_ms = stage_ms["network"]
-        n_batches = sum(1 for name, _, _ in spans if name == "network")
+        n_batches = sum(1 for name, _, _ in spans if name == "frontend")
         host_buf = buf.cpu().numpy()
         clips = [host_buf[offs[k]:offs[k] + lens[k]] for k in range(n_clips)]
         pipe.embed_ragged(clips)                  # warm: the pinned / device staging buffers are sized by the largest batch

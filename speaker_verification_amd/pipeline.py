@@ -319,7 +319,7 @@ class VerificationPipeline:
             out[-1] = (out[-1][0] + tail[0], out[-1][1] + tail[1])
         return out
 
-    def _embed_ragged_batch(self, dev_buf, offs, lens, rows, first_utt, voiced_out=None, spans=None):
+    def _embed_ragged_batch(self, dev_buf, offs, lens, rows, first_utt, voiced_out=None, spans=None, cube_out=None):
         """One batch of clips addressed through offsets / lengths into `dev_buf` -> their embeddings (rows = the clips'
         indices in the caller's list: they key the crop draw)."""
         def timed(name, fn):
@@ -345,7 +345,36 @@ class VerificationPipeline:
         # the crop draw is keyed by the clip's index in the caller's list, whatever batch it landed in
         idx = timed("crops", lambda: self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, 0, self.bad_clips,
                                                          utt_index=rows + first_utt))
+        if cube_out is not None:
+            # deferred network (see _ragged_network): only the 20 x 80 rows the network will read leave this batch
+            timed("gather", lambda: self.eng.cube_gather(feat, idx, c.CUBE_FRAMES, out=cube_out))
+            return None
         return timed("network", lambda: self.embed_features(feat, idx))
+
+    def _ragged_defer(self):
+        """Length-sorted batches are what the front end wants (their feature buffers are sized by the longest clip) and
+        what the network does NOT want: the batch of the longest clips is a few dozen cubes, and a persistent kernel that
+        works on 16-cube groups leaves most of the chip idle there (measured: 0.45 ms of fixed cost per such batch).  So the
+        ragged paths gather each batch's cubes (256 KB per clip, utils.py:351-379) into one buffer and run the network
+        ONCE over full micro-batches; the first block then reads that buffer as feature rows with crop starts 0, 80, 160 ...
+        Needs the libsvk first block (C3D2 geometry); SVK_RAGGED_DEFER=0 runs the network per batch."""
+        import os
+        return (os.environ.get("SVK_RAGGED_DEFER", "1") != "0" and self.embedder is not None and self.stage1_kernel
+                and self.embedder.stage1_tables() is not None and self.spec.num_cols == c.NUM_COEF)
+
+    def _ragged_network(self, cubes, emb_sorted, lo, hi, spans=None):
+        """Embeddings of the gathered cubes [lo, hi) ([n, 1, 20, 80, 40], any clip order) into emb_sorted[lo:hi]."""
+        n = cubes.shape[0]
+        rows = cubes.view(n, c.CUBE_CROPS * c.CUBE_FRAMES, c.NUM_COEF)
+        starts = (torch.arange(c.CUBE_CROPS, dtype=torch.int32, device=self.eng.device) * c.CUBE_FRAMES)[None, :]
+        ev = None
+        if spans is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        emb_sorted[lo:hi] = self.embed_features(rows[lo:hi], starts.expand(hi - lo, -1).contiguous())
+        if ev is not None:
+            ev[1].record()
+            spans.append(("network", ev[0], ev[1]))
 
     def embed_ragged(self, clips, max_batch_samples=64 * 1024 * 1024, first_utt=0, spans=None):
         """Clips of DIFFERENT lengths (VoxCeleb1 utterances run from 4 to 145 s): `clips` is a list of 1-D
@@ -406,6 +435,10 @@ class VerificationPipeline:
                 copied[slot].record(copy_stream)
             meta[k] = (np.asarray(offs, dtype=np.int64), np.asarray(lens, dtype=np.int32))
 
+        defer = self._ragged_defer()
+        cubes = torch.empty((len(clips), 1, c.CUBE_CROPS, c.CUBE_FRAMES, c.NUM_COEF), dtype=torch.float32, device=dev) if defer else None
+        emb_sorted = torch.empty_like(emb) if defer else None
+        order, at, done = [], 0, 0
         stage(0)
         for k, (batch, total) in enumerate(batches):
             slot = k & 1
@@ -413,11 +446,24 @@ class VerificationPipeline:
             offs, lens = meta.pop(k)
             rows = torch.as_tensor(np.asarray(batch, dtype=np.int64), device=dev)
             voiced = self._rag_voiced[:total] if self.use_vad else None
-            emb[rows] = self._embed_ragged_batch(self._rag_dev[slot][:total], offs, lens, rows, first_utt, voiced_out=voiced,
-                                                 spans=spans)
+            out = self._embed_ragged_batch(self._rag_dev[slot][:total], offs, lens, rows, first_utt, voiced_out=voiced, spans=spans,
+                                           cube_out=cubes[at:at + len(batch)] if defer else None)
+            if not defer:
+                emb[rows] = out
+            order += batch
+            at += len(batch)
             consumed[slot].record(main)
+            # the network runs as soon as a full micro-batch of cubes has gathered: its kernels then cover the host-side
+            # packing of the next batch (a single pass at the very end would leave that packing uncovered)
+            while defer and at - done >= self.micro_batch:
+                self._ragged_network(cubes, emb_sorted, done, done + self.micro_batch, spans)
+                done += self.micro_batch
             if k + 1 < len(batches):
                 stage(k + 1)                               # host packing + H2D of the next batch under this batch's kernels
+        if defer:
+            if at > done:
+                self._ragged_network(cubes, emb_sorted, done, at, spans)
+            emb[torch.as_tensor(np.asarray(order, dtype=np.int64), device=dev)] = emb_sorted
         return emb
 
     def embed_ragged_resident(self, buf, offsets, lengths, max_batch_samples=64 * 1024 * 1024, first_utt=0, spans=None):
@@ -436,12 +482,27 @@ class VerificationPipeline:
             raise ValueError("buf must be a 1-D int16 tensor")
         if len(lengths) and int((offsets + lengths).max()) > buf.numel():
             raise ValueError("a clip reaches past the end of buf")
-        emb = torch.empty((len(lengths), 128), dtype=torch.float32, device=self.eng.device)
+        dev = self.eng.device
+        emb = torch.empty((len(lengths), 128), dtype=torch.float32, device=dev)
         voiced = torch.empty_like(buf) if self.use_vad else None
+        defer = self._ragged_defer()
+        cubes = torch.empty((len(lengths), 1, c.CUBE_CROPS, c.CUBE_FRAMES, c.NUM_COEF), dtype=torch.float32, device=dev) if defer else None
+        order, at = [], 0
         for batch, _ in self._ragged_batches(lengths, max_batch_samples):
-            rows = torch.as_tensor(np.asarray(batch, dtype=np.int64), device=self.eng.device)
-            emb[rows] = self._embed_ragged_batch(buf, offsets[batch], lengths[batch], rows, first_utt, voiced_out=voiced,
-                                                 spans=spans)
+            rows = torch.as_tensor(np.asarray(batch, dtype=np.int64), device=dev)
+            out = self._embed_ragged_batch(buf, offsets[batch], lengths[batch], rows, first_utt, voiced_out=voiced, spans=spans,
+                                           cube_out=cubes[at:at + len(batch)] if defer else None)
+            if not defer:
+                emb[rows] = out
+            order += batch
+            at += len(batch)
+        if defer:
+            # nothing to overlap with here: the network runs at the end, over micro-batches as large as the main path's
+            emb_sorted = torch.empty_like(emb)
+            step = max(self.micro_batch, 4096)
+            for lo in range(0, at, step):
+                self._ragged_network(cubes, emb_sorted, lo, min(at, lo + step), spans)
+            emb[torch.as_tensor(np.asarray(order, dtype=np.int64), device=dev)] = emb_sorted
         return emb
 
     def embed_host(self, pcm_host, first_utt=0):

@@ -35,9 +35,12 @@ spans = []
 pipe.embed_ragged_resident(buf, offs, lens, spans=spans)
 torch.cuda.synchronize()
 batches = list(pipe._ragged_batches(lens, 64 * 1024 * 1024))
-per = len(spans) // len(batches)
+net = [(name, a, e) for name, a, e in spans if name == "network"]
+front = [(name, a, e) for name, a, e in spans if name != "network"]
+per = len(front) // len(batches)
+print("network passes (deferred, full micro-batches): " + "  ".join("%.3f ms" % a.elapsed_time(e) for _, a, e in net))
 for b, (idx, total) in enumerate(batches):
-    row = {name: a.elapsed_time(e) for name, a, e in spans[b * per:(b + 1) * per]}
+    row = {name: a.elapsed_time(e) for name, a, e in front[b * per:(b + 1) * per]}
     ll = lens[idx]
     print("batch %d: %4d clips, %6.1f .. %6.1f s (%7.0f s of audio)  " % (b, len(idx), ll.min() / 16000, ll.max() / 16000, ll.sum() / 16000)
           + "  ".join("%s %.3f" % kv for kv in row.items()))
