@@ -9,6 +9,8 @@ Every stage is a libsvk.so kernel, the C3D2 forward included (`svk_c3d2_stage1`,
 `svk_c3d2_conv31/32/41/42`, `svk_c3d2_fc5`); PyTorch-ROCm serves as device memory, streams and the
 module checkpoints load into (its own forward is the A/B path behind the SVK_C3D2_* switches).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -401,7 +403,7 @@ class VerificationPipeline:
             self._rag_voiced = torch.empty((cap,), dtype=torch.int16, device=dev) if self.use_vad else None
             self._rag_stream = torch.cuda.Stream(device=dev)
             from concurrent.futures import ThreadPoolExecutor
-            self._rag_pool = ThreadPoolExecutor(max_workers=8)
+            self._rag_pool = ThreadPoolExecutor(max_workers=int(os.environ.get("SVK_RAGGED_THREADS", "8")))
         main = torch.cuda.current_stream(dev)
         copy_stream = self._rag_stream
         copy_stream.synchronize()                          # a previous call's copies may still read the pinned buffers
@@ -426,7 +428,7 @@ class VerificationPipeline:
             def put(lo, hi):
                 for q in range(lo, hi):
                     np.copyto(dst[offs[q]:offs[q] + lens[q]], np.asarray(clips[batch[q]], dtype=np.int16), casting="no")
-            step = -(-len(batch) // 8)
+            step = -(-len(batch) // self._rag_pool._max_workers)
             jobs = [self._rag_pool.submit(put, lo, min(len(batch), lo + step)) for lo in range(0, len(batch), step)]
             for jb in jobs:
                 jb.result()
