@@ -251,7 +251,10 @@ int svk_roc_eer(svk_ctx* ctx, const float* d_scores, const uint8_t* d_labels, in
  * C3D2 kernel is 3 taps deep: 2 / 3 of the multiply-adds; the transformed weights are derived in the kernel from the
  * same d_w2frag; the same sums in another association, ~1e-6 relative from the direct form); bit 3 (value 8) = the same
  * transform with its input side applied ONCE, where conv1_1's output is produced (c3d2_stage1t_kernel: t planes in LDS,
- * no vector work in conv1_2's loop; needs d_feat 16-byte aligned; takes precedence over bit 2); bit 0 picks the layout:
+ * no vector work in conv1_2's loop; needs d_feat 16-byte aligned; takes precedence over bit 2; measured slower than bit 2 +
+ * bit 4, kept as an experiment); bit 4 (value 16, with bit 2) = the remainder rows 32 .. 35 of two depth pairs share one M
+ * tile, cut by accumulator over the workgroup's eight waves (- 10 % MFMAs; rows 0 .. 31 bit-identical; the default of
+ * speaker_verification_amd.pipeline); bit 0 picks the layout:
  *   folded = 0: [n_utt][16 d][36 h][18 w][16 c]
  *   folded = 1: [n_utt][16 d][18 h/2][18 w][2 (h & 1)][16 c]   (= a (n, 32, 16, 18, 18) channels-last tensor:
  *               the row-parity-in-channels form model.FusedEmbedder feeds conv2_1 / conv2_2)

@@ -1910,7 +1910,7 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   {
     // work-item counters of the kernels that share a CU between workgroups (slots of the handle's 256-byte scratch; svk_log_power
     // owns the first word): zeroed in stream order before the launches
-    static const bool static_items = getenv("SVK_C3D2_STATIC_ITEMS") != nullptr;
+    const bool static_items = getenv("SVK_C3D2_STATIC_ITEMS") != nullptr;
     unsigned* const queues = static_items ? nullptr : reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 64);
     if (queues) SVK_HIP(ctx, hipMemsetAsync(queues, 0, 16, ctx->stream));
     const bool wino = (flags & 1) != 0;   // conv2_1 through the depth transform
@@ -1932,7 +1932,7 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     SVK_LAUNCH_CHECK(ctx);
   }
   {
-    static const bool static_items22 = getenv("SVK_C3D2_STATIC_ITEMS") != nullptr;
+    const bool static_items22 = getenv("SVK_C3D2_STATIC_ITEMS") != nullptr;
     Conv22Params p{d_act2, reinterpret_cast<const f32x4*>(d_w22frag), d_bias22, d_slope22, d_out, n_utt, nullptr,
                    (flags & 4) && !static_items22 ? reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 68) : nullptr};
     if (flags & 4) {   // conv2_2 through the depth transform
@@ -2051,7 +2051,7 @@ extern "C" int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_wfrag)) & 15) == 0,
               "buffers must be 16-byte aligned");
   SVK_REQUIRE(ctx, (int64_t)n_utt * 5 < ((int64_t)1 << 31), "too many cubes for one launch");
-  static const bool static_items31 = getenv("SVK_C3D2_STATIC_ITEMS") != nullptr;
+  const bool static_items31 = getenv("SVK_C3D2_STATIC_ITEMS") != nullptr;
   unsigned* const queue31 = static_items31 ? nullptr : reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 80);
   if (queue31) SVK_HIP(ctx, hipMemsetAsync(queue31, 0, 4, ctx->stream));
   Conv31Params p{d_in, reinterpret_cast<const f32x4*>(d_wfrag), d_bias, d_slope, d_out, n_utt, queue31, (flags & 8) ? 1 : 0};

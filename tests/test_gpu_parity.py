@@ -1879,6 +1879,15 @@ def test_network_kernels_many_items_per_workgroup(eng):
     w2 = eng.c3d2_stage2(act1, t2, depth_transform=True)
     assert float((w2 - d2).abs().max()) <= 4e-6 * float(d2.abs().max())
     assert torch.equal(w2, eng.c3d2_stage2(act1, t2, depth_transform=True))
+    # work items drawn from the device-wide counter (default) or at a fixed stride: the same results, bit for bit
+    t31s = emb.conv31_tables()
+    a2s = torch.randn((90, 12, 15, 7, 32), device=eng.device, generator=g)
+    os.environ["SVK_C3D2_STATIC_ITEMS"] = "1"
+    try:
+        fixed2, fixed31 = eng.c3d2_stage2(act1, t2, depth_transform=True), eng.c3d2_conv31(a2s, t31s)
+    finally:
+        del os.environ["SVK_C3D2_STATIC_ITEMS"]
+    assert torch.equal(fixed2, w2) and torch.equal(fixed31, eng.c3d2_conv31(a2s, t31s))
     pick = [0, 100, 201, 255]
     want2 = _cpu_layers(state, act1[pick].permute(0, 4, 1, 2, 3).cpu().contiguous(), (("2_1", (1, 1, 1)), ("2_2", (1, 2, 1))))
     for name, got in (("direct", d2), ("depth-transformed", w2)):
