@@ -24,6 +24,9 @@ The JSON line also carries
                    multiply-adds instead (what Winograd F(2,3) along depth saves shows as algorithmic_frac > frac);
   roofline_network -- the same two fractions for EVERY network kernel (stage2 = conv2_1 + conv2_2, conv3_1, conv3_2,
                    conv4_1, conv4_2, fc5) with each one's share of the step; roofline_stage2 = its stage2 row;
+                   valu_per_mfma / fp32_lanes_busy: the other vector instructions per MFMA (committed SQ_INSTS_VALU)
+                   and frac x (1 + valu_per_mfma x 4 / 32) -- f32 MFMA and f32 VALU never co-execute on this chip, so
+                   this is the share of the SIMDs' FP32 issue slots that is occupied at all (the rest are stalls);
   roofline_frontend -- the fused front-end kernel (HBM roof): algorithmic HBM bytes of the launches it actually
                    ran (VAD-shortened clips) over their HIP-event durations;
   roofline_e2e  -- the whole step against the f32 matrix peak: frac from the issued MFMA work per utterance,
@@ -927,6 +930,14 @@ def main():
                     mfma += got if got is not None else 0.0
                 if not all(src):
                     mfma, src = float(mfma_design), ["by construction (no committed counter)"]
+                # non-MFMA vector instructions per MFMA (committed SQ_INSTS_VALU, which counts the MFMAs too): f32 MFMA and f32
+                # VALU never run together on this chip (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in every profile), so a VALU
+                # wave-instruction (4 cycles of a SIMD where the MFMA takes 32) is paid in the same issue slots
+                valu = 0.0
+                for sym in symbols:
+                    got, _ = pmc_counter(sym, "SQ_INSTS_VALU")
+                    valu = None if (got is None or valu is None) else valu + got
+                valu_per_mfma = None if (valu is None or not all(src) or mfma <= 0) else (valu - mfma) / mfma
                 tf_issued = cubes_total * mfma * MFMA_FLOP / ms / 1e9
                 tf_alg = cubes_total * 2 * mmac * 1e6 / ms / 1e9
                 issued_gflop_per_utt += mfma * MFMA_FLOP / 1e9
@@ -937,7 +948,10 @@ def main():
                     "algorithmic_frac": tf_alg / F32_MATRIX_PEAK_TFLOPS, "kernel": " + ".join(symbols),
                     "avg_launch_ms": ms / len(evs), "cubes_per_launch": cubes_total / len(evs),
                     "mfma_per_cube": mfma, "mfma_per_cube_by_construction": mfma_design, "mfma_source": src[0],
-                    "direct_form_mmac_per_cube": mmac, "share_of_step": ms / args.steps / ms_per_step}
+                    "direct_form_mmac_per_cube": mmac, "share_of_step": ms / args.steps / ms_per_step,
+                    "valu_per_mfma": valu_per_mfma,
+                    "fp32_lanes_busy": None if valu_per_mfma is None
+                    else tf_issued / F32_MATRIX_PEAK_TFLOPS * (1.0 + valu_per_mfma * 4.0 / 32.0)}
             r1 = network_rows["stage1"]
             t1, t1_src = pmc_traffic(r1["kernel"])
             main_roofline = dict(r1)

@@ -1955,6 +1955,8 @@ def test_bench_two_ranks_share_one_gpu():
         for name, row in net.items():
             if not name.startswith("_"):
                 assert 0.01 < row["frac"] < 1.0 and row["mfma_per_cube"] == pytest.approx(row["mfma_per_cube_by_construction"], rel=1e-3), name
+                # MFMA + the vector instructions that cannot overlap it: still a share of the SIMDs' FP32 issue slots
+                assert row["fp32_lanes_busy"] is None or row["frac"] < row["fp32_lanes_busy"] < 1.0, name
         assert rec["roofline_e2e"]["frac"] < 1.0 and rec["roofline_e2e"]["issued_gflop_per_utt"] == pytest.approx(0.469303, rel=1e-3)
         assert rec["roofline_frontend"]["bound"] == "hbm" and rec["roofline_e2e"]["bound"] == "mfma"
 
