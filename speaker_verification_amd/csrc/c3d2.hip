@@ -24,7 +24,7 @@
 //   d in [8q, 8q + 8), h in [0, 36), w in {2j, 2j + 1}  ->  pooled column j, 16 channels.
 // A persistent workgroup of 4 waves (one per SIMD; it owns the CU's LDS) loops over items:
 //   1. the 12 x 80 x 6 cube patch the item needs is fetched into registers while the previous item's
-//      matrix work runs, then parked in LDS (23 KB);
+//      matrix work runs, then parked in LDS (23 KB) -- by LDS-DMA in the depth-transformed kernel below;
 //   2. conv1_1 as a GEMM on v_mfma_f32_16x16x4_f32: [16 pixels] x [K = 15 taps + 1 (bias)] x [16 channels],
 //      A gathered from the patch, result + PReLU written to the act1 tile in LDS:
 //      10 depths x 80 rows x 2 columns x 16 channels;
@@ -312,28 +312,60 @@ __global__ __launch_bounds__(256) void c3d2_stage1_kernel(const Stage1Params p) 
 // -----------------------------------------------------------------------------------------------------
 constexpr int WPIXF = 18;                                  // average floats per act1 pixel in this layout
 constexpr int WACT_FLOATS = WPIXF * DIN * NFRAME * 2;
-constexpr int WPD = PD / 2;                                // patch depths per thread (512 threads: two halves)
+constexpr int WPW = 8;                                     // floats per patch row in LDS: [ww 0 1 2 | - | ww 3 4 5 | -]
+constexpr int WP_FLOATS = PD * NFRAME * WPW;               // 7 680
 
-__device__ __forceinline__ void fetch_patch_w(const Stage1Params& p, int item, int starts_v, int h, int piece, int dhalf,
-                                              f32x2 (&regs)[WPD]) {
-  const int u = item / 36, rem = item - u * 36, j = rem % 18;
-  const float* base = p.feat + (int64_t)u * p.max_frames * NCOEF + 2 * j + 2 * piece;
-#pragma unroll
-  for (int dd = 0; dd < WPD; ++dd) {
-    f32x2 v = (f32x2){0.f, 0.f};
-    const int start = __builtin_amdgcn_readlane(starts_v, WPD * dhalf + dd);   // wave-uniform (dhalf = wave >> 2)
-    if (h < NFRAME && (unsigned)start < (unsigned)p.max_frames && h < p.max_frames - start)   // (cannot overflow for any int32 start)
-      v = *reinterpret_cast<const f32x2*>(base + (start + h) * NCOEF);
-    regs[dd] = v;
+// The item's cube patch by LDS-DMA (global_load_lds_dwordx3; round 3): patch[dd][h][.] = feat[u][crop[u][8 q + dd] + h][2 j ..
+// 2 j + 5].  A DMA lane's 12 bytes land at a wave-uniform LDS base + 16 lane (measured: tools/experiments/glds12_probe.hip
+// -- the fourth word of every 16 bytes is left alone), so two lanes carry a row's two halves, the row is 8 floats in LDS
+// and one instruction moves 32 rows: no staging registers, no parking writes, no per-lane address arithmetic (the register
+// path before it: twelve 8-byte loads + six ds_write_b64 per thread).  The source needs 4-byte alignment only.  Depth
+// dd's 80 rows are three pieces (32 + 32 + 16 rows, the last with half the lanes); piece n = 3 dd + part belongs to wave
+// n % 8: four or five pieces per wave and item.  A piece that is not wholly inside the clip (a wild crop start: the C-ABI
+// takes any int32) goes the slow way, lane by lane, with zeros outside -- a wave-uniform branch the pipeline's own crops
+// never take.
+struct PatchPiece { const float* src; float* dst; int rows; bool inside, valid; int start, h0; };
+__device__ __forceinline__ PatchPiece patch_piece(const Stage1Params& p, const float* base, int start, int n, float* patch) {
+  PatchPiece pc;
+  pc.valid = n < 3 * PD;
+  const int dd = n / 3, part = n - 3 * dd;
+  pc.rows = part < 2 ? 32 : 16;
+  pc.h0 = 32 * part;
+  pc.start = start;
+  pc.dst = patch + (dd * NFRAME + pc.h0) * WPW;
+  pc.inside = (unsigned)start < (unsigned)p.max_frames && pc.h0 + pc.rows <= p.max_frames - start;   // (cannot overflow for any int32 start)
+  pc.src = base + (int64_t)(start + pc.h0) * NCOEF;
+  return pc;
+}
+__device__ __forceinline__ void patch_piece_issue(const Stage1Params& p, const PatchPiece& pc, int lane) {
+  const int rl = lane >> 1, half = lane & 1;
+  if (!pc.valid) return;
+  if (pc.inside) {
+    if (rl < pc.rows) __builtin_amdgcn_global_load_lds(pc.src + rl * NCOEF + 3 * half, pc.dst, 12, 0, 0);
+  } else if (rl < pc.rows) {
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if ((unsigned)pc.start < (unsigned)p.max_frames && pc.h0 + rl < p.max_frames - pc.start) {
+      const float* src = pc.src + rl * NCOEF + 3 * half;
+      v0 = src[0];
+      v1 = src[1];
+      v2 = src[2];
+    }
+    float* d = pc.dst + rl * WPW + 4 * half;
+    d[0] = v0;
+    d[1] = v1;
+    d[2] = v2;
   }
 }
-
-__device__ __forceinline__ void park_patch_w(float* patch, int h, int piece, int dhalf, const f32x2 (&regs)[WPD]) {
-  if (h < NFRAME) {
-    float* dst = patch + (WPD * dhalf) * (NFRAME * PW) + h * PW + 2 * piece;
+// all of a wave's pieces at once (every crop start is read BEFORE the first DMA: with one in flight the compiler drains
+// vmcnt in front of any use of an ordinary load's result -- `starts_v` is one -- which would serialise the pieces)
+__device__ __forceinline__ void dma_patch_w(const Stage1Params& p, int item, int starts_v, int wave, int lane, float* patch) {
+  const int u = item / 36, rem = item - u * 36, j = rem % 18;
+  const float* base = p.feat + (int64_t)u * p.max_frames * NCOEF + 2 * j;
+  int st[5];
 #pragma unroll
-    for (int dd = 0; dd < WPD; ++dd) *reinterpret_cast<f32x2*>(dst + dd * (NFRAME * PW)) = regs[dd];
-  }
+  for (int k = 0; k < 5; ++k) st[k] = __builtin_amdgcn_readlane(starts_v, (wave + 8 * k < 3 * PD ? wave + 8 * k : 0) / 3);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) patch_piece_issue(p, patch_piece(p, base, st[k], wave + 8 * k, patch), lane);
 }
 
 // Input transform of the depth-Winograd form for one element pair (hf = 0: elements 0, 1; 1: elements 2, 3) of the four
@@ -398,8 +430,8 @@ template <bool SLOPE01, bool MERGE>
 __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem_c3d2[];
   float* act = smem_c3d2;               // [WACT_FLOATS]
-  float* patch = act + WACT_FLOATS;     // [P_FLOATS]
-  float* const exch = patch + P_FLOATS; // MERGE: [2 m][4 k][64 lanes] f32x4
+  float* patch = act + WACT_FLOATS;     // [WP_FLOATS]: [12 dd][80 h][8]
+  float* const exch = patch + WP_FLOATS; // MERGE: [2 m][4 k][64 lanes] f32x4
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: a scalar
   const int i = lane & 15, kk = lane >> 4;
   const int pair = wave & 3, part = wave >> 2;
@@ -418,20 +450,15 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) w1[jj] = p.w1frag[jj * 64 + lane];
   const float sl1 = p.slope1[i], b1 = p.bias1[i], b2 = p.bias2[i], sl2 = p.slope2[i];
-  const int pix_lane = (i >> 1) * PW + (i & 1);
 
-  f32x2 pre[WPD];
   int starts = 0;
-  const int tq = threadIdx.x & 255;
-  const int ph = tq / 3, ppiece = tq - 3 * ph;   // patch row (>= 80: idle) and float2 piece; depths 6 part .. 6 part + 5
   int item = blockIdx.x;
   if (item < n_items) {
     starts = fetch_starts(p, item, lane);
-    fetch_patch_w(p, item, starts, ph, ppiece, part, pre);
-    park_patch_w(patch, ph, ppiece, part, pre);
+    dma_patch_w(p, item, starts, wave, lane, patch);
     if (item + (int)gridDim.x < n_items) starts = fetch_starts(p, item + gridDim.x, lane);
   }
-  __syncthreads();
+  __syncthreads();   // (waits for the DMA in front of the barrier)
 #ifdef SVK_TUNING
   unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
   // the clock the chip holds under this kernel's load: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime) over the loop
@@ -443,13 +470,14 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
     SVK_STAMP(ts1);
 
     // ---- conv1_1 + PReLU: 100 tiles of 16 pixels, tile tt = wave + 8 m: 13 for waves 0 .. 3, 12 for the others, four at
-    // a time (patch offset 48 tt and act1 offset 288 tt are linear in tt: per-lane bases + immediates) ----
+    // a time (patch offset 64 tt and act1 offset 288 tt are linear in tt: per-lane bases + immediates) ----
     {
       const float* pl[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {   // (recomputed per item: this kernel has no registers to spare)
         const int k = 4 * jj + kk;
-        pl[jj] = patch + 48 * wave + pix_lane + (k < 15 ? (k / 5) * (NFRAME * PW) + (k % 5) : 0);
+        const int col = (i & 1) + (k < 15 ? k % 5 : 0);   // patch column 0 .. 5 at float col + (col >= 3) of the 8-float row
+        pl[jj] = patch + 8 * WPW * wave + (i >> 1) * WPW + col + (col >= 3 ? 1 : 0) + (k < 15 ? (k / 5) * (NFRAME * WPW) : 0);
       }
       float* const al = act + 16 * WPIXF * wave + 68 * kk + i;
 #pragma unroll
@@ -458,7 +486,7 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) av[q4][jj] = pl[jj][384 * (4 * g4 + q4)];
+          for (int jj = 0; jj < 4; ++jj) av[q4][jj] = pl[jj][64 * WPW * (4 * g4 + q4)];
         f32x4 acc1[4];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) acc1[q4] = (f32x4){b1, b1, b1, b1};
@@ -476,7 +504,7 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       if (part == 0) {   // tile 96 + wave
         float av[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) av[jj] = pl[jj][384 * 12];
+        for (int jj = 0; jj < 4; ++jj) av[jj] = pl[jj][64 * WPW * 12];
         f32x4 acc1 = (f32x4){b1, b1, b1, b1};
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], w1[jj], acc1, 0, 0, 0);
@@ -505,11 +533,11 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       const int fetch_tl = MERGE ? 3 * part : (part ? 4 : 0);
 #pragma unroll 1
       for (int tl = tl0; tl < tl1; ++tl) {
-        // the next item's patch: twelve scattered 8-byte loads per row take the CU's address path ~2 000 cycles to accept;
-        // the two waves of a SIMD issue their halves at different times, under each other's MFMAs (part 0 in front of
-        // its first tile, part 1 in front of its second), and park them after the last tile
-        if (tl == fetch_tl && next < n_items) {
-          fetch_patch_w(p, next, starts, ph, ppiece, part, pre);
+        // the next item's patch (LDS-DMA): the two waves of a SIMD issue their pieces at different times, under each
+        // other's MFMAs -- part 0 in front of its first tile, part 1 in front of its second (one piece every other row
+        // tap instead of all in one burst: measured 2.7 % SLOWER)
+        if (tl == fetch_tl && next < n_items) {   // (behind barrier 1: conv1_1 has read the patch buffer)
+          dma_patch_w(p, next, starts, wave, lane, patch);
           if (next + (int)gridDim.x < n_items) starts = fetch_starts(p, next + gridDim.x, lane);
         }
         const int h0 = tl < 4 ? 8 * tl : 28;
@@ -585,9 +613,8 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       *reinterpret_cast<f32x4*>(exch + ((part * 4 + pair) * 64 + lane) * 4) = au;
     }
     SVK_STAMP(ts4);
-    if (next < n_items) park_patch_w(patch, ph, ppiece, part, pre);
     SVK_STAMP(ts5);
-    __syncthreads();  // the next patch is in place; act1 may be overwritten
+    __syncthreads();  // the next patch is in place (the DMA is waited for in front of the barrier); act1 may be overwritten
     SVK_STAMP(ts6);
     if (MERGE && pair == 0) {
       // waves 0 and 4 finish merged tile m = part: rows 4 kk + r = (pair 2 m + (kk >> 1), output row 32 + 2 (kk & 1) + (r >> 1),
@@ -938,7 +965,7 @@ __global__ __launch_bounds__(512) void c3d2_stage1t_kernel(const Stage1Params p)
 extern "C" {
 
 // (of the larger variant, the depth-transformed one)
-size_t svk_c3d2_stage1_lds_bytes(void) { return sizeof(float) * (size_t)std::max(WACT_FLOATS + P_FLOATS + 2048, T_LDS_FLOATS); }
+size_t svk_c3d2_stage1_lds_bytes(void) { return sizeof(float) * (size_t)std::max(WACT_FLOATS + WP_FLOATS + 2048, T_LDS_FLOATS); }
 
 int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const float* d_w1frag,
@@ -986,7 +1013,7 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
     p.s_d = (int64_t)OH * OWP * 16;
   }
   p.s_n = (int64_t)OD * OH * OWP * 16;
-  const size_t lds = sizeof(float) * (size_t)(tform ? T_LDS_FLOATS : (wino ? WACT_FLOATS + (merge ? 2048 : 0) : ACT_FLOATS) + P_FLOATS);
+  const size_t lds = sizeof(float) * (size_t)(tform ? T_LDS_FLOATS : wino ? WACT_FLOATS + WP_FLOATS + (merge ? 2048 : 0) : ACT_FLOATS + P_FLOATS);
   if (lds > (size_t)ctx->lds_per_cu)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage1 needs %zu bytes of LDS per workgroup (device: %d)", lds,
                     ctx->lds_per_cu);

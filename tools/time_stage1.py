@@ -8,6 +8,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speaker_verification_amd import _lib                                    # noqa: E402
+if os.environ.get("SVK_TOOL_LIB"):                                            # an experiment build (make stamps EXP=... TAG=...)
+    _lib.LIB_PATH = os.environ["SVK_TOOL_LIB"]
 from speaker_verification_amd.engine import get_engine                       # noqa: E402
 from speaker_verification_amd.model import perturb_inference_state, seeded_model   # noqa: E402
 
