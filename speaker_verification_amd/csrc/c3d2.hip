@@ -458,7 +458,8 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
     dma_patch_w(p, item, starts, wave, lane, patch);
     if (item + (int)gridDim.x < n_items) starts = fetch_starts(p, item + gridDim.x, lane);
   }
-  __syncthreads();   // (waits for the DMA in front of the barrier)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed (the compiler emits this wait too; spelt out: the barrier relies on it)
+  __syncthreads();
 #ifdef SVK_TUNING
   unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
   // the clock the chip holds under this kernel's load: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime) over the loop
@@ -614,7 +615,8 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
     }
     SVK_STAMP(ts4);
     SVK_STAMP(ts5);
-    __syncthreads();  // the next patch is in place (the DMA is waited for in front of the barrier); act1 may be overwritten
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed (as above)
+    __syncthreads();  // the next patch is in place; act1 may be overwritten
     SVK_STAMP(ts6);
     if (MERGE && pair == 0) {
       // waves 0 and 4 finish merged tile m = part: rows 4 kk + r = (pair 2 m + (kk >> 1), output row 32 + 2 (kk & 1) + (r >> 1),

@@ -1998,6 +1998,20 @@ def test_network_block_error_paths(eng):
             yb = eng.c3d2_stage1(featr, bad, tables, folded=False, **kw)
             torch.cuda.synchronize()
             assert torch.equal(yb[1], yb[0]), (wild, kw)
+    # crops that run off the END of the clip (start + 80 > max_frames): the rows past it read as zeros -- bit for bit what the
+    # same crops give on the features padded with zero rows, where every patch piece takes the kernel's fast path (LDS-DMA in
+    # the depth-transformed forms); starts 50 / 60 cut a 32-row piece in the middle, 89 leaves one row
+    part = torch.randint(0, 11, (3, 20), device=eng.device, dtype=torch.int32, generator=torch.Generator(device=eng.device).manual_seed(5))
+    part[1, ::3] = 50
+    part[1, 1] = 60
+    part[2, 5] = 89
+    part[0, 19] = 11
+    featp = torch.zeros((3, 170, 40), device=eng.device)
+    featp[:, :90] = featr
+    for kw in (dict(), dict(depth_transform=True), dict(depth_transform=True, merged_tiles=True), dict(t_planes=True)):
+        for folded in (False, True):
+            assert torch.equal(eng.c3d2_stage1(featr, part, tables, folded=folded, **kw),
+                               eng.c3d2_stage1(featp, part, tables, folded=folded, **kw)), (kw, folded)
 
 
 def test_bias_prelu_pass(eng):
