@@ -508,11 +508,22 @@ def ragged_bench(pipe, eng, torch, n_clips=2048, reps=3):
         clips = [host_buf[offs[k]:offs[k] + lens[k]] for k in range(n_clips)]
         pipe.embed_ragged(clips)                  # warm: the pinned / device staging buffers are sized by the largest batch
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        emb_h = pipe.embed_ragged(clips)
-        torch.cuda.synchronize()
-        t_host = time.perf_counter() - t0
+        th = []
+        for _ in range(max(3, reps)):             # (host packing competes with whatever else the box runs: a median, not one shot)
+            t0 = time.perf_counter()
+            emb_h = pipe.embed_ragged(clips)
+            torch.cuda.synchronize()
+            th.append(time.perf_counter() - t0)
+        t_host = float(np.median(th))
         same = float((emb_h - emb).abs().max().item())
+        tp = []
+        for _ in range(max(3, reps)):             # the same clips handed over as ONE host arena + offsets (a loader that decodes into one buffer)
+            t0 = time.perf_counter()
+            emb_p = pipe.embed_ragged_resident(host_buf, offs, lens)
+            torch.cuda.synchronize()
+            tp.append(time.perf_counter() - t0)
+        t_packed = float(np.median(tp))
+        same = max(same, float((emb_p - emb).abs().max().item()))
     finally:
         pipe.micro_batch = saved_mb
     audio_s = float(lens.sum()) / 16000.0
@@ -525,6 +536,9 @@ def ragged_bench(pipe, eng, torch, n_clips=2048, reps=3):
             "host_fed": {"utt_per_s": n_clips / t_host, "audio_seconds_per_s": audio_s / t_host, "ms": t_host * 1e3,
                          "note": "a list of host NumPy clips: 8 host threads pack batch k + 1 into a pinned buffer and a side stream uploads it "
                                  "while the GPU works on batch k; same kernels"},
+            "host_packed": {"utt_per_s": n_clips / t_packed, "audio_seconds_per_s": audio_s / t_packed, "ms": t_packed * 1e3,
+                            "note": "one pageable host array holding every clip + offsets (embed_ragged_resident takes host memory too): "
+                                    "a single upload, no per-clip packing on the host; same kernels"},
             "max_abs_diff_host_vs_resident": same, "short_clips": int(pipe.bad_clips.item()),
             "fixed_3s_front_end_share_for_comparison": None}
 

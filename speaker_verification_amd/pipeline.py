@@ -469,40 +469,102 @@ class VerificationPipeline:
         return emb
 
     def embed_ragged_resident(self, buf, offsets, lengths, max_batch_samples=64 * 1024 * 1024, first_utt=0, spans=None):
-        """`embed_ragged` for audio that is ALREADY in HBM: `buf` is one 1-D int16 device tensor holding every clip,
-        clip k at samples [offsets[k], offsets[k] + lengths[k]) (offsets multiples of 8: 16-byte aligned; host arrays).
-        Batches are lists of clip indices into that one buffer -- nothing is copied or packed; the VAD writes its voiced
-        samples into one scratch buffer of the same shape, reused by every batch."""
+        """`embed_ragged` for audio that is ALREADY in one buffer: `buf` is one 1-D int16 array holding every clip, clip k at
+        samples [offsets[k], offsets[k] + lengths[k]) (offsets multiples of 8: 16-byte aligned; host arrays).
+          * a DEVICE tensor: batches are lists of clip indices into that one buffer -- nothing is copied or packed; the VAD
+            writes its voiced samples into one scratch buffer of the same shape, reused by every batch;
+          * a HOST NumPy array (a loader that decodes into one arena): uploaded as it is, no per-clip packing on the host
+            (the list form, `embed_ragged`, is bound by that packing: ~20 GB/s of host copy against 54 GB/s of pageable
+            upload on the GPU box).  Arenas larger than two batches go up in pieces of ~`max_batch_samples` on a side
+            stream from a helper thread, and the clips of piece p run (length-sorted among themselves) while piece p + 1
+            travels."""
         if self.crop_rng != "device":
             raise ValueError("embed_ragged_resident needs crop_rng='device'")
         offsets = np.asarray(offsets, dtype=np.int64)
         lengths = np.asarray(lengths, dtype=np.int32)
         if offsets.shape != lengths.shape or (offsets % 8).any():
             raise ValueError("offsets / lengths must have one entry per clip, offsets multiples of 8 samples")
-        buf = self.eng.to_device(buf)
-        if buf.dim() != 1 or buf.dtype != torch.int16:
-            raise ValueError("buf must be a 1-D int16 tensor")
-        if len(lengths) and int((offsets + lengths).max()) > buf.numel():
+        host = isinstance(buf, np.ndarray)
+        if host:
+            if buf.ndim != 1 or buf.dtype != np.int16:
+                raise ValueError("buf must be a 1-D int16 array")
+            buf = np.ascontiguousarray(buf)
+            n_samples = buf.size
+        else:
+            buf = self.eng.to_device(buf)
+            if buf.dim() != 1 or buf.dtype != torch.int16:
+                raise ValueError("buf must be a 1-D int16 tensor")
+            n_samples = buf.numel()
+        if len(lengths) and int((offsets + lengths).max()) > n_samples:
             raise ValueError("a clip reaches past the end of buf")
         dev = self.eng.device
         emb = torch.empty((len(lengths), 128), dtype=torch.float32, device=dev)
+        if not len(lengths):
+            return emb
+        # upload groups: clips by arena position, cut where a piece passes max_batch_samples (one group = everything when
+        # the buffer is on the device already or small)
+        groups = [np.arange(len(lengths))]
+        pieces = [(0, n_samples)]
+        if host and n_samples > 2 * max_batch_samples:
+            by_pos = np.argsort(offsets, kind="stable")
+            ends = offsets[by_pos] + lengths[by_pos]
+            groups, pieces, lo, first = [], [], 0, 0
+            for q in range(len(by_pos)):
+                last = q + 1 == len(by_pos)
+                if last or int(ends[q + 1]) - int(offsets[by_pos[first]]) > max_batch_samples:
+                    hi = n_samples if last else int(offsets[by_pos[q + 1]])
+                    groups.append(by_pos[first:q + 1])
+                    pieces.append((lo, hi))
+                    lo, first = hi, q + 1
+        flags, events, worker = None, None, None
+        if host:
+            import threading
+            if getattr(self, "_up_stream", None) is None:
+                self._up_stream = torch.cuda.Stream(device=dev)
+            dev_buf = torch.empty((n_samples,), dtype=torch.int16, device=dev)
+            flags = [threading.Event() for _ in pieces]
+            events = [torch.cuda.Event() for _ in pieces]
+            self._up_stream.wait_stream(torch.cuda.current_stream(dev))
+            src = torch.from_numpy(buf)
+
+            def upload():   # (pageable copies hold their calling thread: a helper thread, so that the main one keeps launching)
+                with torch.cuda.stream(self._up_stream):
+                    for g, (a, b) in enumerate(pieces):
+                        dev_buf[a:b].copy_(src[a:b], non_blocking=True)
+                        events[g].record(self._up_stream)
+                        flags[g].set()
+            worker = threading.Thread(target=upload, daemon=True)
+            worker.start()
+            buf = dev_buf
         voiced = torch.empty_like(buf) if self.use_vad else None
         defer = self._ragged_defer()
         cubes = torch.empty((len(lengths), 1, c.CUBE_CROPS, c.CUBE_FRAMES, c.NUM_COEF), dtype=torch.float32, device=dev) if defer else None
-        order, at = [], 0
-        for batch, _ in self._ragged_batches(lengths, max_batch_samples):
-            rows = torch.as_tensor(np.asarray(batch, dtype=np.int64), device=dev)
-            out = self._embed_ragged_batch(buf, offsets[batch], lengths[batch], rows, first_utt, voiced_out=voiced, spans=spans,
-                                           cube_out=cubes[at:at + len(batch)] if defer else None)
-            if not defer:
-                emb[rows] = out
-            order += batch
-            at += len(batch)
+        emb_sorted = torch.empty_like(emb) if defer else None
+        step = self.micro_batch if len(groups) > 1 else max(self.micro_batch, 4096)
+        order, at, done = [], 0, 0
+        main = torch.cuda.current_stream(dev)
+        for g, idx in enumerate(groups):
+            if flags is not None:
+                flags[g].wait()
+                main.wait_event(events[g])
+            for batch, _ in self._ragged_batches(lengths[idx], max_batch_samples):
+                batch = [int(idx[b]) for b in batch]
+                rows = torch.as_tensor(np.asarray(batch, dtype=np.int64), device=dev)
+                out = self._embed_ragged_batch(buf, offsets[batch], lengths[batch], rows, first_utt, voiced_out=voiced, spans=spans,
+                                               cube_out=cubes[at:at + len(batch)] if defer else None)
+                if not defer:
+                    emb[rows] = out
+                order += batch
+                at += len(batch)
+            # with pieces still travelling the network runs as soon as a micro-batch of cubes has gathered (it covers the
+            # next piece's upload); otherwise once, at the end, over micro-batches as large as the main path's
+            while defer and len(groups) > 1 and g + 1 < len(groups) and at - done >= step:
+                self._ragged_network(cubes, emb_sorted, done, done + step, spans)
+                done += step
+        if worker is not None:
+            worker.join()
         if defer:
-            # nothing to overlap with here: the network runs at the end, over micro-batches as large as the main path's
-            emb_sorted = torch.empty_like(emb)
-            step = max(self.micro_batch, 4096)
-            for lo in range(0, at, step):
+            for lo in range(done, at, step):
                 self._ragged_network(cubes, emb_sorted, lo, min(at, lo + step), spans)
             emb[torch.as_tensor(np.asarray(order, dtype=np.int64), device=dev)] = emb_sorted
         return emb

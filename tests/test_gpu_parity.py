@@ -250,6 +250,16 @@ def test_ragged_embeddings_of_very_long_clips(eng):
         buf[offs[k]:offs[k] + x.size] = x
     got_r = pipe.embed_ragged_resident(buf, offs, np.array(lens), first_utt=first).cpu().numpy()
     np.testing.assert_array_equal(got_r, got)                          # the same kernels on the same bytes
+    # the arena on the device already; and a host arena uploaded in PIECES on a side stream (three upload groups here, the
+    # clips of a piece running while the next travels), the clips in another arena order than list order
+    got_d = pipe.embed_ragged_resident(torch.as_tensor(buf, device=eng.device), offs, np.array(lens), first_utt=first).cpu().numpy()
+    np.testing.assert_array_equal(got_d, got)
+    got_p = pipe.embed_ragged_resident(buf, offs, np.array(lens), max_batch_samples=600_000, first_utt=first).cpu().numpy()
+    np.testing.assert_array_equal(got_p, got)
+    rev = np.array([2, 0, 1])
+    got_s = pipe.embed_ragged_resident(buf, offs[rev], np.array(lens)[rev], max_batch_samples=600_000, first_utt=first).cpu().numpy()
+    for k, src_k in enumerate(rev):                                    # (crop draws are keyed by the index in the caller's list)
+        assert got_s[k].shape == got[src_k].shape and np.isfinite(got_s[k]).all()
     assert int(pipe.bad_clips.item()) == 0
     state = {k: v.detach().cpu() for k, v in pipe.model.state_dict().items()}
     for k, x in enumerate(clips):
