@@ -1043,7 +1043,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras:
         # host-fed variant (PCIe included; NOT `value`): 8 micro-batches of the shard from pageable host memory (the
-        # first batch's staging + H2D copy is not overlapped: with 4 batches that fill was 17 % of the measurement)
+        # first batch's H2D copy is not overlapped)
         n_host = min(n_local, 8 * (spans[0][1] - spans[0][0]))
         host_pcm = pcm[:n_host].cpu().numpy()
         pipe.embed_host(host_pcm)
@@ -1064,8 +1064,9 @@ def main():
         result["host_fed"] = {"utt_per_s": n_host / t_h, "utt_per_s_from_pinned": n_host / t_p, "clips": n_host,
                               "max_abs_diff_vs_resident": float(max((emb_h - same).abs().max().item(),
                                                                     (emb_p - same).abs().max().item())),
-                              "note": "pageable int16 NumPy -> 8-thread staging into a pinned double buffer -> copy "
-                                      "stream -> same kernels; from_pinned: the caller's buffer is already pinned"}
+                              "note": "pageable int16 NumPy, uploaded micro-batch by micro-batch from a helper thread on a copy "
+                                      "stream into a device double buffer (no staging copy on the host) -> same kernels; "
+                                      "from_pinned: the caller's buffer is pinned"}
         del pinned_pcm, host_pcm
         lo0, hi0 = spans[0]
         result["micro_batch_breakdown"] = stage_breakdown(pipe, eng, torch, pcm[lo0:hi0], 0)

@@ -570,82 +570,75 @@ class VerificationPipeline:
         return emb
 
     def embed_host(self, pcm_host, first_utt=0):
-        """Host-fed variant of `embed`: `pcm_host` is a [n, L] int16 NumPy array (e.g. decoded WAVs) or a
-        PINNED CPU torch tensor.  Micro-batches go through a copy stream and two device buffers, so the
-        H2D copy of batch k+1 overlaps the kernels of batch k (96 kB per 3 s clip over
-        PCIe).  Pageable NumPy input is first staged into two pinned buffers by 8 host threads; a
-        tensor that is already pinned is copied from where it lies."""
+        """Host-fed variant of `embed`: `pcm_host` is a [n, L] int16 NumPy array (e.g. decoded WAVs) or a CPU torch
+        tensor, pinned or not.  Micro-batches go through a copy stream and two device buffers, so the H2D copy of batch
+        k + 1 overlaps the kernels of batch k (96 kB per 3 s clip over PCIe).  A HELPER THREAD issues the
+        copies: a pageable upload holds its calling thread (the runtime stages it through its own pinned chunks, 54 GB/s on
+        the GPU box -- faster than the 20 GB/s at which this process could copy into a pinned buffer of its own, the
+        round-2 form), and the main thread keeps launching kernels."""
         if self.crop_rng != "device":
             raise ValueError("embed_host overlaps copies with compute and needs crop_rng='device'")
-        direct = isinstance(pcm_host, torch.Tensor) and pcm_host.is_pinned() and pcm_host.dtype == torch.int16
-        if isinstance(pcm_host, torch.Tensor) and not direct:
-            pcm_host = pcm_host.numpy()
-        n, L = pcm_host.shape
+        import threading
+        src = pcm_host if isinstance(pcm_host, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pcm_host))
+        if src.dtype != torch.int16 or src.dim() != 2 or src.is_cuda:
+            raise ValueError("pcm_host must be a [n, L] int16 array in host memory")
+        n, L = src.shape
         dev = self.eng.device
         spans = self.chunks(n)
+        emb = torch.empty((n, 128), dtype=torch.float32, device=dev)
+        if not spans:
+            return emb
         size = max(hi - lo for lo, hi in spans)
         key = (size, L)
-        if getattr(self, "_host_key", None) != key:      # pinned allocations are slow: keep them across calls
+        if getattr(self, "_host_key", None) != key:
             self._host_key = key
-            self._pinned = [torch.empty((size, L), dtype=torch.int16).pin_memory() for _ in range(2)]
-            self._pinned_np = [t.numpy() for t in self._pinned]          # same memory, NumPy view
             self._staged = [torch.empty((size, L), dtype=torch.int16, device=dev) for _ in range(2)]
-            from concurrent.futures import ThreadPoolExecutor
-            self._copy_pool = ThreadPoolExecutor(max_workers=8)           # np.copyto releases the GIL
             self._copy_stream = torch.cuda.Stream(device=dev)
-        pinned, staged = self._pinned, self._staged
-        copied = [torch.cuda.Event() for _ in range(2)]
-        consumed = [torch.cuda.Event() for _ in range(2)]
-        copy_stream = self._copy_stream
+        staged, copy_stream = self._staged, self._copy_stream
         main = torch.cuda.current_stream(dev)
-        # The pinned and staged buffers outlive the call.  A previous call may still have H2D copies
-        # queued that READ a pinned buffer (the host refills it below) and kernels on `main` that READ a
-        # staged buffer (the copy stream overwrites it): the host waits for the old copies, the copy
-        # stream for everything queued on `main`.
-        copy_stream.synchronize()
+        # The staged buffers outlive the call: kernels of a previous call on `main` may still READ them.
         copy_stream.wait_stream(main)
-        emb = torch.empty((n, 128), dtype=torch.float32, device=dev)
+        copied = [torch.cuda.Event() for _ in spans]
+        consumed = [torch.cuda.Event() for _ in spans]
+        issued = [threading.Event() for _ in spans]      # host side: copy k is queued / batch k's kernels are queued
+        launched = [threading.Event() for _ in spans]
+        failure = []
 
-        def launch_copy(k):
-            lo, hi = spans[k]
-            slot = k & 1
-            if direct:
+        def uploader():
+            try:
                 with torch.cuda.stream(copy_stream):
-                    if k >= 2:
-                        copy_stream.wait_event(consumed[slot])
-                    staged[slot][:hi - lo].copy_(pcm_host[lo:hi], non_blocking=True)
-                    copied[slot].record(copy_stream)
-                return
-            if k >= 2:
-                consumed[slot].synchronize()           # host: the pinned buffer may be refilled
-            # pageable -> pinned on 8 host threads (one thread moves ~4 GB/s: 94 MB per batch would
-            # take longer than the GPU needs for the batch)
-            rows = hi - lo
-            step = -(-rows // 8)
-            jobs = [self._copy_pool.submit(np.copyto, self._pinned_np[slot][a:min(rows, a + step)],
-                                           pcm_host[lo + a:lo + min(rows, a + step)])
-                    for a in range(0, rows, step)]
-            for j in jobs:
-                j.result()
-            with torch.cuda.stream(copy_stream):
-                if k >= 2:
-                    copy_stream.wait_event(consumed[slot])
-                staged[slot][:hi - lo].copy_(pinned[slot][:hi - lo], non_blocking=True)
-                copied[slot].record(copy_stream)
+                    for k, (lo, hi) in enumerate(spans):
+                        if k >= 2:                        # the slot's previous batch must have been consumed by the GPU
+                            launched[k - 2].wait()
+                            copy_stream.wait_event(consumed[k - 2])
+                        staged[k & 1][:hi - lo].copy_(src[lo:hi], non_blocking=True)
+                        copied[k].record(copy_stream)
+                        issued[k].set()
+            except BaseException as err:                  # surface it in the caller's thread
+                failure.append(err)
+                for ev in issued:
+                    ev.set()
 
-        launch_copy(0)
-        for k, (lo, hi) in enumerate(spans):
-            slot = k & 1
-            main.wait_event(copied[slot])
-            chunk = staged[slot][:hi - lo]
-            voiced, vlen = self.voiced(chunk)
-            feat, n_frames = self.features(voiced, vlen)
-            idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo,
-                                      self.bad_clips)
-            emb[lo:hi] = self.embed_features(feat, idx)
-            consumed[slot].record(main)
-            if k + 1 < len(spans):
-                launch_copy(k + 1)      # the host-side staging copy runs while the GPU works on batch k
+        worker = threading.Thread(target=uploader, daemon=True)
+        worker.start()
+        try:
+            for k, (lo, hi) in enumerate(spans):
+                issued[k].wait()
+                if failure:
+                    raise failure[0]
+                main.wait_event(copied[k])
+                chunk = staged[k & 1][:hi - lo]
+                voiced, vlen = self.voiced(chunk)
+                feat, n_frames = self.features(voiced, vlen)
+                idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo,
+                                          self.bad_clips)
+                emb[lo:hi] = self.embed_features(feat, idx)
+                consumed[k].record(main)
+                launched[k].set()
+        finally:
+            for ev in launched:                           # never leave the helper waiting
+                ev.set()
+            worker.join()
         return emb
 
     def score(self, test_emb, enroll_emb):
