@@ -321,6 +321,23 @@ class VerificationPipeline:
             out[-1] = (out[-1][0] + tail[0], out[-1][1] + tail[1])
         return out
 
+    @staticmethod
+    def _upload_groups(offsets, lengths, n_samples, max_batch_samples):
+        """A host arena cut into upload pieces: clips in arena order, a piece closed where the next clip would take it past
+        `max_batch_samples` (a single longer clip is a piece of its own).  Returns (groups of clip indices, [lo, hi) sample
+        ranges): the ranges tile [0, n_samples) and every clip lies wholly inside its group's range."""
+        by_pos = np.argsort(offsets, kind="stable")
+        ends = offsets[by_pos] + lengths[by_pos]
+        groups, pieces, lo, first = [], [], 0, 0
+        for q in range(len(by_pos)):
+            last = q + 1 == len(by_pos)
+            if last or int(ends[q + 1]) - int(offsets[by_pos[first]]) > max_batch_samples:
+                hi = n_samples if last else int(offsets[by_pos[q + 1]])
+                groups.append(by_pos[first:q + 1])
+                pieces.append((lo, hi))
+                lo, first = hi, q + 1
+        return groups, pieces
+
     def _embed_ragged_batch(self, dev_buf, offs, lens, rows, first_utt, voiced_out=None, spans=None, cube_out=None):
         """One batch of clips addressed through offsets / lengths into `dev_buf` -> their embeddings (rows = the clips'
         indices in the caller's list: they key the crop draw)."""
@@ -503,19 +520,9 @@ class VerificationPipeline:
             return emb
         # upload groups: clips by arena position, cut where a piece passes max_batch_samples (one group = everything when
         # the buffer is on the device already or small)
-        groups = [np.arange(len(lengths))]
-        pieces = [(0, n_samples)]
+        groups, pieces = [np.arange(len(lengths))], [(0, n_samples)]
         if host and n_samples > 2 * max_batch_samples:
-            by_pos = np.argsort(offsets, kind="stable")
-            ends = offsets[by_pos] + lengths[by_pos]
-            groups, pieces, lo, first = [], [], 0, 0
-            for q in range(len(by_pos)):
-                last = q + 1 == len(by_pos)
-                if last or int(ends[q + 1]) - int(offsets[by_pos[first]]) > max_batch_samples:
-                    hi = n_samples if last else int(offsets[by_pos[q + 1]])
-                    groups.append(by_pos[first:q + 1])
-                    pieces.append((lo, hi))
-                    lo, first = hi, q + 1
+            groups, pieces = self._upload_groups(offsets, lengths, n_samples, max_batch_samples)
         flags, events, worker = None, None, None
         if host:
             import threading
@@ -527,12 +534,19 @@ class VerificationPipeline:
             self._up_stream.wait_stream(torch.cuda.current_stream(dev))
             src = torch.from_numpy(buf)
 
+            failure = []
+
             def upload():   # (pageable copies hold their calling thread: a helper thread, so that the main one keeps launching)
-                with torch.cuda.stream(self._up_stream):
-                    for g, (a, b) in enumerate(pieces):
-                        dev_buf[a:b].copy_(src[a:b], non_blocking=True)
-                        events[g].record(self._up_stream)
-                        flags[g].set()
+                try:
+                    with torch.cuda.stream(self._up_stream):
+                        for g, (a, b) in enumerate(pieces):
+                            dev_buf[a:b].copy_(src[a:b], non_blocking=True)
+                            events[g].record(self._up_stream)
+                            flags[g].set()
+                except BaseException as err:   # surfaces in the caller's thread; nobody is left waiting
+                    failure.append(err)
+                    for f in flags:
+                        f.set()
             worker = threading.Thread(target=upload, daemon=True)
             worker.start()
             buf = dev_buf
@@ -546,6 +560,9 @@ class VerificationPipeline:
         for g, idx in enumerate(groups):
             if flags is not None:
                 flags[g].wait()
+                if failure:
+                    worker.join()
+                    raise failure[0]
                 main.wait_event(events[g])
             for batch, _ in self._ragged_batches(lengths[idx], max_batch_samples):
                 batch = [int(idx[b]) for b in batch]

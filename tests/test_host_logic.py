@@ -224,3 +224,29 @@ def test_tail_operand_tables_against_naive_indexing():
         K = 1152 * d + 16 * st + 4 * (lane >> 4) + el               # ((d * 16 + chunk) * 9 + pixel) * 8 + c8
         c8, pix, chunk = K % 8, (K // 8) % 9, (K // 72) % 16
         assert frag[d, nt, st, lane, el] == e.fc_w[16 * nt + (lane & 15), (8 * chunk + c8) * 36 + d * 9 + pix]
+
+
+def test_upload_groups_of_a_host_arena():
+    """`VerificationPipeline._upload_groups` (embed_ragged_resident on a host arena): pieces tile the arena, every clip lies
+    inside its group's piece, pieces stay under the cap unless one clip alone exceeds it, arena order need not be list order."""
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    rng = np.random.default_rng(3)
+    lens = rng.integers(1000, 90000, size=200).astype(np.int32)
+    lens[17] = 400000                                              # longer than the cap: a piece of its own
+    slots = (lens + 7) // 8 * 8
+    order = rng.permutation(200)                                   # clip k sits at the position of its rank in `order`
+    offs = np.zeros(200, dtype=np.int64)
+    at = 0
+    for k in order:
+        offs[k] = at
+        at += int(slots[k]) + 8 * int(rng.integers(0, 3))          # gaps between clips are allowed
+    cap = 250000
+    groups, pieces = VerificationPipeline._upload_groups(offs, lens, at, cap)
+    assert pieces[0][0] == 0 and pieces[-1][1] == at and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+    assert sorted(int(k) for g in groups for k in g) == list(range(200))
+    for g, (lo, hi) in zip(groups, pieces):
+        assert (offs[g] >= lo).all() and (offs[g] + lens[g] <= hi).all()
+        span = int((offs[g] + lens[g]).max() - offs[g].min())
+        assert span <= cap or len(g) == 1
+    assert any(len(g) == 1 and int(g[0]) == 17 for g in groups)
+    assert len(groups) > 10
