@@ -320,26 +320,16 @@ constexpr int WP_FLOATS = PD * NFRAME * WPW;               // 7 680
 // -- the fourth word of every 16 bytes is left alone), so two lanes carry a row's two halves, the row is 8 floats in LDS
 // and one instruction moves 32 rows: no staging registers, no parking writes, no per-lane address arithmetic (the register
 // path before it: twelve 8-byte loads + six ds_write_b64 per thread).  The source needs 4-byte alignment only.  Depth
-// dd's 80 rows are three pieces (32 + 32 + 16 rows, the last with half the lanes); piece n = 3 dd + part belongs to wave
-// n % 8: four or five pieces per wave and item.  A piece that is not wholly inside the clip (a wild crop start: the C-ABI
-// takes any int32) goes the slow way, lane by lane, with zeros outside -- a wave-uniform branch the pipeline's own crops
-// never take.
-struct PatchPiece { const float* src; float* dst; int rows; bool inside, valid; int start, h0; };
-__device__ __forceinline__ PatchPiece patch_piece(const Stage1Params& p, const float* base, int start, int n, float* patch) {
-  PatchPiece pc;
-  pc.valid = n < 3 * PD;
-  const int dd = n / 3, part = n - 3 * dd;
-  pc.rows = part < 2 ? 32 : 16;
-  pc.h0 = 32 * part;
-  pc.start = start;
-  pc.dst = patch + (dd * NFRAME + pc.h0) * WPW;
-  pc.inside = (unsigned)start < (unsigned)p.max_frames && pc.h0 + pc.rows <= p.max_frames - start;   // (cannot overflow for any int32 start)
-  pc.src = base + (int64_t)(start + pc.h0) * NCOEF;
-  return pc;
-}
+// dd's 80 rows are three pieces (32 + 32 + 16 rows, the last with half the lanes).
+// WHO fetches matters more than how: the workgroup's four OLDER waves (part 0) finish their tiles ~5 k cycles before the
+// younger four and wait at the item's last barrier, so they carry the whole fetch -- nine pieces each: depths pair, pair + 4,
+// pair + 8, the piece's part a compile-time constant -- and the younger waves, whose tiles end the item, none: the
+// scalar address work and the issue of a fetch spread over all eight waves cost 2.5 % of the kernel (7.70 -> 7.51 ms; a
+// build with no fetch at all: 7.33).  A piece that is not wholly inside the clip (a wild crop start: the C-ABI takes any
+// int32) goes the slow way, lane by lane, with zeros outside -- a wave-uniform branch the pipeline's own crops never take.
+struct PatchPiece { const float* src; float* dst; int rows; bool inside; int start, h0; };
 __device__ __forceinline__ void patch_piece_issue(const Stage1Params& p, const PatchPiece& pc, int lane) {
   const int rl = lane >> 1, half = lane & 1;
-  if (!pc.valid) return;
   if (pc.inside) {
     if (rl < pc.rows) __builtin_amdgcn_global_load_lds(pc.src + rl * NCOEF + 3 * half, pc.dst, 12, 0, 0);
   } else if (rl < pc.rows) {
@@ -356,16 +346,27 @@ __device__ __forceinline__ void patch_piece_issue(const Stage1Params& p, const P
     d[2] = v2;
   }
 }
-// all of a wave's pieces at once (every crop start is read BEFORE the first DMA: with one in flight the compiler drains
-// vmcnt in front of any use of an ordinary load's result -- `starts_v` is one -- which would serialise the pieces)
-__device__ __forceinline__ void dma_patch_w(const Stage1Params& p, int item, int starts_v, int wave, int lane, float* patch) {
+// the nine pieces of wave `pair` (a part-0 wave).  Every crop start is read BEFORE the first DMA: with one in flight the
+// compiler drains vmcnt in front of any use of an ordinary load's result -- `starts_v` is one -- which would serialise them.
+__device__ __forceinline__ void dma_patch_w(const Stage1Params& p, int item, int starts_v, int pair, int lane, float* patch) {
   const int u = item / 36, rem = item - u * 36, j = rem % 18;
   const float* base = p.feat + (int64_t)u * p.max_frames * NCOEF + 2 * j;
-  int st[5];
+  int st[3];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) st[k] = __builtin_amdgcn_readlane(starts_v, (wave + 8 * k < 3 * PD ? wave + 8 * k : 0) / 3);
+  for (int g = 0; g < 3; ++g) st[g] = __builtin_amdgcn_readlane(starts_v, pair + 4 * g);
 #pragma unroll
-  for (int k = 0; k < 5; ++k) patch_piece_issue(p, patch_piece(p, base, st[k], wave + 8 * k, patch), lane);
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+      PatchPiece pc;
+      pc.rows = part < 2 ? 32 : 16;
+      pc.h0 = 32 * part;
+      pc.start = st[g];
+      pc.dst = patch + ((pair + 4 * g) * NFRAME + pc.h0) * WPW;
+      pc.inside = (unsigned)st[g] < (unsigned)p.max_frames && pc.h0 + pc.rows <= p.max_frames - st[g];   // (cannot overflow for any int32 start)
+      pc.src = base + (int64_t)(st[g] + pc.h0) * NCOEF;
+      patch_piece_issue(p, pc, lane);
+    }
 }
 
 // Input transform of the depth-Winograd form for one element pair (hf = 0: elements 0, 1; 1: elements 2, 3) of the four
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
   int item = blockIdx.x;
   if (item < n_items) {
     starts = fetch_starts(p, item, lane);
-    dma_patch_w(p, item, starts, wave, lane, patch);
+    if (part == 0) dma_patch_w(p, item, starts, pair, lane, patch);
     if (item + (int)gridDim.x < n_items) starts = fetch_starts(p, item + gridDim.x, lane);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed (the compiler emits this wait too; spelt out: the barrier relies on it)
@@ -531,14 +532,12 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       // of both waves' MFMA + VALU time whichever way the five tiles are split, so 3 + 2 it is)
       // MERGE: full tiles at rows 16 part, 16 part + 8 (tl = 2 part, 2 part + 1)
       const int tl0 = MERGE ? 2 * part : (part ? 3 : 0), tl1 = MERGE ? 2 * part + 2 : (part ? 5 : 3);
-      const int fetch_tl = MERGE ? 3 * part : (part ? 4 : 0);
 #pragma unroll 1
       for (int tl = tl0; tl < tl1; ++tl) {
-        // the next item's patch (LDS-DMA): the two waves of a SIMD issue their pieces at different times, under each
-        // other's MFMAs -- part 0 in front of its first tile, part 1 in front of its second (one piece every other row
-        // tap instead of all in one burst: measured 2.7 % SLOWER)
-        if (tl == fetch_tl && next < n_items) {   // (behind barrier 1: conv1_1 has read the patch buffer)
-          dma_patch_w(p, next, starts, wave, lane, patch);
+        // the next item's patch (LDS-DMA), by the older waves in front of their first tile (behind barrier 1: conv1_1 has
+        // read the patch buffer); one piece every other row tap instead of one burst: measured 2.7 % SLOWER
+        if (part == 0 && tl == tl0 && next < n_items) {
+          dma_patch_w(p, next, starts, pair, lane, patch);
           if (next + (int)gridDim.x < n_items) starts = fetch_starts(p, next + gridDim.x, lane);
         }
         const int h0 = tl < 4 ? 8 * tl : 28;
