@@ -9,6 +9,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speaker_verification_amd import _lib                                    # noqa: E402
+if os.environ.get("SVK_TOOL_LIB"):                                            # an experiment build (make stamps EXP=... TAG=...)
+    _lib.LIB_PATH = os.environ["SVK_TOOL_LIB"]
 from speaker_verification_amd.engine import get_engine                       # noqa: E402
 from speaker_verification_amd.model import perturb_inference_state, seeded_model   # noqa: E402
 
@@ -46,6 +49,8 @@ for k, ms in rows.items():
     issued = tf * (2.0 / 3.0 if k != "fc5" else 1.0)
     print("%-8s %8.3f ms  %6.1f TFLOP/s direct-form (%.3f of 157.3), issued %.3f of the pipe" % (k, ms, tf, tf / 157.3, issued / 157.3))
 print("tail total %.3f ms per %d cubes" % (sum(rows.values()), n))
+if os.environ.get("SVK_TOOL_LIB"):
+    sys.exit(0)
 # what it replaces: MIOpen convolutions (exhaustive find) + svk_bias_prelu + F.linear
 xin = torch.randn((n, 8, 9, 5, 64), device=eng.device).permute(0, 4, 1, 2, 3)
 saved = torch.backends.cudnn.benchmark
