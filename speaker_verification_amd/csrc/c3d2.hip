@@ -1249,21 +1249,30 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
     const float* src = p.in + (int64_t)u * (S2_D * S2_H * S2_W * 16);
     constexpr int NV = 6;
     static_assert(C21W_PIX * 4 % (256 * NV) == 0, "whole rounds");
-#pragma unroll 1
-    for (int base = threadIdx.x; base < C21W_PIX * 4; base += 256 * NV) {
-      f32x4 sv[NV];
+    // piece e = t + 256 k of thread t: 16-byte piece e & 3 of pixel (t >> 2) + 64 k.  The LDS address is linear in k (64 k is a
+    // multiple of 4: 16 pix + 4 (pix >> 2) moves by 1 088 k floats); the source is (576 d + 18 hb + pix) * 16 with d = pix / 72,
+    // and for a compile-time k that is a constant plus ONE comparison of t >> 2 with the window's depth boundary: two vector
+    // instructions per piece where the division took a dozen (none of them overlaps an MFMA on this chip).
+    {
+      int tl = threadIdx.x;
+      asm volatile("" : "+v"(tl));   // (keeps this arithmetic inside the item loop: hoisted, it costs registers)
+      const int piece = tl & 3, pix0 = tl >> 2;
+      float* const a0s = reg + 16 * pix0 + 4 * (pix0 >> 2) + 4 * piece;
+      const float* const g0 = src + (int64_t)(hb * S2_W + pix0) * 16 + 4 * piece;
+      constexpr int PER_D = C21W_TH * S2_W;            // 72 staged pixels per depth, 648 in the tensor
+      constexpr int DSTEP = (S2_H * S2_W - PER_D) * 16;  // floats the source gains per depth on top of 16 pix
 #pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int e = base + 256 * k;
-        const int pix = e >> 2, piece = e & 3;
-        const int d = pix / (C21W_TH * S2_W), rem = pix - d * (C21W_TH * S2_W);  // rem = hl * 18 + w
-        sv[k] = *reinterpret_cast<const f32x4*>(src + ((int64_t)(d * S2_H + hb) * S2_W + rem) * 16 + 4 * piece);
-      }
+      for (int r0 = 0; r0 < 18; r0 += NV) {
+        f32x4 sv[NV];
 #pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int e = base + 256 * k;
-        const int pix = e >> 2, piece = e & 3;
-        *reinterpret_cast<f32x4*>(reg + 16 * pix + 4 * (pix >> 2) + 4 * piece) = sv[k];
+        for (int k = r0; k < r0 + NV; ++k) {
+          const int d_lo = (64 * k) / PER_D, cross = PER_D * (d_lo + 1) - 64 * k;   // pix0 >= cross: the next depth
+          const float* g = g0 + 1024 * k + DSTEP * d_lo;
+          if (cross < 64) g = pix0 >= cross ? g + DSTEP : g;
+          sv[k - r0] = *reinterpret_cast<const f32x4*>(g);
+        }
+#pragma unroll
+        for (int k = r0; k < r0 + NV; ++k) *reinterpret_cast<f32x4*>(a0s + 1088 * k) = sv[k - r0];
       }
     }
     if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + (int)gridDim.x : item + (int)gridDim.x;
@@ -1505,22 +1514,31 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
     // thread, seven in flight at a time
     const float* src = p.in + ((int64_t)u * A2_D + C22W_TD * q) * (S2_H * A2_W * 32) + 2 * j * 32;
     constexpr int NV = 7;
-#pragma unroll 1
-    for (int base = threadIdx.x; base < C22W_PIX * 8; base += 256 * NV) {
-      f32x4 sv[NV];
+    // piece e = t + 256 k of thread t: (16-byte piece e & 7, column wq = (e >> 3) & 1) are the thread's own, dh = (t >> 4) +
+    // 16 k.  Its LDS pixel is dh + 36 wq + 36 dl with dl = dh / 36, and 16 k + 36 dl is even, so the address is
+    // A0 + 544 k + 1 224 dl: for a compile-time k, dl is a constant plus ONE comparison of t >> 4 with the window's depth
+    // boundary -- two vector instructions per piece where the general form (a division by 36, the pixel, the pad) took a dozen
+    // (a fifth of this kernel's vector instructions, none of which overlaps an MFMA).
+    {
+      int tl = threadIdx.x;
+      asm volatile("" : "+v"(tl));   // (keeps this arithmetic inside the item loop: hoisted, it costs registers the kernel spills)
+      const int piece = tl & 7, wq = (tl >> 3) & 1, dh0 = tl >> 4;
+      const int pixb = dh0 + 36 * wq;
+      float* const a0s = reg + 32 * pixb + 4 * (pixb >> 1) + 4 * piece;
+      const float* const g0 = src + dh0 * (A2_W * 32) + wq * 32 + 4 * piece;
 #pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int e = base + 256 * k;
-        const int piece = e & 7, wq = (e >> 3) & 1, dh = e >> 4;   // dh = dl * 36 + h
-        if (e < C22W_PIX * 8) sv[k] = *reinterpret_cast<const f32x4*>(src + (int64_t)dh * (A2_W * 32) + wq * 32 + 4 * piece);
-      }
+      for (int r0 = 0; r0 < 14; r0 += NV) {
+        f32x4 sv[NV];
 #pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int e = base + 256 * k;
-        const int piece = e & 7, wq = (e >> 3) & 1, dh = e >> 4;
-        const int dl = dh / S2_H, h = dh - dl * S2_H;
-        const int pix = (dl * 2 + wq) * S2_H + h;
-        if (e < C22W_PIX * 8) *reinterpret_cast<f32x4*>(reg + 32 * pix + 4 * (pix >> 1) + 4 * piece) = sv[k];
+        for (int k = r0; k < r0 + NV; ++k)
+          if (k < 13 || tl < 128) sv[k - r0] = *reinterpret_cast<const f32x4*>(g0 + (int64_t)(16 * k) * (A2_W * 32));
+#pragma unroll
+        for (int k = r0; k < r0 + NV; ++k) {
+          const int dl_lo = (16 * k) / S2_H, cross = S2_H * (dl_lo + 1) - 16 * k;   // dh0 >= cross: the next depth
+          float* d = a0s + 544 * k + 1224 * dl_lo;
+          if (cross < 16) d = dh0 >= cross ? d + 1224 : d;
+          if (k < 13 || tl < 128) *reinterpret_cast<f32x4*>(d) = sv[k - r0];
+        }
       }
     }
     SVK_STAMP(ts1);
@@ -1673,20 +1691,29 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
     // stage [12 d][3 rows][7 w][32 c]: per depth 672 contiguous floats = 168 sixteen-byte pieces; 2 016 in all, eight
     // per thread, four in flight at a time (168 VGPRs at three workgroups per CU)
     const float* src = p.in + ((int64_t)u * 12 * 15 + 3 * rb) * (7 * 32);
-#pragma unroll 1
-    for (int base = threadIdx.x; base < 2016; base += 256 * 4) {
-      f32x4 sv[4];
+    // piece e = t + 256 k of thread t.  168 d is a multiple of 8, so the LDS address 36 (21 d + (r >> 3)) + 4 (r & 7) with
+    // r = e - 168 d is 36 (e >> 3) + 4 (e & 7): no d in it, linear in k.  The source is 4 e + 2 688 d floats, and for a
+    // compile-time k the depth d = e / 168 is a constant plus at most two comparisons of t with the window's boundaries.
+    {
+      int tl = threadIdx.x;
+      asm volatile("" : "+v"(tl));   // (keeps this arithmetic inside the item loop)
+      float* const a0s = reg + C31_PIXF * (tl >> 3) + 4 * (tl & 7);
+      const float* const g0 = src + 4 * tl;
+      constexpr int DSTEP = 15 * 7 * 32 - 4 * 168;   // floats the source gains per depth on top of 4 e
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = base + 256 * k;
-        const int d = e / 168, r = e - d * 168;
-        if (e < 2016) sv[k] = *reinterpret_cast<const f32x4*>(src + (int64_t)d * (15 * 7 * 32) + 4 * r);
-      }
+      for (int r0 = 0; r0 < 8; r0 += 4) {
+        f32x4 sv[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = base + 256 * k;
-        const int d = e / 168, r = e - d * 168;
-        if (e < 2016) *reinterpret_cast<f32x4*>(reg + C31_PIXF * (d * 21 + (r >> 3)) + 4 * (r & 7)) = sv[k];
+        for (int k = r0; k < r0 + 4; ++k) {
+          const int d_lo = (256 * k) / 168, c1 = 168 * (d_lo + 1) - 256 * k, c2 = c1 + 168;   // t >= c1 (c2): one (two) depths on
+          const float* g = g0 + 1024 * k + DSTEP * d_lo;
+          if (c1 < 256) g = tl >= c1 ? g + DSTEP : g;
+          if (c2 < 256) g = tl >= c2 ? g + DSTEP : g;
+          if (256 * k + 255 < 2016 || tl < 2016 - 256 * k) sv[k - r0] = *reinterpret_cast<const f32x4*>(g);
+        }
+#pragma unroll
+        for (int k = r0; k < r0 + 4; ++k)
+          if (256 * k + 255 < 2016 || tl < 2016 - 256 * k) *reinterpret_cast<f32x4*>(a0s + 32 * C31_PIXF * k) = sv[k - r0];
       }
     }
     if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + (int)gridDim.x : item + (int)gridDim.x;
