@@ -477,9 +477,12 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       const float* pl[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {   // (recomputed per item: this kernel has no registers to spare)
-        const int k = 4 * jj + kk;
-        const int col = (i & 1) + (k < 15 ? k % 5 : 0);   // patch column 0 .. 5 at float col + (col >= 3) of the 8-float row
-        pl[jj] = patch + 8 * WPW * wave + (i >> 1) * WPW + col + (col >= 3 ? 1 : 0) + (k < 15 ? (k / 5) * (NFRAME * WPW) : 0);
+        // tap k = 4 jj + kk = (kd, kw) = (k / 5, k % 5) without the division: kk + (4 jj mod 5) wraps at most once
+        const int t5 = kk + (4 * jj) % 5, wrap = t5 >= 5 ? 1 : 0;
+        const int kw = t5 - 5 * wrap, kd = (4 * jj) / 5 + wrap;
+        const bool pad = jj == 3 && kk == 3;                // k = 15: the zero row of the weights, any finite operand
+        const int col = (i & 1) + (pad ? 0 : kw);           // patch column 0 .. 5 at float col + (col >= 3) of the 8-float row
+        pl[jj] = patch + 8 * WPW * wave + (i >> 1) * WPW + col + (col >= 3 ? 1 : 0) + (pad ? 0 : kd * (NFRAME * WPW));
       }
       float* const al = act + 16 * WPIXF * wave + 68 * kk + i;
 #pragma unroll
@@ -583,7 +586,21 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
         }
         // rows 4 kk + r of the tile: output row h0 + 2 kk + (r >> 1), column r & 1: pool = max over r pairs
         if (MERGE || tl < 4 || kk >= 2) {
-          const f32x4 y0 = acc[0] + acc[1] + acc[2] + b2, y1 = acc[1] - acc[2] - acc[3] + b2;
+          // (packed, written out: the compiler emits scalar subtractions for the differences)
+          f32x4 y0, y1;
+          const f32x2 b22 = (f32x2){b2, b2};
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const f32x2 c0 = hf ? __builtin_shufflevector(acc[0], acc[0], 2, 3) : __builtin_shufflevector(acc[0], acc[0], 0, 1);
+            const f32x2 c1 = hf ? __builtin_shufflevector(acc[1], acc[1], 2, 3) : __builtin_shufflevector(acc[1], acc[1], 0, 1);
+            const f32x2 c2 = hf ? __builtin_shufflevector(acc[2], acc[2], 2, 3) : __builtin_shufflevector(acc[2], acc[2], 0, 1);
+            const f32x2 c3 = hf ? __builtin_shufflevector(acc[3], acc[3], 2, 3) : __builtin_shufflevector(acc[3], acc[3], 0, 1);
+            const f32x2 s0 = pk_add(pk_add(pk_add(c0, c1), c2), b22), s1 = pk_add(pk_sub(pk_sub(c1, c2), c3), b22);
+            y0[2 * hf] = s0[0];
+            y0[2 * hf + 1] = s0[1];
+            y1[2 * hf] = s1[0];
+            y1[2 * hf + 1] = s1[1];
+          }
           float* const o00 = obase + (int64_t)(h0 / 2) * p.s_hp;
           float* const o01 = o00 + p.s_par;
           float* const o10 = o00 + p.s_d;
