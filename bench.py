@@ -63,10 +63,10 @@ MFMA_FLOP = 2048                 # v_mfma_f32_16x16x4_f32: 16 x 16 x 4 multiply-
 # per cube BY CONSTRUCTION (items x tiles x taps x 4-deep steps) -- replaced at run time by the committed
 # SQ_INSTS_MFMA counter of profiles/rNN_frontend_pmc.json when that file has the kernel (they agree to 1e-4).
 NETWORK_KERNELS = (
-    ("stage1", ("c3d2_stage1w_kernel",), 12.4416 + 143.327232, 118080),         # 36 items x (400 conv1_1 + 2 880 conv1_2)
+    ("stage1", ("c3d2_stage1w_kernel",), 12.4416 + 143.327232, 36 * (400 + 18 * 144)),   # 36 items x (conv1_1 + 18 tiles of conv1_2)
     ("stage2", ("c3d2_conv21w_kernel", "c3d2_conv22w_kernel"), 46.44864 + 66.3552, 32256 + 43008),
     ("conv3_1", ("c3d2_conv31w_kernel",), 13.824, 9600),
-    ("conv3_2", ("c3d2_conv32w_kernel",), 30.96576, 21504),
+    ("conv3_2", ("c3d2_tail_kernel<Conv32T>",), 30.96576, 20160),          # 20 items x 8 chunks x 28 steps x 18 MFMAs x 4 waves / 16 cubes
     ("conv4_1", ("c3d2_tail_kernel<Conv41>",), 11.943936, 7776),            # 9 items x 4 phases x 24 steps x 18 x 8 waves / 16 cubes
     ("conv4_2", ("c3d2_tail_kernel<Conv42>",), 12.386304, 8064),
     ("fc5", ("fc5_kernel",), 0.589824, 576),                                   # 4 K ranges x 72 steps x 16 x 8 waves / 64 cubes
@@ -88,7 +88,10 @@ def parse(argv=None):
     ap.add_argument("--no-vad", action="store_true")
     ap.add_argument("--no-cmvn", action="store_true")
     ap.add_argument("--no-preemph", action="store_true")
-    ap.add_argument("--no-channels-last", action="store_true")
+    ap.add_argument("--random-init", action="store_true",
+                    help="seeded random-init C3D2 with calibrated BatchNorm (rounds 1-3) instead of the committed trained checkpoint")
+    ap.add_argument("--checkpoint", default=os.path.join(REPO, "speaker_verification_amd", "checkpoints", "c3d2_synth.pt"),
+                    help="{'state_dict': ...} of a C3D2 (reference format, model.py:177-186); loaded weights-only")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel side benches (profiling runs)")
     ap.add_argument("--frontend-only", action="store_true", help="time BASELINE config 2 only (for rocprof)")
     ap.add_argument("--stages-only", action="store_true", help="time the stage-level kernels only (for rocprof)")
@@ -246,24 +249,51 @@ def pmc_traffic(kernel):
     if not files:
         return None, None
     try:
-        rec = json.load(open(files[-1])).get(kernel, {})
+        doc = json.load(open(files[-1]))
     except (OSError, ValueError):
         return None, None
+    rec = doc.get(kernel) or doc.get(kernel + "<merged>") or {}
     return rec.get("hbm_traffic_bytes_per_launch"), os.path.basename(files[-1])
 
 
 def pmc_counter(kernel, counter, per=1024.0):
     """`counter` per cube of `kernel` from the newest committed PMC summary (the c3d2_* kernels were profiled over
-    `bench.py --c3d2-only`: 1 024 cubes per launch), or None."""
+    `bench.py --c3d2-only`: 1 024 cubes per launch), or None.  (Round 3's summaries call the first block
+    "c3d2_stage1w_kernel<merged>": the same kernel before the other forms were pruned.)"""
     import glob
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_frontend_pmc.json")), reverse=True):
         try:
-            rec = json.load(open(path)).get(kernel, {})
+            doc = json.load(open(path))
         except (OSError, ValueError):
             continue
+        rec = doc.get(kernel) or doc.get(kernel + "<merged>") or {}
         if counter in rec:
             return rec[counter] / per, os.path.basename(path)
     return None, None
+
+
+def pmc_provenance(name):
+    """(what profiles/<name> says it was collected from, whether that differs from the kernel sources this run uses)."""
+    from speaker_verification_amd import _lib
+    now = _lib.provenance()
+    try:
+        was = json.load(open(os.path.join(REPO, "profiles", name))).get("_provenance") or {}
+    except (OSError, ValueError, TypeError):
+        was = {}
+    return was, now, was.get("csrc_sha") != now["csrc_sha"]
+
+
+def committed_one_gpu_value(world):
+    """{"one_gpu_value", "n_times_one_gpu_value", "source"} from the newest committed 1-GPU bench line under profiles/."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_bench.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("n_gpus") == 1 and rec.get("value"):
+            return {"one_gpu_value": rec["value"], "n_times_one_gpu_value": world * rec["value"], "source": os.path.basename(path)}
+    return None
 
 
 def _median_ms(torch, fn, reps, warm=3):
@@ -583,6 +613,21 @@ def _cpu_count_frames(i):
     return _cpu_features(i).shape[0]
 
 
+def _cpu_worker_ready(counter):
+    """Pool initializer: one untimed pass of the whole chain in THIS worker (imports, first-touch of the mapped sample,
+    torch-CPU's first convolution), then report in."""
+    _cpu_chain(0)
+    with counter.get_lock():
+        counter.value += 1
+
+
+def _cpu_score_rows(job):
+    """evaluation.py:73-77 for a block of test embeddings: one sklearn-style call per (utterance, speaker) pair."""
+    from oracle import scoring_ref
+    rows, enroll = job
+    return [scoring_ref.compute_similarity(r, enroll) for r in rows]
+
+
 def cpu_child(sample_dir):
     """Runs with OMP/MKL/OPENBLAS_NUM_THREADS=1 in the environment (set by the parent before this
     interpreter started, i.e. before NumPy was imported).  Prints one JSON object."""
@@ -634,15 +679,25 @@ def cpu_child(sample_dir):
     out["chain_sweep"] = {}
     best = None
     for workers in sweep:
-        with ctx.Pool(workers) as pool:
-            pool.map(_cpu_count_frames, range(min(n, 2 * workers)), chunksize=1)      # warm: imports, first-touch
+        ready = ctx.Value("i", 0)
+        with ctx.Pool(workers, initializer=_cpu_worker_ready, initargs=(ready,)) as pool:
+            t_w = time.perf_counter()
+            while ready.value < workers and time.perf_counter() - t_w < 120:          # every worker has run the chain once
+                time.sleep(0.01)
+            t_ready = time.perf_counter() - t_w
             t0 = time.perf_counter()
             embs_w = np.stack(pool.map(_cpu_chain, range(n), chunksize=max(1, n // (8 * workers))))
+            t_chain = time.perf_counter() - t0
+            # pair-by-pair scoring (evaluation.py:73-77), spread over the same workers
             enroll = embs_w[::max(1, n // 40)][:40]
-            for i in range(n):                                                       # evaluation.py:73-77, pair by pair
-                scoring_ref.compute_similarity(embs_w[i], enroll)
-            dt_w = time.perf_counter() - t0
-        out["chain_sweep"][str(workers)] = {"utt_per_s": n / dt_w, "seconds": dt_w, "workers": workers}
+            rows_per_job = max(1, n // (4 * workers))
+            t0 = time.perf_counter()
+            pool.map(_cpu_score_rows, [(embs_w[lo:lo + rows_per_job], enroll) for lo in range(0, n, rows_per_job)], chunksize=1)
+            t_score = time.perf_counter() - t0
+        dt_w = t_chain + t_score
+        out["chain_sweep"][str(workers)] = {"utt_per_s": n / dt_w, "seconds": dt_w, "workers": workers,
+                                            "chain_utt_per_s": n / t_chain, "chain_s": t_chain, "scoring_s": t_score,
+                                            "warm_s": t_ready}
         if best is None or n / dt_w > best[0]:
             best = (n / dt_w, dt_w, workers)
         embs = embs_w                                                                # (identical whatever the pool size)
@@ -719,14 +774,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if world > 1:
-        # one MIOpen find-db / kernel cache per rank: N processes searching kernels at once would
-        # otherwise contend for the same sqlite files under ~/.config/miopen and ~/.cache/miopen
-        import tempfile
-        tag = os.path.join(tempfile.gettempdir(), "svk_miopen_rank%d" % local_rank)
-        os.makedirs(tag, exist_ok=True)
-        os.environ.setdefault("MIOPEN_USER_DB_PATH", tag)
-        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", tag)
+    # (before torch: the host driver of this pool only supports dmabuf IPC; RCCL's intra-node transport needs this)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     from datetime import timedelta
@@ -743,7 +792,6 @@ def main():
     torch.cuda.set_device(device_index)
     use_dist = world > 1 or os.environ.get("SVK_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL with one rank
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         with _stdout_to_stderr():
             # a rank that died before the rendezvous must not hold the others for torch's default 10 / 30 minutes
             # (the launcher ends them within seconds; under torch.distributed.run this timeout is the bound)
@@ -757,7 +805,7 @@ def main():
 
     from speaker_verification_amd import constants as c, distributed as svdist, evaluation, synth
     from speaker_verification_amd.engine import get_engine
-    from speaker_verification_amd.model import calibrate_batchnorm, seeded_model
+    from speaker_verification_amd.model import C3D2, calibrate_batchnorm, seeded_model
     from speaker_verification_amd.pipeline import VerificationPipeline, enroll_last_utterance
 
     eng = get_engine(device_index)
@@ -774,47 +822,59 @@ def main():
                           "cosine_mfma": cosine_mfma_bench(eng, torch)}))
         return 0
 
+    def bench_model():
+        """The committed trained checkpoint (tools/train_synth_checkpoint.py: 100 synthetic speakers disjoint from the
+        corpus's, reference format, loaded weights-only), or with --random-init the seeded random-init network of rounds 1-3."""
+        if args.random_init:
+            return seeded_model(2024, n_labels=1211), {"weights": "random-init (seed 2024), BatchNorm calibrated on 256 clips"}
+        ck = torch.load(args.checkpoint, map_location="cpu", weights_only=True)
+        m = C3D2(int(ck["state_dict"]["FC6.weight"].shape[0]), 1)
+        m.load_state_dict(ck["state_dict"])
+        meta = {k: ck.get("meta", {}).get(k) for k in ("tool", "speakers", "utts_per_speaker", "steps", "init_seed", "clip_seed",
+                                                        "held_out_eer")}
+        meta["weights"] = os.path.relpath(args.checkpoint, REPO)
+        return m.eval(), meta
+
     if args.ragged_only:
-        pipe = VerificationPipeline(seeded_model(2024, n_labels=1211), use_vad=not args.no_vad, normalize=not args.no_cmvn,
+        pipe = VerificationPipeline(bench_model()[0], use_vad=not args.no_vad, normalize=not args.no_cmvn,
                                     preemph_cof=None if args.no_preemph else 0.98, crop_rng="device", micro_batch=1024)
         print(json.dumps(ragged_bench(pipe, eng, torch)))
         return 0
     if args.c3d2_only:
         pcm, _ = synth.corpus_device(1024, dev, first_clip=0, utts_per_speaker=UTTS_PER_SPK)
-        pipe = VerificationPipeline(seeded_model(2024, n_labels=1211), use_vad=not args.no_vad, normalize=not args.no_cmvn,
+        pipe = VerificationPipeline(bench_model()[0], use_vad=not args.no_vad, normalize=not args.no_cmvn,
                                     preemph_cof=None if args.no_preemph else 0.98, crop_rng="device", micro_batch=1024)
         voiced, vlen = pipe.voiced(pcm)
         feat, n_frames = pipe.features(voiced, vlen)
         idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, 0, pipe.bad_clips)
         ms = _median_ms(torch, lambda: pipe.embed_features(feat, idx), max(args.steps, 5))
-        print(json.dumps({"workload": "1024 cubes: svk_c3d2_stage1 + stage2 + conv31 + conv32 + conv41 + conv42 + fc5",
+        print(json.dumps({"workload": "1024 cubes: svk_c3d2_stage1 + stage2 + conv31 + conv32t + conv41 + conv42 + fc5",
                           "ms": ms, "utt_per_s": 1024 / ms * 1e3, "tflops": 1024 * C3D2_GFLOP_PER_UTT / ms}))
         return 0
     n_total = args.corpus
     lo_r, hi_r = svdist.shard_bounds(n_total, world, rank)
     n_local = hi_r - lo_r
     pcm, _ = synth.corpus_device(n_local, dev, first_clip=lo_r, utts_per_speaker=UTTS_PER_SPK)
-    model = seeded_model(2024, n_labels=1211)
+    model, weights_meta = bench_model()
     pipe = VerificationPipeline(model, use_vad=not args.no_vad, normalize=not args.no_cmvn,
                                 preemph_cof=None if args.no_preemph else 0.98, crop_rng="device",
-                                micro_batch=args.micro_batch, channels_last=not args.no_channels_last,
+                                micro_batch=args.micro_batch,
                                 overlap_front=os.environ.get("SVK_BENCH_OVERLAP", "0") == "1")
-    # random-init weights (no checkpoint ships) with BatchNorm statistics calibrated on the first 256 clips
-    # of the corpus, identically on every rank (model.calibrate_batchnorm explains why)
-    # The statistics come from a training-mode forward of the torch module: run on the HOST (torch-CPU, a few seconds,
-    # outside the timed region) so that this process never calls MIOpen -- the inference path is libsvk end to end.
-    cal_pcm, _ = synth.corpus_device(256, dev, first_clip=0, utts_per_speaker=UTTS_PER_SPK)
-    _, cal_cubes = pipe.crops_and_cubes(cal_pcm)
-    threads = torch.get_num_threads()
-    torch.set_num_threads(max(1, min(32, threads)))        # (every hardware thread of a 256-thread host is far slower)
-    cpu_model = seeded_model(2024, n_labels=1211)
-    calibrate_batchnorm(cpu_model, cal_cubes.cpu())
-    torch.set_num_threads(threads)
-    pipe.model.load_state_dict(cpu_model.state_dict())
-    pipe.refresh_model()
-    assert pipe.embedder.tail_in_libsvk() or os.environ.get("SVK_C3D2_CONV4") == "0" or os.environ.get("SVK_C3D2_TAIL") == "0" \
-        or not pipe.stage2_kernel
-    del cal_pcm, cal_cubes, cpu_model
+    if args.random_init:
+        # random-init weights with BatchNorm statistics calibrated on the first 256 clips of the corpus, identically on
+        # every rank (model.calibrate_batchnorm explains why).  The statistics come from a training-mode forward of the
+        # torch module: run on the HOST (torch-CPU, a few seconds, outside the timed region) with this rank's share of the
+        # host's threads (8 ranks x 32 threads at once would oversubscribe it)
+        cal_pcm, _ = synth.corpus_device(256, dev, first_clip=0, utts_per_speaker=UTTS_PER_SPK)
+        _, cal_cubes = pipe.crops_and_cubes(cal_pcm)
+        threads = torch.get_num_threads()
+        torch.set_num_threads(max(1, min(32, threads, (os.cpu_count() or 1) // world)))
+        cpu_model = seeded_model(2024, n_labels=1211)
+        calibrate_batchnorm(cpu_model, cal_cubes.cpu())
+        torch.set_num_threads(threads)
+        pipe.model.load_state_dict(cpu_model.state_dict())
+        pipe.refresh_model()
+        del cal_pcm, cal_cubes, cpu_model
     n_test = min(N_TEST, n_total)
     spk_all = (np.arange(n_total) // UTTS_PER_SPK).astype(np.int32)
     ids, last = enroll_last_utterance(None, spk_all[:n_test])                  # Q17: last utterance enrols
@@ -911,8 +971,7 @@ def main():
                              "share_of_step": float(fe_ms.sum()) / args.steps / ms_per_step}
         main_roofline = frontend_roofline
         stage2_roofline, network_rows, issued_gflop_per_utt = None, None, None
-        wino = bool(getattr(pipe, "depth_transform", False))
-        if kernel_events and wino:
+        if kernel_events:
             # Every network kernel, from HIP events on the launch stream around each launch of the timed region.
             #   frac            = ISSUED matrix work / time / peak: MFMA wave-instructions per cube (the committed SQ_INSTS_MFMA
             #                     counter; by construction when no profile has the kernel) x 2 048 FLOP x cubes -- a share of
@@ -924,15 +983,6 @@ def main():
             issued_gflop_per_utt = 0.0
             covered_ms = 0.0
             for name, symbols, mmac, mfma_design in NETWORK_KERNELS:
-                if name == "stage1" and getattr(pipe, "stage1_t_planes", False):
-                    # the t-plane experiment: 72 items x (240 conv1_1 + 9 x 144 conv1_2) MFMAs per cube
-                    symbols, mfma_design = ("c3d2_stage1t_kernel",), 72 * (240 + 9 * 144)
-                elif name == "stage1" and getattr(pipe, "stage1_merged", False):
-                    # round 3: 36 items x (400 conv1_1 + 18 tiles x 144 conv1_2): the remainder rows of two depth pairs share a tile
-                    symbols, mfma_design = ("c3d2_stage1w_kernel<merged>",), 36 * (400 + 18 * 144)
-                if name == "conv3_2" and getattr(pipe.embedder, "conv32t_kernel", False):
-                    # conv3_2 in the last block's shape: 20 items x 8 chunks x 28 steps x 18 MFMAs x 4 waves per 16 cubes, no padding
-                    symbols, mfma_design = ("c3d2_tail_kernel<Conv32T>",), 20160
                 evs = [sp[name] for sp in kernel_events if name in sp]
                 if not evs:
                     continue
@@ -962,6 +1012,8 @@ def main():
                     "algorithmic_frac": tf_alg / F32_MATRIX_PEAK_TFLOPS, "kernel": " + ".join(symbols),
                     "avg_launch_ms": ms / len(evs), "cubes_per_launch": cubes_total / len(evs),
                     "mfma_per_cube": mfma, "mfma_per_cube_by_construction": mfma_design, "mfma_source": src[0],
+                    "counters_from": None if not all(src) or src[0].startswith("by ") else pmc_provenance(src[0])[0] or "no provenance recorded",
+                    "stale": None if not all(src) or src[0].startswith("by ") else pmc_provenance(src[0])[2],
                     "direct_form_mmac_per_cube": mmac, "share_of_step": ms / args.steps / ms_per_step,
                     "valu_per_mfma": valu_per_mfma,
                     "fp32_lanes_busy": None if valu_per_mfma is None
@@ -979,26 +1031,20 @@ def main():
                         "time / 157.3 TFLOP/s (MI355X_MICROARCH.md): the share of the f32 matrix pipe's issue slots.  "
                         "algorithmic_frac counts SURVEY 8(d)'s direct-form multiply-adds (conv1_1 12.44 M + conv1_2 143.33 M per "
                         "cube) instead and exceeds it because conv1_2 issues 2/3 of its products while conv1_1 recomputes the "
-                        "depth halo per item (24 depths for 18 in the t-plane form, 20 in the round-2 form, which also issues "
-                        "40 rows of conv1_2 for every 36) with K padded 15 -> 16"})
+                        "depth halo per item (20 depths for 18) with K padded 15 -> 16.  `stale`: the committed counters were "
+                        "collected from other kernel sources than this run's (csrc_sha differs); SQ_INSTS_MFMA is then checked "
+                        "against mfma_per_cube_by_construction, valu_per_mfma / fp32_lanes_busy describe the profiled code",
+                "this_run": pmc_provenance("")[1]})
             stage2_roofline = network_rows.get("stage2")
             network_rows["_covered_share_of_step"] = covered_ms / args.steps / ms_per_step
-        elif kernel_events:
-            # direct-form kernels (SVK_C3D2_DEPTH_TRANSFORM=0): issued = algorithmic up to tile padding
-            evs = [sp["stage1"] for sp in kernel_events if "stage1" in sp]
-            ms = float(sum(a.elapsed_time(b) for a, b in evs))
-            cubes_total = float(sum(sp["cubes"] for sp in kernel_events))
-            tf1 = cubes_total * STAGE1_GFLOP_PER_UTT / ms
-            main_roofline = {"bound": "mfma", "achieved": tf1, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tf1 / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
-                             "kernel": "c3d2_stage1_kernel (cube + conv1_1 + conv1_2 + pool1, direct form)",
-                             "avg_launch_ms": ms / len(evs), "cubes_per_launch": cubes_total / len(evs),
-                             "share_of_step": ms / args.steps / ms_per_step}
         result = {
             "metric": "utterances/sec (MFCC->embed->cosine)", "value": value, "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (seeded formant 'voices', 3 s / 16 kHz int16, generated on device; random-init C3D2)",
+            "data": "synthetic (seeded formant 'voices', 3 s / 16 kHz int16, generated on device); C3D2 weights: %s"
+                    % ("seeded random init" if args.random_init else
+                       "the committed checkpoint trained on synthetic speakers disjoint from the corpus's (tools/train_synth_checkpoint.py)"),
+            "weights": weights_meta,
             "config": {"workload": "configs[4]: %d-clip corpus over %d rank(s) (%d clips on rank 0): energy-VAD -> pre-emph + "
                                    "lmfe(25ms/10ms/1024/40) -> CMVN -> 20x80x40 cube -> C3D2(f32) -> all-gather -> "
                                    "%dx%d cosine" % (n_total, world, n_local, n_test, len(ids)),
@@ -1010,6 +1056,9 @@ def main():
             "allgather_us": float(np.median([a.elapsed_time(b) for a, b in ag_events])) * 1e3 if use_dist else None,
             "allgather_bytes_per_rank": svdist.shard_rows(n_total, world) * 128 * 4,
             "per_rank_ms": per_rank_ms,
+            "slowest_rank": int(np.argmax(per_rank_ms)), "fastest_rank": int(np.argmin(per_rank_ms)),
+            # what N GPUs would do at the committed 1-GPU rate (the driver computes the efficiency from its own per-N runs)
+            "scaling_efficiency_vs": committed_one_gpu_value(world),
             # what shaped RCCL's choice of algorithm / transport, when the caller set any of it (NCCL_DEBUG=INFO prints the
             # ring / tree and the xGMI links picked to each rank's stderr file under gpurun_out/bench_ranks/)
             "rccl_env": {k: v for k, v in os.environ.items()
@@ -1036,9 +1085,11 @@ def main():
                                      "Winograd F(2,3) along depth and issue 2/3 of theirs"},
             "eer": {"eer": eer, "auc": auc, "eer_device": eer_dev, "auc_device": auc_dev, "pairs": int(labels.size),
                     "short_clips": bad,
-                    "note": "random-init C3D2 (no checkpoint ships offline): an EER near 0.5 is that of an untrained network.  The "
-                            "statement is numerical -- host sklearn path = svk_roc_eer = CPU oracle on the same scores, and GPU = "
-                            "CPU EER from PCM on the parity sample -- not an operating point of a trained model"},
+                    "note": ("random-init C3D2 (--random-init): an EER near 0.5 is that of an untrained network; the statement is "
+                             "numerical only" if args.random_init else
+                             "C3D2 trained on 100 synthetic speakers that are not in the corpus (speaker_verification_amd/checkpoints/"
+                             "c3d2_synth.json): the 40 test speakers are unseen, the EER is an operating point on a steep ROC")
+                            + ".  Host sklearn path = svk_roc_eer = CPU oracle on the same scores; GPU = CPU EER from PCM on the parity sample"},
         }
 
     if rank == 0 and world == 1 and not args.no_extras:
@@ -1111,7 +1162,8 @@ def main():
                 "value": rec["value"], "unit": "utterances/s", "cores": rec["workers"], "kind": "port",
                 "sample": "the first %d clips of the corpus through oracle/ in a fresh process: vad -> /32768 -> preemph "
                           "-> lmfe -> cmvn -> cube -> C3D2 batch 1 -> per-pair cosine, single-threaded workers "
-                          "(multiprocessing.Pool): the best of %s workers = %d (%.1f s); the host shows %d hardware threads"
+                          "(multiprocessing.Pool; every worker runs the chain once before the clock starts; scoring spread "
+                          "over the same workers): the best of %s workers = %d (%.1f s); the host shows %d hardware threads"
                           % (ns, sorted(int(k) for k in rec["chain_sweep"]), rec["workers"], rec["seconds"], rec["cores"]),
                 "host_threads": rec["cores"], "chain_by_workers": rec["chain_sweep"],
                 "cpu_model": rec["cpu_model"], "os_cpu_count": rec["os_cpu_count"], "versions": rec["versions"],

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 105 /* 0.1.4: + svk_c3d2_conv32t */
+#define SVK_VERSION 106 /* 0.1.5: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone) */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -177,17 +177,6 @@ int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t* d_offsets,
 int svk_cube_gather(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, float* d_out);
 
-/* The same cube, already unfolded for the first C3D2 layer (model.py:110, Conv3d(1, 16, (kd, 1, kw))) run
- * as one GEMM: row (u, d, h, wg) of d_out holds, for the kd consecutive crops d .. d + kd - 1, the
- * kw + group - 1 coefficients shared by the `group` adjacent output columns wg * group ..:
- *     d_out[((u * od + d) * crop_frames + h) * (ow / group) + wg][kdi * (kw + group - 1) + j]
- *         = feat[u][crop[u][d + kdi] + h][wg * group + j],     od = n_crops - kd + 1, ow = n_cols - kw + 1.
- * group must divide ow; group, kw + group - 1 and n_cols must be multiples of 4 (16-byte copies), else
- * SVK_ERR_UNSUPPORTED (build the cube with svk_cube_gather instead).                                        */
-int svk_cube_gather_windows(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
-                            const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, int32_t kd,
-                            int32_t kw, int32_t group, float* d_out);
-
 /* Crop starts drawn ON THE DEVICE (no host round trip for the per-clip frame count):
  * crop[u][c] = floor(uniform(seed, u, c) * (n_frames[u] - crop_frames)), a counter-based
  * generator (splitmix64 of seed, g, c) with g = d_utt_index[u] when that array is given (clips of a
@@ -245,36 +234,28 @@ int svk_roc_eer(svk_ctx* ctx, const float* d_scores, const uint8_t* d_labels, in
  *   d_w2frag [27][64][4] float: lane (co = l & 15, kk = l >> 4), element e = W2[co][ci = 4 kk + e][kd][kh] of
  *                       tap t = 9 kd + kh;   d_bias2 [16];   d_slope1 / d_slope2 [16] PReLU slopes per channel
  * d_feat [n_utt][max_frames][40], d_crop_idx [n_utt][20] as for svk_cube_gather (crop -1 -> zero cube).
- * d_out: the activation after the pool, float32, channels last:
- * `folded` bit 1 (value 2) = the caller asserts every PReLU slope lies in [0, 1] (then prelu(v) = max(v, slope v): two
- * instructions per value instead of four); bit 2 (value 4) = conv1_2 through Winograd's F(2, 3) along depth (every
- * C3D2 kernel is 3 taps deep: 2 / 3 of the multiply-adds; the transformed weights are derived in the kernel from the
- * same d_w2frag; the same sums in another association, ~1e-6 relative from the direct form); bit 3 (value 8) = the same
- * transform with its input side applied ONCE, where conv1_1's output is produced (c3d2_stage1t_kernel: t planes in LDS,
- * no vector work in conv1_2's loop; needs d_feat 16-byte aligned; takes precedence over bit 2; measured slower than bit 2 +
- * bit 4, kept as an experiment); bit 4 (value 16, with bit 2) = the remainder rows 32 .. 35 of two depth pairs share one M
- * tile, cut by accumulator over the workgroup's eight waves (- 10 % MFMAs; rows 0 .. 31 bit-identical; the default of
- * speaker_verification_amd.pipeline); bit 0 picks the layout:
- *   folded = 0: [n_utt][16 d][36 h][18 w][16 c]
- *   folded = 1: [n_utt][16 d][18 h/2][18 w][2 (h & 1)][16 c]   (= a (n, 32, 16, 18, 18) channels-last tensor:
- *               the row-parity-in-channels form model.FusedEmbedder feeds conv2_1 / conv2_2)
- * Geometry other than the 20 x 80 x 40 cube -> SVK_ERR_UNSUPPORTED (run those layers on the host framework). */
+ * conv1_2 runs through Winograd's F(2, 3) along depth (every C3D2 kernel is 3 taps deep: 2 / 3 of the multiply-adds; the
+ * transformed weights are derived in the kernel from d_w2frag; the same sums in another association, ~1e-6 relative from
+ * the direct form); the remainder rows 32 .. 35 of two depth pairs share one M tile, cut by accumulator over the
+ * workgroup's eight waves.
+ * d_out: the activation after the pool, float32, channels last: [n_utt][16 d][36 h][18 w][16 c]
+ * flags bit 1 (value 2) = the caller asserts every PReLU slope lies in [0, 1] (then prelu(v) = max(v, slope v): two
+ * instructions per value instead of four); every other bit must be 0.
+ * Geometry other than the 20 x 80 x 40 cube -> SVK_ERR_UNSUPPORTED (the torch module is the path for other models). */
 size_t svk_c3d2_stage1_lds_bytes(void);
 int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const float* d_w1frag,
                     const float* d_bias1, const float* d_slope1, const float* d_w2frag, const float* d_bias2,
-                    const float* d_slope2, int32_t folded, float* d_out);
+                    const float* d_slope2, int32_t flags, float* d_out);
 
 /* The second block, model.py:119-124 + :151-158: conv2_1 (16 -> 32, kernel (3,1,4)) -> BN -> PReLU -> conv2_2
  * (32 -> 32, kernel (3,8,1), stride (1,2,1)) -> BN -> PReLU -> MaxPool3d((1,1,2)), two f32-MFMA kernels with the
- * input region of a work item in LDS and the weights in registers; epilogues carry bias, PReLU and the pool.
- *   d_in     [n_utt][16][36][18][16]  = svk_c3d2_stage1's output with folded = 0
+ * input region of a work item in LDS and the weights in registers, both through Winograd's F(2, 3) along depth (the
+ * transformed weights derived in the kernels from the direct-form fragments below); epilogues carry bias, PReLU and the pool.
+ *   d_in     [n_utt][16][36][18][16]  = svk_c3d2_stage1's output
  *   d_w21frag [2 nt][12 taps][64][4]  : lane (co = 16 nt + (l & 15), kk = l >> 4), e: W21[co][4 kk + e][kd][kw], tap 4 kd + kw
  *   d_w22frag [2 nt][24 taps][2][64][4]: W22[co][16 chunk + 4 kk + e][kd][kh], tap 8 kd + kh;  biases / slopes [32]
- *   flags    bit 0: conv2_1 through Winograd's F(2, 3) along depth (2 / 3 of the multiply-adds; the same sums in
- *            another association, ~1e-6 relative from the direct form), derived in the kernel from the same fragments;
- *            bit 1: the caller asserts every PReLU slope lies in [0, 1] (as `folded` bit 1 of svk_c3d2_stage1)
- *            bit 2: conv2_2 through the same transform
+ *   flags    bit 1: the caller asserts every PReLU slope lies in [0, 1]; every other bit must be 0
  *   d_act2   [n_utt][14][36][15][32]  scratch the caller provides (conv2_1's output)
  *   d_out    [n_utt][12][15][7][32]   the activation after pool2, channels last                                  */
 int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_w21frag, const float* d_bias21,
@@ -282,35 +263,21 @@ int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float*
                     int32_t flags, float* d_act2, float* d_out);
 
 /* conv3_1 (32 -> 64, kernel (3,1,3)) -> BN -> PReLU, model.py:126-128 + :159-161, one f32-MFMA kernel through Winograd's
- * F(2, 3) along depth (as svk_c3d2_stage2 flags bits 0 / 2; there is no direct-form variant of this one).
+ * F(2, 3) along depth.
  *   d_in    [n_utt][12][15][7][32]   = svk_c3d2_stage2's output
  *   d_wfrag [4 nt][9 taps][2 chunks][64][4]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: W31[co][16 chunk + 4 kk + e][kd][kw],
  *           tap 3 kd + kw (BatchNorm folded);  d_bias / d_slope [64]
- *   flags   bit 1: the caller asserts every PReLU slope lies in [0, 1]
- *   d_out   [n_utt][10][15][5][64]   channels last                                                                    */
+ *   flags   bit 1: the caller asserts every PReLU slope lies in [0, 1]; every other bit must be 0
+ *   d_out   [n_utt][10 d][8 chunks of 8 channels][5 w][15 h][8]: chunked and column-major, what svk_c3d2_conv32t stages from */
 int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);
-
-/* conv3_2 (64 -> 64, kernel (3,7,1)) -> BN -> PReLU, model.py:129-131 + :162-164, depth-transformed; its transformed
- * weights do not fit one workgroup's registers: two workgroup roles (a pair of 16-channel N tiles each), eight waves =
- * (N tile, 16-channel K chunk), partial sums over the four chunks added through LDS.
- *   d_in    [n_utt][10][15][5][64]   = svk_c3d2_conv31's output
- *   d_wfrag [4 nt][21 taps][4 chunks][64][4]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: W32[co][16 chunk + 4 kk + e][kd][kh],
- *           tap 7 kd + kh (BatchNorm folded);  d_bias / d_slope [64];  flags bit 1: every PReLU slope lies in [0, 1]
- *   d_out   [n_utt][8][9][5][64]     channels last                                                                    */
-int svk_c3d2_conv32(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
-                    const float* d_slope, int32_t flags, float* d_out);
-/* (flags bit 3 of svk_c3d2_conv31: write d_out chunked and column-major, [n_utt][10 d][8 chunks of 8 channels][5 w][15 h][8] --
- * the layout svk_c3d2_conv32t stages from)                                                                              */
-/* (flags bit 3 of svk_c3d2_conv32: write d_out CHUNKED, [n_utt][8 d][8 chunks of 8 channels][45 = 9 h x 5 w][8] -- the
- * layout svk_c3d2_conv41 stages from: a chunk of a plane is contiguous)                                              */
 
 /* The last block, model.py:132-139 (definitions) + :165-170 (forward): conv4_1 (64 -> 128, kernel (3,1,3)) -> BN -> PReLU,
  * conv4_2 (128 -> 128, kernel (3,7,1)) -> BN -> PReLU, flatten, FC5 (4 608 -> 128) -- GEMMs over the BATCH on
  * v_mfma_f32_16x16x4_f32 (csrc/c3d2_tail.hip): an M tile is one output position of 16 cubes, the convolutions run
  * through Winograd's F(2, 3) along depth with the input transform applied once while a chunk is staged into LDS and the
  * weight transform applied by the HOST.  Activations between these kernels are chunked: [cube][depth][channel / 8][pixel][channel % 8].
- *   svk_c3d2_conv41  d_in  [n_utt][8][8][45][8]   = svk_c3d2_conv32's output with flags bit 3
+ *   svk_c3d2_conv41  d_in  [n_utt][8][8][45][8]   = svk_c3d2_conv32t's output
  *                    d_wfrag [8 nt][8 chunks][3 kw][4 k][64][2]: lane (co = 16 nt + (l & 15), kk = l >> 4), e:
  *                            G_k[co][8 chunk + 2 kk + e][kw], G0 = g0, G1 = (g0 + g1 + g2) / 2, G2 = (g0 - g1 + g2) / 2,
  *                            G3 = g2 over the three depth taps g of the BN-folded weights;  d_bias / d_slope [128]
@@ -324,8 +291,8 @@ int svk_c3d2_conv32(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float*
  *                    added in a fixed order: bitwise repeatable);  d_out [n_utt][128]                                  */
 int svk_c3d2_conv41(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);
-/* conv3_2 in the shape of the last block (the default since round 3; svk_c3d2_conv32 above is the round-2 kernel, kept for A/B):
- *   d_in    [n_utt][10][8][5][15][8] = svk_c3d2_conv31's output with flags bit 3
+/* conv3_2 (64 -> 64, kernel (3,7,1)) -> BN -> PReLU, model.py:129-131 + :162-164, in the shape of the last block:
+ *   d_in    [n_utt][10][8][5][15][8] = svk_c3d2_conv31's output
  *   d_wfrag [4 nt][8 chunks][7 kh][4 k][64][2] (host-transformed G, as for svk_c3d2_conv41);  d_bias / d_slope [64]
  *   d_out   [n_utt][8][8][45][8]     = what svk_c3d2_conv41 takes                                                       */
 int svk_c3d2_conv32t(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
@@ -336,11 +303,6 @@ size_t svk_c3d2_fc5_workspace_floats(int32_t n_utt);
 int svk_c3d2_fc5(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias, float* d_work,
                  float* d_out);
 
-/* What follows each of conv3_1 .. conv4_2 (model.py:159-167; those convolutions run on the host framework): + bias
- * (BatchNorm folded), PReLU -- one in-place pass over channels-last activations d_x [n_rows][n_channels]
- * (n_channels a multiple of 4): x <- prelu(x + bias[c], slope[c]).                                            */
-int svk_bias_prelu(svk_ctx* ctx, float* d_x, int64_t n_rows, int32_t n_channels, const float* d_bias,
-                   const float* d_slope);
 
 /* ---- multi-GPU: the one exchange step of the path ------------------------------------------------
  * Utterances shard over the GPUs of a node with no data-path exchange until scoring; then every rank needs

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsvk.so")
 
 SVK_OK = 0
-VERSION = 105                      # include/svk.h SVK_VERSION
+VERSION = 106                      # include/svk.h SVK_VERSION
 SVK_ERR_BAD_ARG, SVK_ERR_UNSUPPORTED, SVK_ERR_HIP, SVK_ERR_NO_DEVICE, SVK_ERR_OOM, SVK_ERR_RCCL = -1, -2, -3, -4, -5, -6
 OUT_MFE, OUT_LMFE, OUT_MFCC = 0, 1, 2
 PCM_I16, PCM_F32 = 0, 1
@@ -70,7 +70,6 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _vp]),
     "svk_cube_draw_crops": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _i32, _i32, C.c_uint64, _vp, _vp]),
     "svk_cube_gather": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
-    "svk_cube_gather_windows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "svk_cosine_scores": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "svk_roc_workspace_bytes": (C.c_size_t, [_i64]),
     "svk_roc_eer": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_size_t, C.POINTER(C.c_double)]),
@@ -79,13 +78,11 @@ SIGNATURES = {
     "svk_c3d2_stage1": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_stage2": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "svk_c3d2_conv31": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
-    "svk_c3d2_conv32": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_conv32t": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_conv41": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_conv42": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_fc5_workspace_floats": (C.c_size_t, [_i32]),
     "svk_c3d2_fc5": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
-    "svk_bias_prelu": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "svk_comm_unique_id": (C.c_int, [_vp, C.c_char_p]),
     "svk_comm_init": (C.c_int, [_vp, C.c_char_p, _i32, _i32]),
     "svk_allgather_f32": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -106,6 +103,12 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `make -C speaker_verification_amd/csrc`); there is no CPU fallback")
+        # torch first, when it is there: its wheel carries its own HIP runtime, and a process must not end up with two
+        # (libsvk.so loaded before torch would pull in /opt/rocm's copy; the second runtime then sees no device)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)            # AttributeError if the .so is stale
@@ -125,3 +128,25 @@ def check(rc, ctx=None):
             raw = load().svk_last_error(ctx)
             msg = raw.decode("utf-8", "replace") if raw else ""
         raise SvkError(rc, msg)
+
+
+def provenance():
+    """What a measurement was made with: {"csrc_sha": sha256 over the kernel sources (csrc/*.hip, csrc/*.h, csrc/Makefile,
+    include/svk.h: file names + bytes, sorted), "libsvk_sha": sha256 of the built library}, 16 hex digits each.  Profiles
+    under profiles/ carry it (tools/summarize_prof.py) and bench.py marks a roofline row `stale` when the counters it uses
+    were collected from other kernel sources than the ones it runs."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")) or f == "Makefile")
+    files.append(os.path.join(os.path.dirname(here), "include", "svk.h"))
+    h = hashlib.sha256()
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    out = {"csrc_sha": h.hexdigest()[:16], "libsvk_sha": None}
+    if os.path.exists(LIB_PATH):
+        with open(LIB_PATH, "rb") as fh:
+            out["libsvk_sha"] = hashlib.sha256(fh.read()).hexdigest()[:16]
+    return out

@@ -840,67 +840,6 @@ __global__ __launch_bounds__(256) void cube_gather_kernel(const float* __restric
   }
 }
 
-// ---- feature cube, already unfolded for the network's first layer ---------------------------------
-// The first C3D2 layer (1 -> 16 channels, kernel (kd, 1, kw)) runs as one GEMM over a patch matrix
-// whose row (u, d, h, wg) holds, for kd consecutive crops, the `win` = kw + G - 1 coefficients that
-// the G adjacent output columns of group wg share (model.py: FusedEmbedder).  Building that matrix
-// from the cube is a strided copy of 0.26 GB -> 0.81 GB per 978 clips on the PyTorch side; here
-// it is written straight from the feature rows: every row is kd runs of `win` contiguous floats,
-//     out[m][kdi * win + j] = feat[u][crop[u][d + kdi] + h][wg * G + j].
-// One workgroup per (clip, output depth d); pure 16-byte copies.
-__global__ __launch_bounds__(256) void cube_windows_kernel(const float* __restrict__ feat, int max_frames, int ncols,
-                                                           const int32_t* __restrict__ crop, int n_crops,
-                                                           int crop_frames, int kd, int win, int G, int n_wg, int od,
-                                                           float* __restrict__ out) {
-  const int u = blockIdx.x / od, d = blockIdx.x - u * od;
-  const int w4 = win >> 2, row4 = kd * w4;              // float4 per window / per matrix row
-  const int per_block = crop_frames * n_wg * row4;      // float4 this workgroup writes
-  f32x4* dst = reinterpret_cast<f32x4*>(out) + (int64_t)blockIdx.x * per_block;
-  for (int v = threadIdx.x; v < per_block; v += blockDim.x) {
-    const int m = v / row4, s = v - m * row4;           // row inside the block, float4 inside the row
-    const int h = m / n_wg, wg = m - h * n_wg;
-    const int kdi = s / w4, j4 = s - kdi * w4;
-    const int start = crop[(int64_t)u * n_crops + d + kdi];
-    f32x4 val = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (start >= 0 && start + h < max_frames)            // svk_cube_draw_crops marks too-short clips with -1
-      val = *reinterpret_cast<const f32x4*>(feat + ((int64_t)u * max_frames + start + h) * ncols + wg * G + 4 * j4);
-    dst[v] = val;
-  }
-}
-
-// The C3D2 geometry (kd = 3 crops x a 16-float window, 3 column groups: 12 float4 per matrix row) with
-// the index arithmetic on compile-time constants and four independent copies in flight per lane.
-__global__ __launch_bounds__(256) void cube_windows_c3d2_kernel(const float* __restrict__ feat, int max_frames,
-                                                                int ncols, const int32_t* __restrict__ crop,
-                                                                int n_crops, int crop_frames, int G, int od,
-                                                                float* __restrict__ out) {
-  constexpr int KD = 3, W4 = 4, NWG = 3, ROW4 = KD * W4;
-  const int u = blockIdx.x / od, d = blockIdx.x - u * od;
-  const int per_block = crop_frames * NWG * ROW4;
-  f32x4* dst = reinterpret_cast<f32x4*>(out) + (int64_t)blockIdx.x * per_block;
-  int start[KD];  // wave-uniform: scalar loads
-#pragma unroll
-  for (int k = 0; k < KD; ++k) start[k] = crop[(int64_t)u * n_crops + d + k];
-  const float* base = feat + (int64_t)u * max_frames * ncols;
-  for (int v0 = threadIdx.x; v0 < per_block; v0 += 4 * 256) {
-    f32x4 val[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int v = v0 + 256 * q;
-      const int m = v / ROW4, s = v - m * ROW4;
-      const int h = m / NWG, wg = m - h * NWG;
-      const int kdi = s / W4, j4 = s - kdi * W4;
-      const int st = kdi == 0 ? start[0] : (kdi == 1 ? start[1] : start[2]);
-      val[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (v < per_block && st >= 0 && st + h < max_frames)
-        val[q] = *reinterpret_cast<const f32x4*>(base + (int64_t)(st + h) * ncols + wg * G + 4 * j4);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (v0 + 256 * q < per_block) dst[v0 + 256 * q] = val[q];
-  }
-}
-
 // ---- crop starts drawn on device ---------------------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -1208,32 +1147,6 @@ int svk_cube_gather(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
   const unsigned grid = (unsigned)std::min<int64_t>(jobs, (int64_t)ctx->num_cu * 16);
   hipLaunchKernelGGL(cube_gather_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols,
                      d_crop_idx, n_crops, crop_frames, jobs, d_out);
-  SVK_LAUNCH_CHECK(ctx);
-  return SVK_OK;
-}
-
-int svk_cube_gather_windows(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
-                            const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, int32_t kd, int32_t kw,
-                            int32_t group, float* d_out) {
-  if (!ctx) return SVK_ERR_BAD_ARG;
-  SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 1 && n_cols >= 1 && n_crops >= 1 && crop_frames >= 1, "shape");
-  if (n_utt == 0) return SVK_OK;
-  SVK_REQUIRE(ctx, d_feat && d_crop_idx && d_out, "NULL buffer");
-  SVK_REQUIRE(ctx, kd >= 1 && kd <= n_crops && kw >= 1 && kw <= n_cols && group >= 1, "kernel / group geometry");
-  const int ow = n_cols - kw + 1, win = kw + group - 1, od = n_crops - kd + 1;
-  SVK_REQUIRE(ctx, ow % group == 0, "group must divide the output width n_cols - kw + 1");
-  if ((group & 3) || (win & 3) || (n_cols & 3) || (reinterpret_cast<uintptr_t>(d_feat) & 15) ||
-      (reinterpret_cast<uintptr_t>(d_out) & 15))
-    return svk_fail(ctx, SVK_ERR_UNSUPPORTED,
-                    "svk_cube_gather_windows copies 16-byte pieces: group, kw + group - 1 and n_cols must be "
-                    "multiples of 4 and the buffers 16-byte aligned (group %d, window %d, n_cols %d)", group, win, n_cols);
-  SVK_REQUIRE(ctx, (int64_t)n_utt * od < ((int64_t)1 << 31), "too many (clip, depth) blocks for one launch");
-  if (kd == 3 && win == 16 && ow / group == 3)
-    hipLaunchKernelGGL(cube_windows_c3d2_kernel, dim3((unsigned)(n_utt * od)), dim3(256), 0, ctx->stream, d_feat,
-                       max_frames, n_cols, d_crop_idx, n_crops, crop_frames, group, od, d_out);
-  else
-    hipLaunchKernelGGL(cube_windows_kernel, dim3((unsigned)(n_utt * od)), dim3(256), 0, ctx->stream, d_feat, max_frames,
-                       n_cols, d_crop_idx, n_crops, crop_frames, kd, win, group, ow / group, od, d_out);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }

@@ -336,10 +336,11 @@ class Engine:
         return power
 
     def vad_energy(self, pcm, threshold, fs=16000, frame_ms=30, padding_ms=300, lengths=None, compact=True,
-                   want_segments=False, frame_samples=None, ring_len=None, offsets=None, voiced_out=None):
+                   want_segments=False, frame_samples=None, ring_len=None, offsets=None, voiced_out=None, longest=None):
         """pcm [n_utt, L] int16 (or, with `offsets` + `lengths`, a 1-D concatenation of ragged clips) ->
         dict(keep [n, F] u8, n_vad_frames [n] i32, voiced (same layout as pcm; a clip's samples past its
-        voiced_len are unspecified) i16, voiced_len [n] i32, seg [n, F] i32)."""
+        voiced_len are unspecified) i16, voiced_len [n] i32, seg [n, F] i32).  `longest`: the longest clip in samples when
+        the caller knows it (device-side lengths would otherwise cost a host round trip to size the outputs)."""
         torch = _torch()
         x = self.to_device(pcm)
         if x.dtype != torch.int16:
@@ -353,7 +354,9 @@ class Engine:
                 raise ValueError("offsets need lengths")
             offs = self.to_device(offsets, torch.int64)
             n_utt, stride = offs.numel(), 0
-            if not n_utt:
+            if longest is not None:
+                longest = int(longest)
+            elif not n_utt:
                 longest = 0
             elif isinstance(lengths, np.ndarray):          # host lengths: no device round trip
                 longest = int(lengths.max())
@@ -413,98 +416,61 @@ class Engine:
                                        self._ptr(out)), self.ctx)
         return out
 
-    def cube_windows(self, feat, crop_idx, crop_frames, kd, kw, group):
-        """svk_cube_gather_windows: the feature cube already unfolded into the patch matrix of the network's
-        first layer (see FusedEmbedder): [n * od * crop_frames * (ow / group), kd * (kw + group - 1)]."""
-        torch = _torch()
-        feat = self.to_device(feat, torch.float32)
-        idx = self.to_device(crop_idx, torch.int32)
-        n, T, Cc = feat.shape
-        n_crops = idx.shape[1]
-        od, ow, win = n_crops - kd + 1, Cc - kw + 1, kw + group - 1
-        out = torch.empty((n * od * crop_frames * (ow // group), kd * win), dtype=torch.float32, device=self.device)
-        self._stream()
-        check(self.lib.svk_cube_gather_windows(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), n_crops,
-                                               crop_frames, kd, kw, group, self._ptr(out)), self.ctx)
-        return out
-
-    def c3d2_stage1(self, feat, crop_idx, tables, folded=True, crop_frames=80, depth_transform=False, t_planes=False,
-                    merged_tiles=False):
-        """svk_c3d2_stage1: feature rows + crop starts -> the activation after C3D2's first block (conv1_1,
-        conv1_2, pool1 with their BN + PReLU): [n, 16, 18, 18, 2, 16] (row-folded) or [n, 16, 36, 18, 16] f32.
-        `depth_transform`: conv1_2 through Winograd's F(2, 3) along depth (2 / 3 of the multiply-adds; the same sums
-        in another association, ~1e-6 relative from the direct form).  `t_planes` (implies the depth transform): the
-        round-3 kernel that applies the input transform once, where conv1_1's output is produced (c3d2_stage1t_kernel).
-        `merged_tiles` (with depth_transform): the 4-row remainders of two depth pairs share one M tile (- 10 % MFMAs)."""
+    def c3d2_stage1(self, feat, crop_idx, tables, crop_frames=80):
+        """svk_c3d2_stage1: feature rows + crop starts -> the activation after C3D2's first block (conv1_1, conv1_2,
+        pool1 with their BN + PReLU): [n, 16, 36, 18, 16] f32, channels last.  conv1_2 runs through Winograd's F(2, 3)
+        along depth (2 / 3 of the multiply-adds; the same sums in another association, ~1e-6 relative from the direct form)."""
         torch = _torch()
         feat = self.to_device(feat, torch.float32)
         idx = self.to_device(crop_idx, torch.int32)
         n, T, Cc = feat.shape
         w1frag, bias1, slope1, w2frag, bias2, slope2 = tables[:6]
         slope01 = bool(tables[6]) if len(tables) > 6 else False          # every slope in [0, 1]: the two-instruction PReLU
-        out = torch.empty((n, 16, 18, 18, 2, 16) if folded else (n, 16, 36, 18, 16), dtype=torch.float32,
-                          device=self.device)
+        out = torch.empty((n, 16, 36, 18, 16), dtype=torch.float32, device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_stage1(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), idx.shape[1], crop_frames,
                                        self._ptr(w1frag), self._ptr(bias1), self._ptr(slope1), self._ptr(w2frag), self._ptr(bias2),
-                                       self._ptr(slope2), int(bool(folded)) | (2 if slope01 else 0) |
-                                       (8 if t_planes else (4 | (16 if merged_tiles else 0)) if depth_transform else 0),
-                                       self._ptr(out)),
-              self.ctx)
+                                       self._ptr(slope2), 2 if slope01 else 0, self._ptr(out)), self.ctx)
         return out
 
-    def c3d2_stage2(self, act1, tables, depth_transform=False):
-        """svk_c3d2_stage2: [n, 16, 36, 18, 16] (svk_c3d2_stage1, folded = 0) -> conv2_1 -> conv2_2 -> pool2 with
-        their BN + PReLU -> [n, 12, 15, 7, 32] f32 (channels last).  `depth_transform`: both convolutions through
-        Winograd's F(2, 3) along depth (True), or the flag bits of include/svk.h: 1 = conv2_1 only, 4 = conv2_2 only."""
+    def c3d2_stage2(self, act1, tables):
+        """svk_c3d2_stage2: [n, 16, 36, 18, 16] (svk_c3d2_stage1's output) -> conv2_1 -> conv2_2 -> pool2 with their
+        BN + PReLU -> [n, 12, 15, 7, 32] f32 (channels last), both convolutions depth-transformed."""
         torch = _torch()
         n = act1.shape[0]
+        if tuple(act1.shape[1:]) != (16, 36, 18, 16) or not act1.is_contiguous():
+            raise ValueError("c3d2_stage2 wants the activation [n, 16, 36, 18, 16]")
         w21, b21, s21, w22, b22, s22 = tables[:6]
-        slope01 = bool(tables[6]) if len(tables) > 6 else False          # every slope in [0, 1]: the two-instruction PReLU
+        slope01 = bool(tables[6]) if len(tables) > 6 else False
         act2 = torch.empty((n, 14, 36, 15, 32), dtype=torch.float32, device=self.device)
         out = torch.empty((n, 12, 15, 7, 32), dtype=torch.float32, device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_stage2(self.ctx, self._ptr(act1), n, self._ptr(w21), self._ptr(b21), self._ptr(s21),
-                                       self._ptr(w22), self._ptr(b22), self._ptr(s22),
-                                       (depth_transform if isinstance(depth_transform, int) and not isinstance(depth_transform, bool)
-                                        else 5 if depth_transform else 0) | (2 if slope01 else 0),
+                                       self._ptr(w22), self._ptr(b22), self._ptr(s22), 2 if slope01 else 0,
                                        self._ptr(act2), self._ptr(out)), self.ctx)
         return out
 
-    def c3d2_conv31(self, act, tables, chunked=False):
-        """svk_c3d2_conv31: [n, 12, 15, 7, 32] (svk_c3d2_stage2's output) -> conv3_1 + BN + PReLU -> [n, 10, 15, 5, 64]
-        f32, channels last (Winograd F(2, 3) along depth); with `chunked` [n, 10 d, 8 chunks, 5 w, 15 h, 8]: what
-        svk_c3d2_conv32t stages from."""
+    def c3d2_conv31(self, act, tables):
+        """svk_c3d2_conv31: [n, 12, 15, 7, 32] (svk_c3d2_stage2's output) -> conv3_1 + BN + PReLU -> chunked, column-major
+        [n, 10 d, 8 chunks, 5 w, 15 h, 8] f32: what svk_c3d2_conv32t stages from."""
         torch = _torch()
         n = act.shape[0]
+        if tuple(act.shape[1:]) != (12, 15, 7, 32) or not act.is_contiguous():
+            raise ValueError("c3d2_conv31 wants the activation [n, 12, 15, 7, 32]")
         wfrag, bias, slope = tables[:3]
         slope01 = bool(tables[3]) if len(tables) > 3 else False
-        out = torch.empty((n, 10, 8, 5, 15, 8) if chunked else (n, 10, 15, 5, 64), dtype=torch.float32, device=self.device)
+        out = torch.empty((n, 10, 8, 5, 15, 8), dtype=torch.float32, device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_conv31(self.ctx, self._ptr(act), n, self._ptr(wfrag), self._ptr(bias), self._ptr(slope),
-                                       (2 if slope01 else 0) | (8 if chunked else 0), self._ptr(out)), self.ctx)
+                                       2 if slope01 else 0, self._ptr(out)), self.ctx)
         return out
 
     def c3d2_conv32t(self, act, tables):
-        """svk_c3d2_conv32t: chunked, column-major [n, 10, 8, 5, 15, 8] (svk_c3d2_conv31 with chunked=True) -> conv3_2 + BN
-        + PReLU -> chunked [n, 8 d, 8 chunks, 45 = 9 h x 5 w, 8] (the shape of the last block: M tile = one position of 16 cubes)."""
+        """svk_c3d2_conv32t: chunked, column-major [n, 10, 8, 5, 15, 8] (svk_c3d2_conv31's output) -> conv3_2 + BN + PReLU ->
+        chunked [n, 8 d, 8 chunks, 45 = 9 h x 5 w, 8] (the shape of the last block: M tile = one position of 16 cubes)."""
         if tuple(act.shape[1:]) != (10, 8, 5, 15, 8) or not act.is_contiguous():
             raise ValueError("c3d2_conv32t wants the chunked activation [n, 10, 8, 5, 15, 8]")
         return self._c3d2_tail_conv(self.lib.svk_c3d2_conv32t, act, tables, (8, 8, 45, 8))
-
-    def c3d2_conv32(self, act, tables, chunked=False):
-        """svk_c3d2_conv32: [n, 10, 15, 5, 64] (svk_c3d2_conv31's output) -> conv3_2 + BN + PReLU -> [n, 8, 9, 5, 64]
-        f32, channels last (Winograd F(2, 3) along depth, partial sums over four K chunks added through LDS); with
-        `chunked` the output is [n, 8 d, 8 chunks, 45 pixels, 8]: what svk_c3d2_conv41 stages from."""
-        torch = _torch()
-        n = act.shape[0]
-        wfrag, bias, slope = tables[:3]
-        slope01 = bool(tables[3]) if len(tables) > 3 else False
-        out = torch.empty((n, 8, 8, 45, 8) if chunked else (n, 8, 9, 5, 64), dtype=torch.float32, device=self.device)
-        self._stream()
-        check(self.lib.svk_c3d2_conv32(self.ctx, self._ptr(act), n, self._ptr(wfrag), self._ptr(bias), self._ptr(slope),
-                                       (2 if slope01 else 0) | (8 if chunked else 0), self._ptr(out)), self.ctx)
-        return out
 
     def _c3d2_tail_conv(self, fn, act, tables, out_shape):
         torch = _torch()
@@ -518,7 +484,7 @@ class Engine:
         return out
 
     def c3d2_conv41(self, act, tables):
-        """svk_c3d2_conv41: chunked [n, 8 d, 8 chunks, 45, 8] (svk_c3d2_conv32 with chunked=True) -> conv4_1 + BN + PReLU
+        """svk_c3d2_conv41: chunked [n, 8 d, 8 chunks, 45, 8] (svk_c3d2_conv32t's output) -> conv4_1 + BN + PReLU
         -> chunked [n, 6 d, 16 chunks, 27 = 9 h x 3 w, 8] (a GEMM over the batch: M tile = one position of 16 cubes)."""
         if tuple(act.shape[1:]) != (8, 8, 45, 8) or not act.is_contiguous():
             raise ValueError("c3d2_conv41 wants the chunked activation [n, 8, 8, 45, 8]")
@@ -543,19 +509,6 @@ class Engine:
         check(self.lib.svk_c3d2_fc5(self.ctx, self._ptr(act), n, self._ptr(wfrag), self._ptr(bias), self._ptr(work),
                                     self._ptr(out)), self.ctx)
         return out
-
-    def bias_prelu_(self, x, bias, slope):
-        """svk_bias_prelu, in place on a channels-last activation: x (n, C, D, H, W) with channels_last_3d memory (or
-        any [rows, C] contiguous tensor): x <- prelu(x + bias[c], slope[c])."""
-        torch = _torch()
-        channels = x.shape[1] if x.dim() == 5 else x.shape[-1]
-        ok = x.is_contiguous(memory_format=torch.channels_last_3d) if x.dim() == 5 else x.is_contiguous()
-        if not ok or x.dtype != torch.float32:
-            raise ValueError("bias_prelu_ wants a float32 tensor with channels-last memory")
-        self._stream()
-        check(self.lib.svk_bias_prelu(self.ctx, self._ptr(x), x.numel() // channels, channels, self._ptr(bias),
-                                      self._ptr(slope)), self.ctx)
-        return x
 
     def cosine_scores(self, test, enroll):
         torch = _torch()

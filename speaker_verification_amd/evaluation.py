@@ -4,10 +4,11 @@
 
 The reference scores one (utterance, speaker) pair per sklearn call inside a
 Python double loop (evaluation.py:67-84, 112-134); here the whole score matrix
-is one MFMA kernel launch (`svk_cosine_scores`).  ROC / EER / AUC stay on the
-host exactly as the reference computes them (sklearn + scipy, evaluation.py:
-47-52): one sort of n_test * n_speakers scores, milliseconds at the VoxCeleb1
-verification shape (SURVEY.md 8(f) lists a GPU ROC as a later row).
+is one MFMA kernel launch (`svk_cosine_scores`), and the embeddings behind it
+come from the libsvk network kernels (`model.C3D2.forward` in eval mode on the
+device; `dataset_embeddings` for the file-driven entry points).  ROC / EER / AUC
+stay on the host exactly as the reference computes them (sklearn + scipy,
+evaluation.py:47-52); `get_eer_auc_device` is the device form (`svk_roc_eer`).
 """
 import os
 
@@ -100,6 +101,8 @@ class Evaluation:
         return self._enroll
 
     def embed(self, utterance):
+        """`self.model(utterance, development=False)` in eval mode on the device (evaluation.py:68-69): for a `model.C3D2`
+        that is the seven libsvk network kernels (the cube read as feature rows, model.C3D2.forward)."""
         eng = get_engine()
         self.model.eval()
         self.model.to(eng.device)
@@ -133,12 +136,44 @@ def labels_from_ids(test_ids, speaker_ids):
     return labels
 
 
+def _read_batch(dataset, lo, hi):
+    """Files [lo, hi) of an `AudioDataset` as ONE arena + 16-byte-aligned clip offsets + lengths.  16 kHz mono 16-bit files
+    (what the reference's tree holds, vad.py:10-22) are read straight into an int16 arena -- no float copy on the host, the
+    `/ 32768` of `librosa.load` (utils.py:170-173) is folded into the front end's filterbank weights; a batch with any other
+    rate / channel count falls back to `load_signal`'s float32 (resampled on the device)."""
+    import wave
+    from . import constants as c
+    paths = [os.path.join(dataset.audio_dir, dataset.sound_files[i]) for i in range(lo, hi)]
+    heads = []
+    for path in paths:
+        with wave.open(path, "rb") as wf:
+            heads.append((wf.getnchannels(), wf.getsampwidth(), wf.getframerate(), wf.getnframes()))
+    plain = all(h[:3] == (1, 2, c.SAMPLE_RATE) for h in heads)
+    if plain:
+        lens = np.array([h[3] for h in heads], dtype=np.int32)
+        align = 8
+    else:
+        sigs = [np.asarray(dataset.load_signal(i), dtype=np.float32) for i in range(lo, hi)]
+        lens = np.array([x.size for x in sigs], dtype=np.int32)
+        align = 4
+    slots = (lens.astype(np.int64) + align - 1) // align * align
+    offs = np.concatenate([[0], np.cumsum(slots)[:-1]]).astype(np.int64)
+    buf = np.zeros(int(slots.sum()), dtype=np.int16 if plain else np.float32)
+    for k, path in enumerate(paths):
+        if plain:
+            with wave.open(path, "rb") as wf:
+                buf[offs[k]:offs[k] + lens[k]] = np.frombuffer(wf.readframes(int(lens[k])), dtype=np.int16)
+        else:
+            buf[offs[k]:offs[k] + lens[k]] = sigs[k]
+    return buf, offs, lens, plain
+
+
 def dataset_embeddings(dataset, model, batch=256):
     """Embeddings [len(dataset), 128] (device) of every file of a `load_data.AudioDataset`, in order:
     the per-item chain of the reference (load_data.py:50-87 `load_wav` -> `lmfe`; utils.py:382-397 CMVN;
     utils.py:351-379 FeatureCube with crop starts from the GLOBAL NumPy RNG, drawn in file order;
-    `model(cube, development=False)`) run `batch` files at a time: one ragged front-end launch, one
-    CMVN, one cube gather, one network call per batch."""
+    `model(cube, development=False)`) run `batch` files at a time: one ragged front-end launch, one CMVN and the seven
+    libsvk network kernels per batch -- the cube is never built (`svk_c3d2_stage1` reads feature rows + crop starts)."""
     from . import _lib
     from . import constants as c
     from .engine import spec_from_seconds
@@ -147,33 +182,26 @@ def dataset_embeddings(dataset, model, batch=256):
     n = len(dataset)
     out = torch.empty((n, 128), dtype=torch.float32, device=eng.device)
     if c.DERIVATIVE:
-        # three-channel cubes (utils.py:385-391): the per-item transform chain, network call batched
+        # three-channel cubes (utils.py:385-391): the per-item transform chain, the torch module's forward batched
         for lo in range(0, n, batch):
             cubes = np.stack([np.asarray(dataset[i][0], dtype=np.float32) for i in range(lo, min(n, lo + batch))])
             with torch.no_grad():
                 out[lo:lo + len(cubes)] = model(eng.to_device(cubes), development=False)
         return out
-    spec = spec_from_seconds(c.SAMPLE_RATE, c.FRAME_LEN, c.FRAME_STEP, c.NUM_FFT, c.NUM_COEF, c.NUM_COEF,
-                             _lib.OUT_LMFE)
-    embed = model.fused_inference(channels_last=True) if hasattr(model, "fused_inference") else None
+    specs = {plain: spec_from_seconds(c.SAMPLE_RATE, c.FRAME_LEN, c.FRAME_STEP, c.NUM_FFT, c.NUM_COEF, c.NUM_COEF, _lib.OUT_LMFE,
+                                      input_scale=1.0 / 32768.0 if plain else 1.0) for plain in (True, False)}
+    embed = model.fused_inference()
     for lo in range(0, n, batch):
         hi = min(n, lo + batch)
-        sigs = [np.asarray(dataset.load_signal(i), dtype=np.float32) for i in range(lo, hi)]
-        lens = np.array([s.size for s in sigs], dtype=np.int32)
-        offs = np.zeros(len(sigs), dtype=np.int64)
-        offs[1:] = np.cumsum((lens[:-1] + 3) // 4 * 4)               # 16-byte aligned clip starts
-        buf = np.zeros(int(offs[-1] + (lens[-1] + 3) // 4 * 4), dtype=np.float32)
-        for o, s in zip(offs, sigs):
-            buf[o:o + s.size] = s
+        buf, offs, lens, plain = _read_batch(dataset, lo, hi)
+        spec = specs[plain]
         frames = [spec.num_frames(int(v)) for v in lens]
         feat, n_frames, _ = eng.features(buf, spec, lengths=lens, offsets=offs, max_frames=max(frames))
         if c.NORMALIZE:
             eng.cmvn_(feat, n_frames, variance=True)
         # utils.py:372, one draw per file in file order (numpy raises for clips of <= 80 frames, as there)
         idx = np.stack([np.random.randint(T - c.CUBE_FRAMES, size=c.CUBE_CROPS) for T in frames]).astype(np.int32)
-        cube = eng.cube_gather(feat, idx, c.CUBE_FRAMES)
-        with torch.no_grad():
-            out[lo:hi] = embed(cube) if embed is not None else model(cube, development=False)
+        out[lo:hi] = embed.embed_features(feat, idx)
     return out
 
 

@@ -1,21 +1,22 @@
-"""C3D2 speaker-embedding network: the PyTorch module (what checkpoints load into, what training uses, the
-parity oracle of the libsvk kernels) and `FusedEmbedder`, the inference path: since round 3 every layer runs in
-libsvk (`svk_c3d2_stage1`, `svk_c3d2_stage2`, `svk_c3d2_conv31/32`: csrc/c3d2.hip; `svk_c3d2_conv41/42`, `svk_c3d2_fc5`:
-csrc/c3d2_tail.hip); the same layers on PyTorch-ROCm (MIOpen / hipBLASLt, `svk_bias_prelu` behind each convolution)
-remain as the A/B path behind the SVK_C3D2_* switches and for models whose layers are not C3D2's.
+"""C3D2 speaker-embedding network (`/root/reference/model.py:104-191`): the PyTorch module -- what checkpoints load
+into and what training differentiates -- and `FusedEmbedder`, its inference form: seven hand-written f32-MFMA kernels of
+libsvk (`svk_c3d2_stage1`, `svk_c3d2_stage2`, `svk_c3d2_conv31`, `svk_c3d2_conv32t`: csrc/c3d2.hip, csrc/c3d2_tail.hip;
+`svk_c3d2_conv41`, `svk_c3d2_conv42`, `svk_c3d2_fc5`: csrc/c3d2_tail.hip).
 
-Mirrors `/root/reference/model.py:104-191`: same constructor arguments, same
-sub-module names (so a reference-format checkpoint's `state_dict` loads
-unchanged), same `forward(x, development=True)`, `load_checkpoint(d)` and
-`create_Speaker_Model(u)`.  Input convention `(batch, 1, 20, 80, 40)`
-(`/root/reference/utils.py:368-379`).
+Same constructor arguments, same sub-module names (a reference-format checkpoint's `state_dict` loads unchanged), same
+`forward(x, development=True)`, `load_checkpoint(d)` and `create_Speaker_Model(u)` as the reference.  Input convention
+`(batch, 1, 20, 80, 40)` (`/root/reference/utils.py:368-379`).
 
-What is different, on purpose, for MI355X inference:
-  * the network is described by one table and built in a loop;
-  * `fused_inference()` folds eval-mode BatchNorm into the convolution weights
-    and returns a lean callable for large-batch embedding extraction;
-  * nothing here hard-codes `.cuda()` or prints (cf. Q20).
+Which code runs a forward:
+  * eval mode, input on the GPU, one-channel 20 x 80 x 40 cubes, no gradient asked of the input -- what
+    `evaluation.py:67-84,113-121` and `model.py:188-191,374-388` do -- : the libsvk kernels.  A cube IS a feature
+    matrix of 1 600 rows with crop starts 0, 80, 160 ...: `svk_c3d2_stage1` reads it as such, nothing is copied;
+  * training mode, gradients, three-channel cubes (`utils.FeatureCube3C`), tensors on the host: the torch layers
+    (autograd needs them; the north-star leaves the training forward on PyTorch-ROCm).
+`model.inference_kernels = False` keeps an instance on the torch layers (A/B comparisons in tools).
 """
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -33,9 +34,13 @@ _LAYERS = (
 )
 EMBED_DIM = 128
 _FLAT = 4 * 3 * 3 * 128
+CUBE_SHAPE = (1, 20, 80, 40)          # channel, crops, frames, coefficients (utils.py:20-21, 368-379)
+_EMBEDDERS = weakref.WeakKeyDictionary()   # model -> (state key, FusedEmbedder): kept off the module (deepcopy / pickling stay plain)
 
 
 class C3D2(nn.Module):
+    inference_kernels = True          # False on an instance: forward stays on the torch layers whatever the mode
+
     def __init__(self, n_labels, num_channels):
         super().__init__()
         self.n_labels, self.num_channels = n_labels, num_channels
@@ -52,14 +57,28 @@ class C3D2(nn.Module):
         self.PReLu5 = nn.PReLU()
         self.FC6 = nn.Linear(EMBED_DIM, n_labels)
 
-    def forward(self, x, development=True):
+    def torch_layers(self, x):
+        """conv -> BatchNorm -> PReLU (-> pool) x 8 -> FC5 on torch operators (model.py:141-169): training, autograd,
+        host tensors, three-channel cubes."""
         for tag, _, _, _, _, pool in _LAYERS:
             x = getattr(self, "conv" + tag)(x)
             x = getattr(self, "batch_norm" + tag)(x)
             x = getattr(self, "PReLu" + tag)(x)
             if pool:
                 x = getattr(self, "pool" + tag[0])(x)
-        x = self.FC5(x.view(-1, _FLAT))
+        return self.FC5(x.view(-1, _FLAT))
+
+    def runs_on_kernels(self, x):
+        """True when forward(x) is an inference call the libsvk network covers (see the module docstring)."""
+        return bool(self.inference_kernels and not self.training and isinstance(x, torch.Tensor) and x.is_cuda
+                    and x.dim() == 5 and tuple(x.shape[1:]) == CUBE_SHAPE and x.dtype == torch.float32
+                    and self.num_channels == 1 and not (torch.is_grad_enabled() and x.requires_grad))
+
+    def forward(self, x, development=True):
+        if self.runs_on_kernels(x):
+            x = self.fused_inference()(x)
+        else:
+            x = self.torch_layers(x)
         if development:
             x = F.softmax(self.FC6(self.PReLu5(x)), dim=1)
         return x
@@ -84,151 +103,100 @@ class C3D2(nn.Module):
         return self.forward(utterance, development=False)
 
     # ---- MI355X inference path -------------------------------------------
-    def fused_inference(self, channels_last=False):
-        """Embedding-only callable with BatchNorm folded into the convolutions
-        (eval-mode statistics).  Same maths as forward(development=False)."""
-        return FusedEmbedder(self, channels_last=channels_last)
+    def _state_key(self):
+        """Identity and version of every tensor the embedding depends on: in-place updates (an optimiser step,
+        load_state_dict) bump `_version`, `.to(device)` changes the storage."""
+        return tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items()
+                     if not k.startswith(("FC6", "PReLu5")))
+
+    def fused_inference(self):
+        """The embedding-only inference form of the CURRENT weights (eval-mode BatchNorm folded into the convolutions,
+        operands in the kernels' lane order): same maths as forward(development=False).  Cached until a weight changes."""
+        key = self._state_key()
+        hit = _EMBEDDERS.get(self)
+        if hit is None or hit[0] != key:
+            hit = _EMBEDDERS[self] = (key, FusedEmbedder(self))
+        return hit[1]
 
 
 class FusedEmbedder:
-    """conv(+folded BN) -> PReLU chain; weights snapshot the model at build time."""
+    """C3D2's forward(development=False) as seven libsvk kernels; the weights are a snapshot of the model at build time.
+    Built for C3D2's layer shapes on one-channel cubes only: anything else raises (no framework fallback here -- the torch
+    module itself is the path for other shapes)."""
 
-    def __init__(self, model, channels_last=False):
-        self.channels_last = channels_last
+    def __init__(self, model):
+        self.device = model.conv1_1.weight.device       # tables are built where the weights live; kernels need the GPU
+        self._eng = None
         self.stages = []
-        fmt = torch.channels_last_3d if channels_last else torch.contiguous_format
         with torch.no_grad():
             for tag, _, _, _, stride, pool in _LAYERS:
                 conv = getattr(model, "conv" + tag)
                 bn = getattr(model, "batch_norm" + tag)
                 act = getattr(model, "PReLu" + tag)
                 scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-                w = (conv.weight * scale.view(-1, 1, 1, 1, 1)).contiguous(memory_format=fmt)
+                w = (conv.weight * scale.view(-1, 1, 1, 1, 1)).contiguous()
                 b = ((conv.bias - bn.running_mean) * scale + bn.bias).contiguous()
-                # max-pool commutes with PReLU when the slope is >= 0 (PReLU is then non-decreasing):
-                # pooling FIRST halves what the activation reads and writes (bit-identical result)
-                pool_first = bool(pool and float(act.weight.detach().min()) >= 0.0)
-                self.stages.append((w, b, act.weight.detach().clone(), stride, pool, pool_first))
+                self.stages.append((w, b, act.weight.detach().clone(), tuple(conv.stride), pool, False))
             self.fc_w = model.FC5.weight.detach().clone()
             self.fc_b = model.FC5.bias.detach().clone()
-            self.fc_w_cl = None
-            # engine for svk_bias_prelu after conv3_1 .. conv4_2 (GPU + channels-last only; SVK_C3D2_TAIL=0 disables)
-            self.fused_tail = None
-            self.conv31_kernel = False       # conv3_1 in libsvk behind svk_c3d2_stage2 (SVK_C3D2_CONV31=0 disables)
-            self.conv32_kernel = False       # ... and conv3_2 behind it (SVK_C3D2_CONV32=0 disables)
-            self.conv4_kernels = False       # ... and conv4_1, conv4_2, FC5 (SVK_C3D2_CONV4=0 hands them back to PyTorch-ROCm)
-            self.conv32t_kernel = False      # conv3_2 in the last block's shape (SVK_C3D2_CONV32T=0: the round-2 kernel)
-            if channels_last and self.fc_w.is_cuda:
-                import os
-                if os.environ.get("SVK_C3D2_TAIL", "1") != "0":
-                    from .engine import get_engine
-                    self.fused_tail = get_engine(self.fc_w.device.index)
-                    self.conv31_kernel = os.environ.get("SVK_C3D2_CONV31", "1") != "0"
-                    self.conv32_kernel = self.conv31_kernel and os.environ.get("SVK_C3D2_CONV32", "1") != "0"
-                    self.conv4_kernels = self.conv32_kernel and os.environ.get("SVK_C3D2_CONV4", "1") != "0"
-                    self.conv32t_kernel = self.conv4_kernels and os.environ.get("SVK_C3D2_CONV32T", "1") != "0"
-            # First layer as patch-matrix x weight GEMM.  MIOpen has no direct kernel for a 1-channel
-            # Conv3d and falls back to im2col + per-group GEMM + layout transposes (6.5 ms per 978
-            # cubes).  Here ONE strided copy gathers, for every group of G adjacent output columns, the
-            # kd x (kw + G - 1) input window they share, and addmm multiplies it by a Toeplitz-expanded
-            # weight matrix [kd (kw + G - 1), G * out_channels]: 3x the FLOPs of the plain patch matrix
-            # but 1/4 of its bytes and a GEMM shape the library handles well (1.5 ms at G = 12); its
-            # row-major result is already in channels-last (NDHWC) order.
-            w0 = self.stages[0][0]
-            self.first_as_gemm = bool(channels_last and w0.shape[1] == 1 and w0.shape[3] == 1 and
-                                      self.stages[0][3] == (1, 1, 1))
-            self._gemm_cache = {}
-            self.row_fold = self._row_fold_tables(fmt) if channels_last else None
+        tables = (self.stage1_tables(), self.stage2_tables(), self.conv31_tables(), self.conv32t_tables(),
+                  self.conv41_tables(), self.conv42_tables(), self.fc5_tables())
+        if any(t is None for t in tables):
+            raise ValueError("libsvk's network kernels are built for C3D2's layers on one-channel 20 x 80 x 40 cubes "
+                             "(model.py:110-139); this model's layers differ")
+        self._starts = {}
 
-    def _row_fold_tables(self, fmt):
-        """Stages 1-3 (conv1_2, conv2_1, conv2_2 of C3D2) with the PARITY OF THE ROW folded into the
-        channels -- a pure re-indexing (same products, another summation order):
-          * conv1_2 (kernel (kd, kh, 1), row stride 2) becomes a Toeplitz-widened conv that emits two
-            output rows per position as 2 x co channels: kernel (kd, kh + 2, 1), row stride 4.  It has
-            1.22x the multiply-adds but a GEMM N of 32 instead of 16: 5.3 -> 4.2 ms per 978 cubes;
-          * conv2_1 (kernel (kd, 1, kw)) never mixes rows: the folded tensor's memory (.., w, parity, c) is
-            read as 16 channels over the interleaved axis (w, parity) and the ORIGINAL weights run with a
-            dilation of 2 along it (a view, no copy; 1.09 ms against 1.22 ms as a 2-group conv);
-          * conv2_2 (kernel (kd, 8, 1), row stride 2) over rows 2 hp + parity is a stride-1 conv with
-            kernel (kd, 4, 1) over row PAIRS whose input channels are (parity, ci): it un-folds the
-            layout for free.
-        The max-pool / PReLU between them act per channel along W and are unaffected (slopes tiled).
-        Returns None when the layer shapes do not have this structure."""
-        try:
-            (w1, b1, s1, st1, _, _), (w2, b2, s2, st2, pool2, _), (w3, b3, s3, st3, _, _) = self.stages[1:4]
-        except ValueError:
-            return None
-        ok = (tuple(st1) == (1, 2, 1) and w1.shape[4] == 1 and tuple(st2) == (1, 1, 1) and w2.shape[3] == 1 and
-              not pool2 and
-              tuple(st3) == (1, 2, 1) and w3.shape[4] == 1 and w3.shape[3] % 2 == 0 and
-              w2.shape[1] == w1.shape[0] and w3.shape[1] == w2.shape[0])
-        if not ok:
-            return None
-        co1, ci1, kd1, kh1, _ = w1.shape
-        f1 = torch.zeros(2, co1, ci1, kd1, kh1 + 2, 1, dtype=w1.dtype, device=w1.device)
-        for parity in range(2):
-            f1[parity, :, :, :, 2 * parity:2 * parity + kh1, :] = w1
-        f1 = f1.reshape(2 * co1, ci1, kd1, kh1 + 2, 1).contiguous(memory_format=fmt)
-        f2 = w2.repeat(2, 1, 1, 1, 1).contiguous(memory_format=fmt)                  # groups = 2
-        co3, ci3, kd3, kh3, _ = w3.shape
-        # f3[co, parity * ci3 + ci, kd, khp] = w3[co, ci, kd, 2 khp + parity]
-        f3 = (w3.reshape(co3, ci3, kd3, kh3 // 2, 2, 1).permute(0, 4, 1, 2, 3, 5)
-              .reshape(co3, 2 * ci3, kd3, kh3 // 2, 1).contiguous(memory_format=fmt))
-        def tile(slope):                      # nn.PReLU() has ONE slope; a per-channel one follows its channels
-            return slope if slope.numel() == 1 else slope.repeat(2)
-        return {"kh1": kh1, 1: (f1, b1.repeat(2), tile(s1), (1, 4, 1), 1),
-                2: (f2, b2.repeat(2), tile(s2), (1, 1, 1), 2), 3: (f3, b3, s3, (1, 1, 1), 1)}
+    @property
+    def eng(self):
+        if self._eng is None:
+            if self.device.type != "cuda":
+                raise RuntimeError("FusedEmbedder runs on the GPU (libsvk); move the model to the device -- there is no CPU fallback")
+            from .engine import get_engine
+            self._eng = get_engine(self.device.index)
+        return self._eng
 
-    def _first_layer_tables(self, ow):
-        """(G, Toeplitz weight matrix, tiled bias) for an output width `ow`; G = largest divisor <= 12."""
-        hit = self._gemm_cache.get(ow)
+    def crop_starts(self, n, device):
+        """[n, 20] int32: 0, 80, 160 ... -- a cube read as 1 600 feature rows."""
+        hit = self._starts.get(n)
         if hit is None:
-            w, b = self.stages[0][0], self.stages[0][1]
-            co, kd, kw = w.shape[0], w.shape[2], w.shape[4]
-            G = max(g for g in range(1, 13) if ow % g == 0)
-            win = kw + G - 1
-            wt = torch.zeros(kd, win, G, co, dtype=w.dtype, device=w.device)
-            taps = w[:, 0, :, 0, :].permute(1, 2, 0)                      # (kd, kw, co)
-            for g in range(G):
-                wt[:, g:g + kw, g, :] = taps
-            hit = (G, wt.reshape(kd * win, G * co).contiguous(), b.repeat(G))
-            self._gemm_cache[ow] = hit
+            from . import constants as c
+            row = torch.arange(c.CUBE_CROPS, dtype=torch.int32, device=device) * c.CUBE_FRAMES
+            hit = self._starts[n] = row[None, :].expand(n, -1).contiguous()
+            if len(self._starts) > 8:
+                self._starts.pop(next(iter(self._starts)))
         return hit
 
-    def first_layer_windows(self, n_crops, n_cols):
-        """(kd, kw, G) of the patch matrix the first layer's GEMM consumes for cubes of `n_crops` x `n_cols`
-        (svk_cube_gather_windows can write it directly), or None when the first layer is a plain conv."""
-        if not self.first_as_gemm:
-            return None
-        w = self.stages[0][0]
-        kd, kw = int(w.shape[2]), int(w.shape[4])
-        G = self._first_layer_tables(n_cols - kw + 1)[0]
-        return kd, kw, G
+    @torch.no_grad()
+    def embed_features(self, feat, crop_idx, timed=None):
+        """feature rows [n, T, 40] + crop starts [n, 20] -> embeddings [n, 128].  The cube (utils.py:351-379) is never
+        materialised: the first-block kernel gathers its patches from the feature rows.  `timed(name, fn)`: the
+        pipeline's HIP-event hook around each kernel (bench.py)."""
+        run = timed or (lambda name, fn: fn())
+        eng = self.eng
+        y = run("stage1", lambda: eng.c3d2_stage1(feat, crop_idx, self.stage1_tables()))
+        z = run("stage2", lambda: eng.c3d2_stage2(y, self.stage2_tables()))
+        y = run("conv3_1", lambda: eng.c3d2_conv31(z, self.conv31_tables()))
+        y = run("conv3_2", lambda: eng.c3d2_conv32t(y, self.conv32t_tables()))
+        y = run("conv4_1", lambda: eng.c3d2_conv41(y, self.conv41_tables()))
+        y = run("conv4_2", lambda: eng.c3d2_conv42(y, self.conv42_tables()))
+        return run("fc5", lambda: eng.c3d2_fc5(y, self.fc5_tables()))
 
     @torch.no_grad()
-    def from_windows(self, windows, n, n_crops, crop_frames, n_cols):
-        """Embeddings from the first layer's patch matrix (see first_layer_windows) instead of the cube."""
-        w = self.stages[0][0]
-        kd, kw = int(w.shape[2]), int(w.shape[4])
-        od, ow = n_crops - kd + 1, n_cols - kw + 1
-        _, wt, bt = self._first_layer_tables(ow)
-        x = torch.addmm(bt, windows, wt)
-        x = x.view(n, od, crop_frames, ow, w.shape[0]).permute(0, 4, 1, 2, 3)     # NDHWC memory = channels_last_3d
-        return self._run(x, first_done=True)
-
-    @torch.no_grad()
-    def __call__(self, x):
-        if self.channels_last:
-            x = x.contiguous(memory_format=torch.channels_last_3d)
-        return self._run(x, first_done=False)
-
-    def _channel_slopes(self, li):
-        """PReLU slope of stage `li` as one value per output channel (nn.PReLU() holds a single one), cached."""
-        cache = self.__dict__.setdefault("_slopes", {})
-        if li not in cache:
-            w, _, slope = self.stages[li][:3]
-            cache[li] = slope.expand(w.shape[0]).contiguous() if slope.numel() == 1 else slope.contiguous()
-        return cache[li]
+    def __call__(self, cubes, batch=4096):
+        """cubes [n, 1, 20, 80, 40] f32 on the device -> [n, 128]: the cube's memory is read as [n, 1 600, 40] feature rows
+        with crop starts 0, 80, ... (a view: nothing is copied or re-gathered)."""
+        if cubes.dim() != 5 or tuple(cubes.shape[1:]) != CUBE_SHAPE:
+            raise ValueError("expected cubes of shape (n, 1, 20, 80, 40), got %s" % (tuple(cubes.shape),))
+        x = self.eng.to_device(cubes, torch.float32)
+        n = x.shape[0]
+        rows = x.view(n, CUBE_SHAPE[1] * CUBE_SHAPE[2], CUBE_SHAPE[3])
+        if n <= batch:
+            return self.embed_features(rows, self.crop_starts(n, x.device)) if n else x.new_empty((0, EMBED_DIM))
+        out = torch.empty((n, EMBED_DIM), dtype=torch.float32, device=x.device)
+        for lo in range(0, n, batch):
+            hi = min(n, lo + batch)
+            out[lo:hi] = self.embed_features(rows[lo:hi], self.crop_starts(hi - lo, x.device))
+        return out
 
     # ---- the first block (conv1_1 .. pool1) as one libsvk kernel ------------------------------------
     def stage1_tables(self):
@@ -333,34 +301,6 @@ class FusedEmbedder:
         self._conv31 = (frag.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
         return self._conv31
 
-    def conv32_tables(self):
-        """Operand fragments of `svk_c3d2_conv32` (conv3_2: 64 -> 64, k(3,7,1), stride 1, no pool), BN folded, or None
-        when the layer differs:  wfrag [4 nt][21][4 chunks][64][4]: lane (co = 16 nt + (l & 15), kk = l >> 4):
-        W[co][16 chunk + 4 kk + e][kd][kh], tap 7 kd + kh."""
-        hit = getattr(self, "_conv32", False)
-        if hit is not False:
-            return hit
-        self._conv32 = None
-        if len(self.stages) < 6:
-            return None
-        w, b, sl, st, pool, _ = self.stages[5]
-        if tuple(w.shape) != (64, 64, 3, 7, 1) or tuple(st) != (1, 1, 1) or pool:
-            return None
-        dev = w.device
-        lane = torch.arange(64, device=dev)
-        ch, kq = lane & 15, lane >> 4
-        a = w.contiguous()[:, :, :, :, 0]                                    # [co][ci][kd][kh]
-        frag = torch.empty((4, 21, 4, 64, 4), dtype=torch.float32, device=dev)
-        for nt in range(4):
-            for kd in range(3):
-                for kh in range(7):
-                    for chunk in range(4):
-                        for e in range(4):
-                            frag[nt, 7 * kd + kh, chunk, :, e] = a[16 * nt + ch, 16 * chunk + 4 * kq + e, kd, kh]
-        slope = sl.expand(64).contiguous() if sl.numel() == 1 else sl.contiguous()
-        self._conv32 = (frag.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
-        return self._conv32
-
     @staticmethod
     def _depth_transformed(w):
         """Winograd F(2, 3) weight transform along depth of a BN-folded Conv3d weight [co][ci][3][kh][kw] ->
@@ -435,122 +375,6 @@ class FusedEmbedder:
         frag = wv[:, n_, :, :, kq].permute(2, 1, 3, 0, 4).contiguous()       # lane axis first -> [d][nt][step][lane][e]
         self._fc5 = (frag, self.fc_b.contiguous())
         return self._fc5
-
-    def tail_in_libsvk(self):
-        """True when conv3_1 .. FC5 all have libsvk kernels for this model (then `from_stage2` calls no framework op)."""
-        return bool(self.fused_tail is not None and self.conv31_kernel and self.conv32_kernel and self.conv4_kernels
-                    and self.conv31_tables() is not None and self.conv32_tables() is not None
-                    and self.conv41_tables() is not None and self.conv42_tables() is not None
-                    and self.fc5_tables() is not None)
-
-    @torch.no_grad()
-    def tail_from_conv32(self, y, n, timed=None):
-        """conv4_1 -> conv4_2 -> FC5 in libsvk from conv3_2's CHUNKED output [n][8][8][45][8] (csrc/c3d2_tail.hip)."""
-        timed = timed or (lambda name, fn: fn())
-        y = timed("conv4_1", lambda: self.fused_tail.c3d2_conv41(y, self.conv41_tables()))
-        y2 = timed("conv4_2", lambda: self.fused_tail.c3d2_conv42(y, self.conv42_tables()))
-        return timed("fc5", lambda: self.fused_tail.c3d2_fc5(y2, self.fc5_tables()))
-
-    @torch.no_grad()
-    def from_stage2(self, z, n, timed=None):
-        """Embeddings from the output of `svk_c3d2_stage2`: the activation after pool2, [n][12][15][7][32].  conv3_1 ..
-        FC5 run in libsvk too when the engine is there (SVK_C3D2_CONV31 / CONV32 / CONV4 = 0 hand layers back to
-        PyTorch-ROCm).  `timed(name, fn)`: the pipeline's HIP-event hook around each kernel (bench.py)."""
-        t31 = self.conv31_tables() if (self.fused_tail is not None and self.conv31_kernel and z.is_cuda) else None
-        if t31 is not None:
-            timed_ = timed or (lambda name, fn: fn())
-            if self.conv32t_kernel and self.tail_in_libsvk() and self.conv32t_tables() is not None:
-                # conv3_2 in the last block's shape (the default): conv3_1 writes the chunked, column-major layout it stages from
-                y = timed_("conv3_1", lambda: self.fused_tail.c3d2_conv31(z.view(n, 12, 15, 7, 32), t31, chunked=True))
-                yc = timed_("conv3_2", lambda: self.fused_tail.c3d2_conv32t(y, self.conv32t_tables()))
-                return self.tail_from_conv32(yc, n, timed)
-            y = timed_("conv3_1", lambda: self.fused_tail.c3d2_conv31(z.view(n, 12, 15, 7, 32), t31))
-            t32 = self.conv32_tables() if self.conv32_kernel else None
-            if t32 is not None:
-                if (self.conv4_kernels and self.conv41_tables() is not None and self.conv42_tables() is not None
-                        and self.fc5_tables() is not None):
-                    # the whole rest of the network in libsvk: conv3_2 writes the chunked layout conv4_1 stages from
-                    yc = timed_("conv3_2", lambda: self.fused_tail.c3d2_conv32(y, t32, chunked=True))
-                    return self.tail_from_conv32(yc, n, timed)
-                y = self.fused_tail.c3d2_conv32(y, t32)
-                x = y.view(n, 8, 9, 5, 64).permute(0, 4, 1, 2, 3)           # (n, 64, 8, 9, 5), channels_last_3d memory
-                return self._run(x, start=6)
-            x = y.view(n, 10, 15, 5, 64).permute(0, 4, 1, 2, 3)             # (n, 64, 10, 15, 5), channels_last_3d memory
-            return self._run(x, start=5)
-        x = z.view(n, 12, 15, 7, 32).permute(0, 4, 1, 2, 3)                 # (n, 32, 12, 15, 7), channels_last_3d memory
-        return self._run(x, start=4)
-
-    @torch.no_grad()
-    def from_stage1(self, y, n):
-        """Embeddings from the output of `svk_c3d2_stage1` -- the activation after pool1, in the row-folded
-        channels-last layout [n][16][18][18][2][16] when `self.row_fold` exists, plain [n][16][36][18][16] otherwise."""
-        if self.row_fold is not None:
-            x = y.view(n, 16, 18, 18, 32).permute(0, 4, 1, 2, 3)           # (n, 32, 16, 18, 18), channels_last_3d memory
-            return self._run(x, start=2, fold=self.row_fold)
-        x = y.view(n, 16, 36, 18, 16).permute(0, 4, 1, 2, 3)
-        return self._run(x, start=2)
-
-    def _run(self, x, first_done=False, start=0, fold=None):
-        for li, (w, b, slope, stride, pool, pool_first) in enumerate(self.stages):
-            if li < start:
-                continue
-            groups = 1
-            if li == 1 and self.row_fold is not None:
-                # rows fold only when conv1_2's output has an even number of rows that the stride-4 form reproduces
-                h_out = (x.shape[3] - self.row_fold["kh1"]) // 2 + 1
-                if h_out % 2 == 0 and (x.shape[3] - self.row_fold["kh1"] - 2) // 4 + 1 == h_out // 2:
-                    fold = self.row_fold
-            if fold is not None and li == 2 and x.is_contiguous(memory_format=torch.channels_last_3d):
-                # (parity, c) channels over w  ==  c channels over the interleaved (w, parity) axis: same bytes
-                n_, c2, d_, hp_, w_ = x.shape
-                xv = x.as_strided((n_, c2 // 2, d_, hp_, 2 * w_), (x.stride(0), 1, x.stride(2), x.stride(3), c2 // 2))
-                y = F.prelu(F.conv3d(xv, w, b, dilation=(1, 1, 2)), slope)
-                # the view below re-reads y's memory as NDHWC; a convolution solver may hand back NCDHW
-                y = y.contiguous(memory_format=torch.channels_last_3d)
-                co = y.shape[1]
-                x = y.as_strided((n_, 2 * co, y.shape[2], hp_, y.shape[4] // 2),
-                                 (y.stride(0), 1, y.stride(2), y.stride(3), 2 * co))
-                continue
-            if fold is not None and li in (1, 2, 3):
-                w, b, slope, stride, groups = fold[li]
-            if li == 0 and first_done:
-                pass
-            elif li == 0 and self.first_as_gemm:
-                n, _, d, h, wd = x.shape
-                kd, kw = w.shape[2], w.shape[4]
-                od, ow = d - kd + 1, wd - kw + 1
-                G, wt, bt = self._first_layer_tables(ow)
-                xs = x.reshape(n, d, h, wd)
-                windows = xs.as_strided((n, od, h, ow // G, kd, kw + G - 1), (d * h * wd, h * wd, wd, G, h * wd, 1))
-                x = torch.addmm(bt, windows.reshape(n * od * h * (ow // G), kd * (kw + G - 1)), wt)
-                x = x.view(n, od, h, ow, w.shape[0]).permute(0, 4, 1, 2, 3)     # NDHWC memory = channels_last_3d
-            elif (self.fused_tail is not None and not pool and groups == 1 and w.shape[0] % 4 == 0 and x.is_cuda
-                  and x.is_contiguous(memory_format=torch.channels_last_3d)):
-                # conv3_1 .. conv4_2: the framework's convolution WITHOUT bias, then bias + PReLU in one in-place
-                # libsvk pass (svk_bias_prelu) instead of a bias-add kernel and a PReLU kernel
-                y = F.conv3d(x, w, None, stride=stride).contiguous(memory_format=torch.channels_last_3d)
-                x = self.fused_tail.bias_prelu_(y, b, self._channel_slopes(li))
-                continue
-            else:
-                x = F.conv3d(x, w, b, stride=stride, groups=groups)
-            if pool_first:
-                # MaxPool3d((1,1,2)) as one element-wise max of the even and odd columns (an odd last
-                # column is dropped, as the pooling floor does): 2.3x faster than max_pool3d here
-                w2 = x.shape[-1] // 2 * 2
-                x = F.prelu(torch.maximum(x[..., 0:w2:2], x[..., 1:w2:2]), slope)
-            else:
-                x = F.prelu(x, slope)
-                if pool:
-                    x = F.max_pool3d(x, kernel_size=(1, 1, 2), stride=(1, 1, 2))
-        if x.dim() == 5 and x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous():
-            # flatten in memory order (d, h, w, c) -- a view -- against FC5's columns permuted to match
-            # (model.py:168 flattens NCDHW: column c * 36 + (d, h, w))
-            if self.fc_w_cl is None:
-                cdhw = self.fc_w.view(self.fc_w.shape[0], x.shape[1], -1)                    # [out][c][dhw]
-                self.fc_w_cl = cdhw.permute(0, 2, 1).reshape(self.fc_w.shape[0], _FLAT).contiguous()
-            return F.linear(x.permute(0, 2, 3, 4, 1).reshape(x.shape[0], _FLAT), self.fc_w_cl, self.fc_b)
-        return F.linear(x.reshape(x.shape[0], _FLAT), self.fc_w, self.fc_b)
-
 
 def seeded_model(seed, n_labels=1211, num_channels=1):
     """Random-init C3D2 under a fixed torch seed (the reference's checkpoint

@@ -6,8 +6,8 @@ utterance at a time on the host:
   vad.py:135-168  ->  load_data.py:50-87  ->  utils.py:351-397  ->
   model.py:141-170  ->  evaluation.py:67-84.
 Every stage is a libsvk.so kernel, the C3D2 forward included (`svk_c3d2_stage1`, `svk_c3d2_stage2`,
-`svk_c3d2_conv31/32/41/42`, `svk_c3d2_fc5`); PyTorch-ROCm serves as device memory, streams and the
-module checkpoints load into (its own forward is the A/B path behind the SVK_C3D2_* switches).
+`svk_c3d2_conv31/32t/41/42`, `svk_c3d2_fc5`: `model.FusedEmbedder`); PyTorch-ROCm serves as device memory, streams and
+the module checkpoints load into.
 """
 import os
 
@@ -21,9 +21,10 @@ from .engine import get_engine, spec_from_seconds
 
 class VerificationPipeline:
     def __init__(self, model, use_vad=True, vad_threshold=c.VAD_ENERGY_THRESHOLD, normalize=c.NORMALIZE,
-                 fused_model=True, crop_seed=12345, micro_batch=1024, channels_last=True, preemph_cof=None,
-                 crop_rng="reference", miopen_find=True, overlap_front=False, pcm_scale=1.0 / 32768.0):
-        """crop_rng: "reference" draws crop starts on the host exactly like utils.py:372 (needs the
+                 crop_seed=12345, micro_batch=1024, preemph_cof=None, crop_rng="reference", overlap_front=False,
+                 pcm_scale=1.0 / 32768.0):
+        """model: a `model.C3D2` (one-channel cubes): its inference form is `model.fused_inference()`, seven libsvk kernels.
+        crop_rng: "reference" draws crop starts on the host exactly like utils.py:372 (needs the
         per-clip frame counts on the host: one small D2H per micro-batch); "device" draws them
         in a kernel keyed by (crop_seed, global clip index) -- no host round trip.
         preemph_cof: fuse processing.preemphasis(clip, cof=...) in front of the log-mel stage.
@@ -33,33 +34,13 @@ class VerificationPipeline:
         log-mel values of THAT scale (2 ln 32768 = 20.79 below those of raw int16 amplitudes).  The
         default reproduces it (a power of two folded into the filterbank weights: exact); 1.0 gives
         speechpy-on-raw-int16 values.
-        overlap_front: build the cube of micro-batch k+1 (VAD, front end, CMVN, crops, gather) on a
-        second HIP stream while the network runs on micro-batch k (device-drawn crops only)."""
+        overlap_front: run VAD, front end, CMVN and the crop draw of micro-batch k+1 on a second HIP stream
+        while the network runs on micro-batch k (device-drawn crops only)."""
         self.eng = get_engine()
-        # MIOpen's exhaustive find picks 1.7x faster f32 Conv3d kernels for these odd filter
-        # shapes than its immediate-mode heuristic (46.8 -> 27.5 ms per 1 024 cubes; with
-        # channels_last_3d 22.3 ms); it costs a few seconds on the first call per input shape.
-        # The switch is process-global in torch: it is set around this pipeline's own network
-        # calls only (`_find_mode`), not left on for the rest of the process.
-        self.miopen_find = bool(miopen_find)
-        import os
-        # SVK_C3D2_STAGE1=0: run the first block on PyTorch-ROCm too (A/B and parity tests)
-        self.stage1_kernel = os.environ.get("SVK_C3D2_STAGE1", "1") != "0"
-        self.stage2_kernel = self.stage1_kernel and os.environ.get("SVK_C3D2_STAGE2", "1") != "0"
-        # conv1_2 and conv2_1 through Winograd's F(2, 3) along depth (2 / 3 of the multiply-adds);
-        # SVK_C3D2_DEPTH_TRANSFORM=0 = direct sums
-        self.depth_transform = os.environ.get("SVK_C3D2_DEPTH_TRANSFORM", "1") != "0"
-        # the first block's kernel form: "t" = input transform applied once at conv1_1's output (c3d2_stage1t_kernel, the
-        # default), "w" = at every fragment read (c3d2_stage1w_kernel, round 2)
-        form = os.environ.get("SVK_C3D2_STAGE1_FORM", "m")
-        self.stage1_t_planes = self.depth_transform and form == "t"
-        # "m" (default): the round-2 form with the remainder rows of two depth pairs merged into one tile; "w": round 2 as it was
-        self.stage1_merged = self.depth_transform and form == "m"
         # bench.py sets this to a list: one {kernel name: (start, end) HIP events on the launch stream, "cubes": n} per
         # micro-batch, around every network kernel
         self.kernel_events = None
         self.model = model.to(self.eng.device).eval()
-        self.fused_model, self.channels_last = fused_model, channels_last
         self.refresh_model()
         self.use_vad, self.vad_threshold, self.normalize = use_vad, int(vad_threshold), bool(normalize)
         self.micro_batch = int(micro_batch)
@@ -80,12 +61,12 @@ class VerificationPipeline:
 
     def refresh_model(self):
         """Re-snapshot the (BN-folded) inference weights after the model's state changed."""
-        self.embedder = self.model.fused_inference(channels_last=self.channels_last) if self.fused_model else None
+        self.embedder = self.model.fused_inference()
 
     def chunks(self, n):
         """(lo, hi) micro-batches of ONE size where possible: the count is ceil(n / micro_batch),
         the size ceil(n / count), and the last one is shifted back to keep that size (it redoes
-        a few clips of its neighbour) -- MIOpen's kernel search runs once per input shape."""
+        a few clips of its neighbour): every launch sequence sees the same shapes."""
         if n <= 0:
             return []
         count = -(-n // self.micro_batch)
@@ -152,73 +133,27 @@ class VerificationPipeline:
         crops = np.concatenate(crops).astype(np.int32) if crops else np.zeros((0, c.CUBE_CROPS), np.int32)
         return (crops, torch.cat(cubes)) if want_cubes else crops
 
-    def _find_mode(self):
-        import contextlib
-
-        @contextlib.contextmanager
-        def scope():
-            saved = torch.backends.cudnn.benchmark
-            torch.backends.cudnn.benchmark = self.miopen_find or saved
-            try:
-                yield
-            finally:
-                torch.backends.cudnn.benchmark = saved
-        return scope()
-
     def embed_cubes(self, cubes):
-        with torch.no_grad(), self._find_mode():
-            if self.embedder is not None:
-                return self.embedder(cubes)
-            return self.model(cubes, development=False)
+        """[n, 1, 20, 80, 40] cubes -> [n, 128]: the cube read as feature rows by the first-block kernel (no copy)."""
+        return self.embedder(cubes)
 
     def embed_features(self, feat, crop_idx):
         """features + crop starts -> embeddings.  The cube is never materialised: `svk_c3d2_stage1` reads the
-        feature rows and crop starts itself (C3D2 geometry); for other first layers `svk_cube_gather_windows` writes
-        the first layer's patch matrix (FusedEmbedder.from_windows); otherwise cube -> network."""
-        tables = self.embedder.stage1_tables() if (self.embedder is not None and self.stage1_kernel) else None
-        if tables is not None and feat.shape[2] == c.NUM_COEF and crop_idx.shape[1] == c.CUBE_CROPS:
-            # conv1_1 .. pool1 in one libsvk kernel (csrc/c3d2.hip): the cube and conv1_1's 3.3 MB-per-cube output
-            # never reach HBM
-            tables2 = self.embedder.stage2_tables() if self.stage2_kernel else None
-            if tables2 is not None:
-                # ... and conv2_1, conv2_2, pool2 in two more; conv3_1 .. FC5 follow inside from_stage2 (libsvk too)
-                spans = {"cubes": feat.shape[0]} if self.kernel_events is not None else None
+        feature rows and crop starts itself; the other six kernels follow (model.FusedEmbedder.embed_features)."""
+        if self.kernel_events is None:
+            return self.embedder.embed_features(feat, crop_idx)
+        spans = {"cubes": feat.shape[0]}
 
-                def timed(name, fn):
-                    if spans is None:
-                        return fn()
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    out = fn()
-                    b.record()
-                    spans[name] = (a, b)
-                    return out
-                y = timed("stage1", lambda: self.eng.c3d2_stage1(feat, crop_idx, tables, folded=False, crop_frames=c.CUBE_FRAMES,
-                                                                  depth_transform=self.depth_transform,
-                                                                  t_planes=self.stage1_t_planes, merged_tiles=self.stage1_merged))
-                z = timed("stage2", lambda: self.eng.c3d2_stage2(y, tables2, depth_transform=self.depth_transform))
-                if spans is not None:
-                    self.kernel_events.append(spans)
-                if self.embedder.tail_in_libsvk():
-                    # conv3_1 .. FC5 are libsvk kernels too: nothing of the host framework runs, no MIOpen find to scope
-                    return self.embedder.from_stage2(z, feat.shape[0], timed)
-                with self._find_mode():
-                    return self.embedder.from_stage2(z, feat.shape[0])
-            folded = self.embedder.row_fold is not None
-            y = self.eng.c3d2_stage1(feat, crop_idx, tables, folded=folded, crop_frames=c.CUBE_FRAMES,
-                                     depth_transform=self.depth_transform, t_planes=self.stage1_t_planes,
-                                     merged_tiles=self.stage1_merged)
-            with self._find_mode():
-                return self.embedder.from_stage1(y, feat.shape[0])
-        geo = self.embedder.first_layer_windows(c.CUBE_CROPS, feat.shape[2]) if self.embedder is not None else None
-        if geo is not None:
-            kd, kw, G = geo
-            if G % 4 == 0 and (kw + G - 1) % 4 == 0 and feat.shape[2] % 4 == 0:
-                windows = self.eng.cube_windows(feat, crop_idx, c.CUBE_FRAMES, kd, kw, G)
-                with self._find_mode():
-                    return self.embedder.from_windows(windows, feat.shape[0], c.CUBE_CROPS, c.CUBE_FRAMES,
-                                                      feat.shape[2])
-        return self.embed_cubes(self.cubes(feat, crop_idx))
+        def timed(name, fn):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn()
+            b.record()
+            spans[name] = (a, b)
+            return out
+        out = self.embedder.embed_features(feat, crop_idx, timed)
+        self.kernel_events.append(spans)
+        return out
 
     # ---- whole path ---------------------------------------------------------------------
     def embed(self, pcm, crop_idx=None, return_intermediates=False, first_utt=0):
@@ -253,8 +188,8 @@ class VerificationPipeline:
         return (emb, inter) if return_intermediates else emb
 
     def _embed_overlapped(self, pcm, spans, emb, first_utt):
-        """Two HIP streams: the side stream turns micro-batch k+1 into its cube (all libsvk kernels: they
-        are HBM / VALU work) while the main stream runs the MFMA-bound network on micro-batch k."""
+        """Two HIP streams: the side stream turns micro-batch k+1 into features + crop starts (HBM / VALU work) while the
+        main stream runs the MFMA-bound network on micro-batch k."""
         dev = self.eng.device
         main = torch.cuda.current_stream(dev)
         if self._side_stream is None:
@@ -269,37 +204,23 @@ class VerificationPipeline:
                 feat, n_frames = self.features(voiced, vlen)
                 idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo,
                                           self.bad_clips)
-                geo = self.embedder.first_layer_windows(c.CUBE_CROPS, feat.shape[2]) if self.embedder is not None else None
-                if self.embedder is not None and self.stage1_kernel and self.embedder.stage1_tables() is not None:
-                    cube = ("features", (feat, idx), 0, 0)      # the first-block kernel reads the feature rows itself
-                elif geo is not None and geo[2] % 4 == 0 and (geo[1] + geo[2] - 1) % 4 == 0 and feat.shape[2] % 4 == 0:
-                    cube = ("windows", self.eng.cube_windows(feat, idx, c.CUBE_FRAMES, *geo), feat.shape[0], feat.shape[2])
-                else:
-                    cube = ("cube", self.cubes(feat, idx), 0, 0)
                 done = torch.cuda.Event()
                 done.record(side)
-            return cube, done
+            return (feat, idx), done
 
         nxt = stage(0)
         for k, (lo, hi) in enumerate(spans):
-            cube, done = nxt
+            data, done = nxt
             if k + 1 < len(spans):
                 nxt = stage(k + 1)
             main.wait_event(done)
-            kind, data, n_rows, n_cols = cube
-            for t in (data if isinstance(data, tuple) else (data,)):
+            for t in data:
                 t.record_stream(main)              # allocated on the side stream, consumed on the main one
-            if kind == "features":
-                emb[lo:hi] = self.embed_features(*data)
-            elif kind == "windows":
-                with self._find_mode():
-                    emb[lo:hi] = self.embedder.from_windows(data, n_rows, c.CUBE_CROPS, c.CUBE_FRAMES, n_cols)
-            else:
-                emb[lo:hi] = self.embed_cubes(data)
+            emb[lo:hi] = self.embed_features(*data)
         side.wait_stream(main)
         return emb
 
-    def _ragged_batches(self, lengths, max_batch_samples):
+    def _ragged_batches(self, lengths, max_batch_samples, max_feature_bytes=1 << 30):
         """Clip indices sorted by length and cut into batches of at most `micro_batch` clips and `max_batch_samples`
         samples (16-byte-aligned clip slots): a batch costs its own samples, not n x the longest clip."""
         order = sorted(range(len(lengths)), key=lambda k: int(lengths[k]))
@@ -314,33 +235,46 @@ class VerificationPipeline:
                 total += n
                 pos += 1
             out.append((batch, total))
-        # the longest clips would otherwise end up as a batch of a handful: seven network launches and a dozen-workgroup
-        # front end for a few clips.  A last batch of fewer than 64 clips joins its predecessor (at most 1.5 x the cap).
-        if len(out) >= 2 and len(out[-1][0]) < 64 and out[-2][1] + out[-1][1] <= max_batch_samples * 3 // 2:
-            tail = out.pop()
-            out[-1] = (out[-1][0] + tail[0], out[-1][1] + tail[1])
+        # the longest clips would otherwise end up as a batch of a handful: a dozen-workgroup front end for a few clips.  A last
+        # batch of fewer than 64 clips joins its predecessor -- when the merged batch stays within `micro_batch` clips, 1.5 x
+        # the sample cap, and a feature buffer (clips x the LONGEST clip's frames x 40 floats) of `max_feature_bytes`: joining
+        # 145 s clips to a full batch of 20 s ones would multiply that buffer instead
+        if len(out) >= 2 and len(out[-1][0]) < 64:
+            merged = len(out[-2][0]) + len(out[-1][0])
+            longest = int(lengths[out[-1][0][-1]])
+            feat_bytes = merged * max(1, longest // 160) * 40 * 4
+            if (merged <= self.micro_batch and out[-2][1] + out[-1][1] <= max_batch_samples * 3 // 2
+                    and feat_bytes <= max_feature_bytes):
+                tail = out.pop()
+                out[-1] = (out[-1][0] + tail[0], out[-1][1] + tail[1])
         return out
 
     @staticmethod
     def _upload_groups(offsets, lengths, n_samples, max_batch_samples):
         """A host arena cut into upload pieces: clips in arena order, a piece closed where the next clip would take it past
         `max_batch_samples` (a single longer clip is a piece of its own).  Returns (groups of clip indices, [lo, hi) sample
-        ranges): the ranges tile [0, n_samples) and every clip lies wholly inside its group's range."""
+        ranges): the ranges tile [0, n_samples) and every clip lies wholly inside its group's range -- also when clips
+        OVERLAP in the arena (windows over one recording): a piece ends at the furthest end of its clips, and a clip that
+        starts before that point belongs to the same piece."""
         by_pos = np.argsort(offsets, kind="stable")
-        ends = offsets[by_pos] + lengths[by_pos]
-        groups, pieces, lo, first = [], [], 0, 0
+        starts = offsets[by_pos].astype(np.int64)
+        ends = starts + lengths[by_pos]
+        groups, pieces, lo, first, reach = [], [], 0, 0, 0
         for q in range(len(by_pos)):
+            reach = max(reach, int(ends[q]))
             last = q + 1 == len(by_pos)
-            if last or int(ends[q + 1]) - int(offsets[by_pos[first]]) > max_batch_samples:
-                hi = n_samples if last else int(offsets[by_pos[q + 1]])
+            # the next clip may open a new piece only if it starts at or past everything this piece's clips cover
+            if last or (int(starts[q + 1]) >= reach and int(ends[q + 1]) - int(starts[first]) > max_batch_samples):
+                hi = n_samples if last else int(starts[q + 1])
                 groups.append(by_pos[first:q + 1])
                 pieces.append((lo, hi))
                 lo, first = hi, q + 1
         return groups, pieces
 
-    def _embed_ragged_batch(self, dev_buf, offs, lens, rows, first_utt, voiced_out=None, spans=None, cube_out=None):
-        """One batch of clips addressed through offsets / lengths into `dev_buf` -> their embeddings (rows = the clips'
-        indices in the caller's list: they key the crop draw)."""
+    def _ragged_front(self, dev_buf, offs, lens, longest, rows, voiced_out=None, spans=None):
+        """VAD -> front end -> CMVN -> crop draw of one batch of clips addressed through offsets / lengths (device slices)
+        into `dev_buf`; `longest`: the batch's longest clip in samples (host int); rows: the clips' global indices (they key
+        the crop draw).  Returns (features [n, T, 40], crop starts [n, 20]); nothing here touches the host."""
         def timed(name, fn):
             if spans is None:
                 return fn()
@@ -355,57 +289,82 @@ class VerificationPipeline:
         if self.use_vad:
             res = timed("vad", lambda: self.eng.vad_energy(dev_buf, self.vad_threshold, fs=c.SAMPLE_RATE, frame_ms=c.VAD_FRAME_MS,
                                                            padding_ms=c.VAD_PADDING_MS, lengths=lens, offsets=offs, compact=True,
-                                                           voiced_out=voiced_out))
+                                                           voiced_out=voiced_out, longest=longest))
             buf, dev_lens = res["voiced"], res["voiced_len"]
         feat, n_frames, _ = timed("frontend", lambda: self.eng.features(buf, self.spec, lengths=dev_lens, offsets=offs,
-                                                                         max_frames=self.spec.num_frames(int(np.max(lens)))))
+                                                                         max_frames=self.spec.num_frames(int(longest))))
         if self.normalize:
             timed("cmvn", lambda: self.eng.cmvn_(feat, n_frames, variance=True))
-        # the crop draw is keyed by the clip's index in the caller's list, whatever batch it landed in
         idx = timed("crops", lambda: self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, 0, self.bad_clips,
-                                                         utt_index=rows + first_utt))
-        if cube_out is not None:
-            # deferred network (see _ragged_network): only the 20 x 80 rows the network will read leave this batch
-            timed("gather", lambda: self.eng.cube_gather(feat, idx, c.CUBE_FRAMES, out=cube_out))
-            return None
-        return timed("network", lambda: self.embed_features(feat, idx))
+                                                         utt_index=rows))
+        return feat, idx
 
-    def _ragged_defer(self):
-        """Length-sorted batches are what the front end wants (their feature buffers are sized by the longest clip) and
-        what the network does NOT want: the batch of the longest clips is a few dozen cubes, and a persistent kernel that
-        works on 16-cube groups leaves most of the chip idle there (measured: 0.45 ms of fixed cost per such batch).  So the
-        ragged paths gather each batch's cubes (256 KB per clip, utils.py:351-379) into one buffer and run the network
-        ONCE over full micro-batches; the first block then reads that buffer as feature rows with crop starts 0, 80, 160 ...
-        Needs the libsvk first block (C3D2 geometry); SVK_RAGGED_DEFER=0 runs the network per batch."""
-        import os
-        return (os.environ.get("SVK_RAGGED_DEFER", "1") != "0" and self.embedder is not None and self.stage1_kernel
-                and self.embedder.stage1_tables() is not None and self.spec.num_cols == c.NUM_COEF)
+    class _CubeRing:
+        """Length-sorted batches are what the front end wants (their feature buffers are sized by the longest clip) and what
+        the network does NOT want: the batch of the longest clips is a few dozen cubes, and a persistent kernel that works on
+        16-cube groups leaves most of the chip idle there (measured: 0.45 ms of fixed cost per such batch).  So every batch
+        leaves only its gathered cubes (the 20 x 80 rows the network will read: 256 KB per clip, utils.py:351-379) in a RING
+        of 2 x `step` cubes, and the network runs over `step` cubes as soon as that many have gathered; the first block reads
+        the ring as feature rows with crop starts 0, 80, 160 ...  Memory is O(step), whatever the number of clips."""
 
-    def _ragged_network(self, cubes, emb_sorted, lo, hi, spans=None):
-        """Embeddings of the gathered cubes [lo, hi) ([n, 1, 20, 80, 40], any clip order) into emb_sorted[lo:hi]."""
-        n = cubes.shape[0]
-        rows = cubes.view(n, c.CUBE_CROPS * c.CUBE_FRAMES, c.NUM_COEF)
-        starts = (torch.arange(c.CUBE_CROPS, dtype=torch.int32, device=self.eng.device) * c.CUBE_FRAMES)[None, :]
-        ev = None
-        if spans is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        emb_sorted[lo:hi] = self.embed_features(rows[lo:hi], starts.expand(hi - lo, -1).contiguous())
-        if ev is not None:
-            ev[1].record()
-            spans.append(("network", ev[0], ev[1]))
+        def __init__(self, pipe, step, emb, order_dev, spans):
+            self.pipe, self.step, self.cap = pipe, int(step), 2 * int(step)
+            self.emb, self.order, self.spans = emb, order_dev, spans
+            hit = getattr(pipe, "_ring_buf", None)
+            if hit is None or hit.shape[0] != self.cap:
+                hit = pipe._ring_buf = torch.empty((self.cap, 1, c.CUBE_CROPS, c.CUBE_FRAMES, c.NUM_COEF), dtype=torch.float32,
+                                                   device=pipe.eng.device)
+            self.cubes = hit
+            self.rows = hit.view(self.cap, c.CUBE_CROPS * c.CUBE_FRAMES, c.NUM_COEF)
+            self.at = self.done = 0            # cubes gathered / handed to the network so far (absolute counts)
+
+        def _event(self):
+            if self.spans is None:
+                return None
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+
+        def push(self, feat, idx):
+            n = feat.shape[0]
+            assert n <= self.step, "a batch must not exceed the network step"
+            a = self._event()
+            w = self.at % self.cap
+            first = min(n, self.cap - w)
+            self.pipe.eng.cube_gather(feat[:first], idx[:first], c.CUBE_FRAMES, out=self.cubes[w:w + first])
+            if first < n:                        # the batch wraps around the end of the ring
+                self.pipe.eng.cube_gather(feat[first:], idx[first:], c.CUBE_FRAMES, out=self.cubes[:n - first])
+            if a is not None:
+                self.spans.append(("gather", a, self._event()))
+            self.at += n
+            while self.at - self.done >= self.step:
+                self._network(self.step)
+
+        def _network(self, n):
+            lo = self.done % self.cap              # a multiple of `step`: [lo, lo + n) never wraps
+            a = self._event()
+            out = self.pipe.embed_features(self.rows[lo:lo + n], self.pipe.embedder.crop_starts(n, self.cubes.device))
+            self.emb[self.order[self.done:self.done + n]] = out
+            if a is not None:
+                self.spans.append(("network", a, self._event()))
+            self.done += n
+
+        def finish(self):
+            if self.at > self.done:
+                self._network(self.at - self.done)
 
     def embed_ragged(self, clips, max_batch_samples=64 * 1024 * 1024, first_utt=0, spans=None):
         """Clips of DIFFERENT lengths (VoxCeleb1 utterances run from 4 to 145 s): `clips` is a list of 1-D
         int16 arrays on the HOST.  They are sorted by length, packed back to back (16-byte aligned) into batches of
         at most `max_batch_samples` samples and `micro_batch` clips, uploaded, and addressed through the
         offsets / lengths form of the C-ABI.  Embeddings come back in the order of `clips`.  Needs crop_rng='device'.
-        `spans`: a list that receives ("vad" | "frontend" | "cmvn" | "crops" | "network", start, end) HIP events per batch (bench.py)."""
+        `spans`: a list that receives ("vad" | "frontend" | "cmvn" | "crops" | "gather" | "network", start, end) HIP events (bench.py)."""
         if self.crop_rng != "device":
             raise ValueError("embed_ragged needs crop_rng='device'")
         dev = self.eng.device
         emb = torch.empty((len(clips), 128), dtype=torch.float32, device=dev)
-        batches = self._ragged_batches([len(x) for x in clips], max_batch_samples)
+        lengths = np.array([len(x) for x in clips], dtype=np.int64)
+        batches = self._ragged_batches(lengths, max_batch_samples)
         if not batches:
             return emb
         # Two pinned host buffers + two device buffers: batch k + 1 is packed by 8 host threads (np.copyto releases the
@@ -420,74 +379,72 @@ class VerificationPipeline:
             self._rag_voiced = torch.empty((cap,), dtype=torch.int16, device=dev) if self.use_vad else None
             self._rag_stream = torch.cuda.Stream(device=dev)
             from concurrent.futures import ThreadPoolExecutor
-            self._rag_pool = ThreadPoolExecutor(max_workers=int(os.environ.get("SVK_RAGGED_THREADS", "8")))
+            self._rag_threads = int(os.environ.get("SVK_RAGGED_THREADS", "8"))
+            self._rag_pool = ThreadPoolExecutor(max_workers=self._rag_threads)
+        # every batch's clip order, batch-local offsets and lengths go up ONCE, before the loop: a host array handed to a
+        # launch is a synchronous copy that waits for everything queued before it
+        order = np.concatenate([np.asarray(b, dtype=np.int64) for b, _ in batches])
+        lens_sorted = lengths[order]
+        offs_sorted = np.empty_like(order)
+        pos = 0
+        for batch, _ in batches:
+            slots = (lens_sorted[pos:pos + len(batch)] + 7) // 8 * 8
+            offs_sorted[pos:pos + len(batch)] = np.concatenate([[0], np.cumsum(slots)[:-1]])
+            pos += len(batch)
+        order_dev = torch.from_numpy(order).to(dev)
+        keys_dev = order_dev + int(first_utt)
+        offs_dev = torch.from_numpy(offs_sorted).to(dev)
+        lens_dev = torch.from_numpy(lens_sorted.astype(np.int32)).to(dev)
         main = torch.cuda.current_stream(dev)
         copy_stream = self._rag_stream
         copy_stream.synchronize()                          # a previous call's copies may still read the pinned buffers
         copy_stream.wait_stream(main)
         copied = [torch.cuda.Event() for _ in range(2)]
         consumed = [torch.cuda.Event() for _ in range(2)]
-        meta = {}
+        starts = np.concatenate([[0], np.cumsum([len(b) for b, _ in batches])])
 
         def stage(k):
             batch, total = batches[k]
             slot = k & 1
             if k >= 2:
                 consumed[slot].synchronize()               # the GPU is done with what this pinned / device pair held
-            offs, lens, at = [], [], 0
-            for j in batch:
-                n = len(clips[j])
-                offs.append(at)
-                lens.append(n)
-                at += (n + 7) // 8 * 8
+            offs = offs_sorted[starts[k]:starts[k + 1]]
             dst = self._rag_np[slot]
 
             def put(lo, hi):
                 for q in range(lo, hi):
-                    np.copyto(dst[offs[q]:offs[q] + lens[q]], np.asarray(clips[batch[q]], dtype=np.int16), casting="no")
-            step = -(-len(batch) // self._rag_pool._max_workers)
+                    src = np.asarray(clips[batch[q]], dtype=np.int16)
+                    np.copyto(dst[offs[q]:offs[q] + src.size], src, casting="no")
+            step = -(-len(batch) // self._rag_threads)
             jobs = [self._rag_pool.submit(put, lo, min(len(batch), lo + step)) for lo in range(0, len(batch), step)]
             for jb in jobs:
                 jb.result()
             with torch.cuda.stream(copy_stream):
                 self._rag_dev[slot][:total].copy_(self._rag_pinned[slot][:total], non_blocking=True)
                 copied[slot].record(copy_stream)
-            meta[k] = (np.asarray(offs, dtype=np.int64), np.asarray(lens, dtype=np.int32))
 
-        defer = self._ragged_defer()
-        cubes = torch.empty((len(clips), 1, c.CUBE_CROPS, c.CUBE_FRAMES, c.NUM_COEF), dtype=torch.float32, device=dev) if defer else None
-        emb_sorted = torch.empty_like(emb) if defer else None
-        order, at, done = [], 0, 0
+        ring = self._CubeRing(self, self.micro_batch, emb, order_dev, spans)
         stage(0)
         for k, (batch, total) in enumerate(batches):
             slot = k & 1
             main.wait_event(copied[slot])
-            offs, lens = meta.pop(k)
-            rows = torch.as_tensor(np.asarray(batch, dtype=np.int64), device=dev)
+            sl = slice(int(starts[k]), int(starts[k + 1]))
             voiced = self._rag_voiced[:total] if self.use_vad else None
-            out = self._embed_ragged_batch(self._rag_dev[slot][:total], offs, lens, rows, first_utt, voiced_out=voiced, spans=spans,
-                                           cube_out=cubes[at:at + len(batch)] if defer else None)
-            if not defer:
-                emb[rows] = out
-            order += batch
-            at += len(batch)
+            feat, idx = self._ragged_front(self._rag_dev[slot][:total], offs_dev[sl], lens_dev[sl], int(lens_sorted[sl].max()),
+                                           keys_dev[sl], voiced_out=voiced, spans=spans)
             consumed[slot].record(main)
             # the network runs as soon as a full micro-batch of cubes has gathered: its kernels then cover the host-side
-            # packing of the next batch (a single pass at the very end would leave that packing uncovered)
-            while defer and at - done >= self.micro_batch:
-                self._ragged_network(cubes, emb_sorted, done, done + self.micro_batch, spans)
-                done += self.micro_batch
+            # packing of the next batch
+            ring.push(feat, idx)
             if k + 1 < len(batches):
                 stage(k + 1)                               # host packing + H2D of the next batch under this batch's kernels
-        if defer:
-            if at > done:
-                self._ragged_network(cubes, emb_sorted, done, at, spans)
-            emb[torch.as_tensor(np.asarray(order, dtype=np.int64), device=dev)] = emb_sorted
+        ring.finish()
         return emb
 
     def embed_ragged_resident(self, buf, offsets, lengths, max_batch_samples=64 * 1024 * 1024, first_utt=0, spans=None):
         """`embed_ragged` for audio that is ALREADY in one buffer: `buf` is one 1-D int16 array holding every clip, clip k at
-        samples [offsets[k], offsets[k] + lengths[k]) (offsets multiples of 8: 16-byte aligned; host arrays).
+        samples [offsets[k], offsets[k] + lengths[k]) (offsets multiples of 8: 16-byte aligned; host arrays; clips may
+        overlap, e.g. windows over one recording).
           * a DEVICE tensor: batches are lists of clip indices into that one buffer -- nothing is copied or packed; the VAD
             writes its voiced samples into one scratch buffer of the same shape, reused by every batch;
           * a HOST NumPy array (a loader that decodes into one arena): uploaded as it is, no per-clip packing on the host
@@ -523,6 +480,17 @@ class VerificationPipeline:
         groups, pieces = [np.arange(len(lengths))], [(0, n_samples)]
         if host and n_samples > 2 * max_batch_samples:
             groups, pieces = self._upload_groups(offsets, lengths, n_samples, max_batch_samples)
+        # the whole schedule is known from the lengths: plan every group's batches and upload order / offsets / lengths ONCE
+        plan = []                                             # (group, clip indices of the batch, longest clip)
+        for g, idx in enumerate(groups):
+            for batch, _ in self._ragged_batches(lengths[idx], max_batch_samples):
+                ids = idx[np.asarray(batch, dtype=np.int64)]
+                plan.append((g, ids, int(lengths[ids].max())))
+        order = np.concatenate([ids for _, ids, _ in plan]).astype(np.int64)
+        order_dev = torch.from_numpy(order).to(dev)
+        keys_dev = order_dev + int(first_utt)
+        offs_dev = torch.from_numpy(offsets[order]).to(dev)
+        lens_dev = torch.from_numpy(lengths[order]).to(dev)
         flags, events, worker = None, None, None
         if host:
             import threading
@@ -551,39 +519,27 @@ class VerificationPipeline:
             worker.start()
             buf = dev_buf
         voiced = torch.empty_like(buf) if self.use_vad else None
-        defer = self._ragged_defer()
-        cubes = torch.empty((len(lengths), 1, c.CUBE_CROPS, c.CUBE_FRAMES, c.NUM_COEF), dtype=torch.float32, device=dev) if defer else None
-        emb_sorted = torch.empty_like(emb) if defer else None
+        # with pieces still travelling the network runs per micro-batch of gathered cubes (it covers the next piece's upload);
+        # otherwise over micro-batches as large as the main path's
         step = self.micro_batch if len(groups) > 1 else max(self.micro_batch, 4096)
-        order, at, done = [], 0, 0
+        ring = self._CubeRing(self, step, emb, order_dev, spans)
         main = torch.cuda.current_stream(dev)
-        for g, idx in enumerate(groups):
-            if flags is not None:
+        pos, seen = 0, -1
+        for g, ids, longest in plan:
+            if flags is not None and g != seen:
                 flags[g].wait()
                 if failure:
                     worker.join()
                     raise failure[0]
                 main.wait_event(events[g])
-            for batch, _ in self._ragged_batches(lengths[idx], max_batch_samples):
-                batch = [int(idx[b]) for b in batch]
-                rows = torch.as_tensor(np.asarray(batch, dtype=np.int64), device=dev)
-                out = self._embed_ragged_batch(buf, offsets[batch], lengths[batch], rows, first_utt, voiced_out=voiced, spans=spans,
-                                               cube_out=cubes[at:at + len(batch)] if defer else None)
-                if not defer:
-                    emb[rows] = out
-                order += batch
-                at += len(batch)
-            # with pieces still travelling the network runs as soon as a micro-batch of cubes has gathered (it covers the
-            # next piece's upload); otherwise once, at the end, over micro-batches as large as the main path's
-            while defer and len(groups) > 1 and g + 1 < len(groups) and at - done >= step:
-                self._ragged_network(cubes, emb_sorted, done, done + step, spans)
-                done += step
+                seen = g
+            sl = slice(pos, pos + len(ids))
+            feat, idx = self._ragged_front(buf, offs_dev[sl], lens_dev[sl], longest, keys_dev[sl], voiced_out=voiced, spans=spans)
+            ring.push(feat, idx)
+            pos += len(ids)
         if worker is not None:
             worker.join()
-        if defer:
-            for lo in range(done, at, step):
-                self._ragged_network(cubes, emb_sorted, lo, min(at, lo + step), spans)
-            emb[torch.as_tensor(np.asarray(order, dtype=np.int64), device=dev)] = emb_sorted
+        ring.finish()
         return emb
 
     def embed_host(self, pcm_host, first_utt=0):

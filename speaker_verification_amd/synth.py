@@ -86,7 +86,8 @@ def corpus_device(n_clips, device, first_clip=0, utts_per_speaker=123, n_samples
     syllable modulation, noise floor) but synthesised with torch on the GPU, so the bytes are
     NOT those of `speaker_clip`; parity checks copy the clips they need back to the host.
     Clip g (global index first_clip + row) belongs to speaker g // utts_per_speaker and its
-    parameters depend only on (seed, g).  Unlike `speaker_clip`, the formants of a speaker swell in
+    bytes depend only on (seed, g, chunk): the noise is drawn per GLOBAL chunk of `chunk` clips (clips [k chunk, (k + 1) chunk),
+    always at full chunk size), so a shard that starts anywhere holds the same clips as the whole corpus does.  Unlike `speaker_clip`, the formants of a speaker swell in
     a speaker-specific +-1 pattern: per-clip CMVN removes a speaker's static spectral envelope, so
     without speaker-specific DYNAMICS the normalised features carry no speaker information at all
     and every scorer sits at EER 0.5."""
@@ -97,8 +98,10 @@ def corpus_device(n_clips, device, first_clip=0, utts_per_speaker=123, n_samples
     t = torch.arange(n_samples, device=device, dtype=torch.float32) / float(fs)
     K, NB = 6, 5                                   # formants (padded), bursts per clip
     voices = {}
-    for lo in range(0, n_clips, chunk):
-        hi = min(n_clips, lo + chunk)
+    last = first_clip + n_clips
+    for c0 in range(first_clip // chunk * chunk, last, chunk):          # global chunk [c0, c0 + chunk)
+        g_lo, g_hi = max(c0, first_clip), min(c0 + chunk, last)
+        lo, hi = g_lo - first_clip, g_hi - first_clip                    # rows of `out`
         m = hi - lo
         f = np.zeros((m, K), dtype=np.float32)
         a = np.zeros((m, K), dtype=np.float32)
@@ -149,9 +152,9 @@ def corpus_device(n_clips, device, first_clip=0, utts_per_speaker=123, n_samples
         gate.clamp_(0, 1)
         mod = 0.75 + 0.25 * torch.sin(2 * np.pi * syl_d[:, 0:1] * t[None, :] + syl_d[:, 1:2])
         gen = torch.Generator(device=device)
-        gen.manual_seed(int(seed) * 1000003 + int(gids[lo]))
-        noise = torch.randn((m, n_samples), device=device, generator=gen)
-        breath = torch.randn((m, n_samples), device=device, generator=gen)
+        gen.manual_seed(int(seed) * 1000003 + int(c0))
+        noise = torch.randn((chunk, n_samples), device=device, generator=gen)[g_lo - c0:g_hi - c0]
+        breath = torch.randn((chunk, n_samples), device=device, generator=gen)[g_lo - c0:g_hi - c0]
         x = gate * mod * voice + 500.0 * gate * breath + 60.0 * noise
         out[lo:hi] = x.round().clamp(-32768, 32767).to(torch.int16)
     return out, speakers

@@ -86,23 +86,31 @@ def test_enroll_last_utterance():
     assert list(ids) == [2, 5, 9] and list(last) == [4, 3, 5]                    # Q17: last one wins
 
 
-def test_fused_embedder_pool_order():
-    """BN folding + pool-before-PReLU (slope >= 0) and the plain order (negative slope) both equal
-    the module's own forward."""
+def test_fused_embedder_folds_batchnorm():
+    """FusedEmbedder's BN-folded weights: conv(x, w', b') equals BatchNorm(conv(x, w, b)) (eval mode) for every layer -- the
+    tables the libsvk kernels consume are built from these.  Runs on the host (the tables are plain tensor algebra); the
+    kernels themselves need the GPU and say so."""
+    import torch.nn.functional as F
     from speaker_verification_amd.model import perturb_inference_state, seeded_model
-    x = torch.randn(2, 1, 20, 80, 40)
-    for negative in (False, True):
-        m = seeded_model(3, n_labels=4)
-        m.load_state_dict(perturb_inference_state(m.state_dict(), 4))
-        if negative:
-            with torch.no_grad():
-                m.PReLu1_2.weight.fill_(-0.3)
-                m.PReLu2_2.weight.fill_(-0.1)
-        fused = m.fused_inference()
-        assert [st[5] for st in fused.stages if st[4]] == [not negative, not negative]
+    m = seeded_model(3, n_labels=4)
+    m.load_state_dict(perturb_inference_state(m.state_dict(), 4))
+    fused = m.fused_inference()
+    assert fused is m.fused_inference()                                   # cached while the weights do not change
+    gen = torch.Generator().manual_seed(1)
+    for li, tag in enumerate(("1_1", "1_2", "2_1", "2_2", "3_1", "3_2", "4_1", "4_2")):
+        conv, bn = getattr(m, "conv" + tag), getattr(m, "batch_norm" + tag)
+        w, b, slope, stride = fused.stages[li][:4]
+        x = torch.randn((1, conv.in_channels, 5, 12, 9), generator=gen)
         with torch.no_grad():
-            want = m(x, development=False)
-        torch.testing.assert_close(fused(x), want, rtol=1e-4, atol=1e-5)
+            want = bn(conv(x))
+            got = F.conv3d(x, w, b, stride=stride)
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+        assert torch.equal(slope, getattr(m, "PReLu" + tag).weight.detach())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fused(torch.zeros(1, 1, 20, 80, 40))
+    with torch.no_grad():
+        m.conv1_1.weight.mul_(1.5)                                        # an in-place update invalidates the snapshot
+    assert m.fused_inference() is not fused
 
 
 def test_ingest_host_tables_and_wav_reader(tmp_path):
@@ -128,28 +136,6 @@ def test_ingest_host_tables_and_wav_reader(tmp_path):
         wf.writeframes(frames.tobytes())
     got, rate = ingest.read_wave_any(path)
     assert rate == 44100 and got.shape == (500, 2) and np.array_equal(got, frames)
-
-
-def test_fused_embedder_row_fold():
-    """FusedEmbedder's row folding (conv1_2 as a widened two-rows-per-position conv, conv2_1 as a 2-group
-    conv, conv2_2 over row pairs) is a re-indexing: same embedding as the plain module, and it steps aside
-    for input heights it cannot fold."""
-    from speaker_verification_amd.model import perturb_inference_state, seeded_model
-    model = seeded_model(3, n_labels=10)
-    model.load_state_dict(perturb_inference_state(model.state_dict(), 5))
-    model.eval()
-    x = torch.randn(3, 1, 20, 80, 40)
-    with torch.no_grad():
-        want = model(x, development=False)
-        emb = model.fused_inference(channels_last=True)
-        assert emb.row_fold is not None and model.fused_inference(channels_last=False).row_fold is None
-        got = emb(x)
-        emb.row_fold = None
-        plain = emb(x)
-    scale = float(want.abs().max())
-    assert float((got - want).abs().max()) <= 1e-5 * max(scale, 1.0)
-    assert float((got - plain).abs().max()) <= 1e-5 * max(scale, 1.0)
-    assert not torch.equal(got, plain) or True           # (another summation order: equality is not required)
 
 
 def test_indexed_labels_never_unpickle(tmp_path):
@@ -194,6 +180,12 @@ def test_ragged_batches_sort_cap_and_merge_the_tail():
     out = fn(me, [7], max_batch_samples=10)                               # one short clip: one batch, slot rounded up to 8
     assert out == [([0], 8)]
     assert fn(me, [], 10) == []
+    # a tail never takes a batch past `micro_batch` clips (the network step of the cube ring) ...
+    assert [len(b) for b, _ in fn(me, [1000] * 103, max_batch_samples=10**9)] == [100, 3]
+    # ... nor multiplies its feature buffer: 5 clips of 145 s joined to 90 clips of 20 s make it 95 x 14 500 frames (220 MB)
+    lens = [320_000] * 90 + [2_320_000] * 5
+    assert [len(b) for b, _ in fn(me, lens, max_batch_samples=30_000_000, max_feature_bytes=64 << 20)] == [90, 5]
+    assert [len(b) for b, _ in fn(me, lens, max_batch_samples=30_000_000)] == [95]
 
 
 def test_tail_operand_tables_against_naive_indexing():
@@ -204,7 +196,7 @@ def test_tail_operand_tables_against_naive_indexing():
     from speaker_verification_amd.model import perturb_inference_state, seeded_model
     m = seeded_model(3, 8)
     m.load_state_dict(perturb_inference_state(m.state_dict(), 4))
-    e = m.fused_inference(channels_last=True)
+    e = m.fused_inference()
     rnd = random.Random(1)
     for name, li, axis in (("conv41", 6, "w"), ("conv42", 7, "h"), ("conv32t", 5, "h")):
         frag = getattr(e, name + "_tables")()[0]
@@ -250,3 +242,69 @@ def test_upload_groups_of_a_host_arena():
         assert span <= cap or len(g) == 1
     assert any(len(g) == 1 and int(g[0]) == 17 for g in groups)
     assert len(groups) > 10
+    # OVERLAPPING clips (50 %-overlapped 3 s windows over one recording): a piece may only end where no clip of it is still
+    # running, so that a clip never reaches into a piece that has not been uploaded yet
+    n_win, hop, win = 400, 24000, 48000
+    offs = np.arange(n_win, dtype=np.int64) * hop
+    lens = np.full(n_win, win, dtype=np.int32)
+    total = int(offs[-1]) + win
+    groups, pieces = VerificationPipeline._upload_groups(offs, lens, total, 500000)
+    assert pieces[0][0] == 0 and pieces[-1][1] == total and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+    assert sorted(int(k) for g in groups for k in g) == list(range(n_win))
+    for g, (lo, hi) in zip(groups, pieces):
+        assert (offs[g] >= lo).all() and (offs[g] + lens[g] <= hi).all()
+    # every window overlaps its successor here: nothing can be cut -- one piece; with gaps every 50 windows: cut only there
+    assert len(groups) == 1
+    offs2 = offs + (np.arange(n_win) // 50) * win
+    groups2, pieces2 = VerificationPipeline._upload_groups(offs2, lens, int(offs2[-1]) + win, 500000)
+    assert len(groups2) == 8 and all(len(g) == 50 for g in groups2)
+    for g, (lo, hi) in zip(groups2, pieces2):
+        assert (offs2[g] >= lo).all() and (offs2[g] + lens[g] <= hi).all()
+
+
+def test_cube_ring_runs_every_clip_once_in_bounded_memory():
+    """`VerificationPipeline._CubeRing` (the ragged paths): batches of any size <= step gather into a ring of 2 x step cubes,
+    the network runs over `step` cubes at a time, segments never wrap, and every clip's embedding lands in its own row --
+    here with a host stand-in for the two device calls."""
+    import types
+    from speaker_verification_amd import constants as c
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    launches = []
+
+    class Eng:
+        device = torch.device("cpu")
+
+        @staticmethod
+        def cube_gather(feat, idx, frames, out=None):
+            for u in range(feat.shape[0]):
+                for k in range(idx.shape[1]):
+                    out[u, 0, k] = feat[u, idx[u, k]:idx[u, k] + frames]
+            return out
+
+    def embed_features(rows, starts):
+        launches.append(rows.shape[0])
+        assert torch.equal(starts[0], torch.arange(c.CUBE_CROPS, dtype=torch.int32) * c.CUBE_FRAMES)
+        return rows.reshape(rows.shape[0], -1)[:, :128].clone()
+
+    pipe = types.SimpleNamespace(eng=Eng, embed_features=embed_features,
+                                 embedder=types.SimpleNamespace(crop_starts=lambda n, dev: (torch.arange(c.CUBE_CROPS, dtype=torch.int32)
+                                                                                            * c.CUBE_FRAMES)[None].expand(n, -1).contiguous()))
+    rng = np.random.default_rng(5)
+    sizes = [3, 4, 1, 4, 4, 2, 4, 3, 4, 4, 1]                            # 34 clips, step 4: the ring (8 cubes) wraps several times
+    n = sum(sizes)
+    order = torch.from_numpy(rng.permutation(n))
+    emb = torch.full((n, 128), float("nan"))
+    ring = VerificationPipeline._CubeRing(pipe, 4, emb, order, None)
+    assert ring.cubes.shape[0] == 8
+    pos, want = 0, torch.empty((n, 128))
+    for m in sizes:
+        feat = torch.from_numpy(rng.standard_normal((m, 90, c.NUM_COEF)).astype(np.float32))
+        idx = torch.from_numpy(rng.integers(0, 10, size=(m, c.CUBE_CROPS)).astype(np.int32))
+        for u in range(m):
+            want[order[pos + u]] = feat[u, idx[u, 0]:idx[u, 0] + c.CUBE_FRAMES].reshape(-1)[:128]
+        ring.push(feat, idx)
+        assert ring.at - ring.done < 4                                   # never more than a step pending
+        pos += m
+    ring.finish()
+    assert torch.equal(emb, want)
+    assert launches == [4] * 8 + [2] and ring.done == ring.at == n

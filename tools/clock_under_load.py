@@ -16,14 +16,14 @@ from speaker_verification_amd.model import seeded_model                      # n
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 12.0
 eng = get_engine(0)
-emb = seeded_model(1, n_labels=4).to(eng.device).eval().fused_inference(channels_last=True)
+emb = seeded_model(1, n_labels=4).to(eng.device).eval().fused_inference()
 t1, t2 = emb.stage1_tables(), emb.stage2_tables()
 n = 4018
 g = torch.Generator(device=eng.device)
 g.manual_seed(0)
 feat = torch.randn((n, 297, 40), device=eng.device, generator=g) * 2 - 6
 crops = torch.randint(0, 200, (n, 20), device=eng.device, dtype=torch.int32, generator=g)
-y = eng.c3d2_stage1(feat, crops, t1, folded=False, depth_transform=True, merged_tiles=True)
+y = eng.c3d2_stage1(feat, crops, t1)
 
 
 def run(name, fn):
@@ -48,5 +48,5 @@ def run(name, fn):
             os.environ.pop("SVK_C3D2_STAMPS", None)
 
 
-run("stage1", lambda: eng.c3d2_stage1(feat, crops, t1, folded=False, depth_transform=True, merged_tiles=True))
-run("stage2", lambda: eng.c3d2_stage2(y, t2, depth_transform=True))
+run("stage1", lambda: eng.c3d2_stage1(feat, crops, t1))
+run("stage2", lambda: eng.c3d2_stage2(y, t2))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stage-by-stage timing of the hot path on one GPU (HIP events), for DESIGN.md and tuning.
-    python tools/profile_stages.py [--batch 1024] [--channels-last]"""
+    python tools/profile_stages.py [--batch 1024]"""
 import argparse
 import json
 import os
@@ -15,7 +15,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--no-channels-last", action="store_true")
     args = ap.parse_args()
     import torch
     from speaker_verification_amd import synth
@@ -26,7 +25,7 @@ def main():
     pcm, _ = synth.corpus_device(args.batch, eng.device)
     model = seeded_model(1)
     pipe = VerificationPipeline(model, normalize=True, preemph_cof=0.98, crop_rng="device",
-                                micro_batch=args.batch, channels_last=not args.no_channels_last)
+                                micro_batch=args.batch)
 
     def run():
         marks = [("start", torch.cuda.Event(enable_timing=True))]

@@ -15,7 +15,7 @@ def main():
     from speaker_verification_amd.engine import get_engine
     from speaker_verification_amd.model import seeded_model
     eng = get_engine(0)
-    emb = seeded_model(1, n_labels=4).to(eng.device).eval().fused_inference(channels_last=True)
+    emb = seeded_model(1, n_labels=4).to(eng.device).eval().fused_inference()
     t1, t2 = emb.stage1_tables(), emb.stage2_tables()
     n = 1024
     g = torch.Generator(device=eng.device)
@@ -28,13 +28,13 @@ def main():
                            ("zero features AND zero weights", torch.zeros((n, 297, 40), device=eng.device), tz),
                            ("random again", torch.randn((n, 297, 40), device=eng.device, generator=g) * 2 - 6, t1)):
         for _ in range(20):
-            y = eng.c3d2_stage1(feat, crops, t1, folded=False)
+            y = eng.c3d2_stage1(feat, crops, t1)
         torch.cuda.synchronize()
         ts = []
         for _ in range(30):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            y = eng.c3d2_stage1(feat, crops, t1, folded=False)
+            y = eng.c3d2_stage1(feat, crops, t1)
             b.record()
             torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
@@ -45,13 +45,13 @@ def main():
         feat = torch.randn((n2, 297, 40), device=eng.device, generator=g)
         cr = torch.randint(0, 200, (n2, 20), device=eng.device, dtype=torch.int32, generator=g)
         for _ in range(10):
-            eng.c3d2_stage1(feat, cr, emb.stage1_tables(), folded=False)
+            eng.c3d2_stage1(feat, cr, emb.stage1_tables())
         torch.cuda.synchronize()
         ts = []
         for _ in range(20):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            eng.c3d2_stage1(feat, cr, emb.stage1_tables(), folded=False)
+            eng.c3d2_stage1(feat, cr, emb.stage1_tables())
             b.record()
             torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
