@@ -93,6 +93,8 @@ def parse(argv=None):
     ap.add_argument("--checkpoint", default=os.path.join(REPO, "speaker_verification_amd", "checkpoints", "c3d2_synth.pt"),
                     help="{'state_dict': ...} of a C3D2 (reference format, model.py:177-186); loaded weights-only")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel side benches (profiling runs)")
+    ap.add_argument("--parity-only", action="store_true",
+                    help="of the extras, only the CPU-oracle leg: cpu_baseline + parity (EER on both sides) on --cpu-sample clips")
     ap.add_argument("--frontend-only", action="store_true", help="time BASELINE config 2 only (for rocprof)")
     ap.add_argument("--stages-only", action="store_true", help="time the stage-level kernels only (for rocprof)")
     ap.add_argument("--ragged-only", action="store_true", help="the realistic-length workload only (4 .. 145 s clips)")
@@ -1092,7 +1094,7 @@ def main():
                             + ".  Host sklearn path = svk_roc_eer = CPU oracle on the same scores; GPU = CPU EER from PCM on the parity sample"},
         }
 
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not args.parity_only:
         # host-fed variant (PCIe included; NOT `value`): 8 micro-batches of the shard from pageable host memory (the
         # first batch's H2D copy is not overlapped)
         n_host = min(n_local, 8 * (spans[0][1] - spans[0][0]))
@@ -1129,6 +1131,7 @@ def main():
         mb = result["micro_batch_breakdown"]["stages"]
         result["ragged"]["fixed_3s_front_end_share_for_comparison"] = float(
             sum(v["share"] for k, v in mb.items() if not k.startswith(("cube", "cosine"))))
+    if rank == 0 and world == 1 and (not args.no_extras or args.parity_only):
         if args.cpu_sample > 0:
             # sample: whole speakers from the start of the corpus (the last utterance of each enrols, Q17)
             ns = min(args.cpu_sample, n_local)
@@ -1152,6 +1155,13 @@ def main():
             if lab.shape[1] > 1:
                 par["eer_gpu"] = float(evaluation.get_eer_auc(lab.flatten(), s_gpu.flatten())[0])
                 par["eer_cpu_ref"] = float(scoring_ref.get_eer_auc(lab.flatten(), s_ref.flatten())[0])
+                par["eer_equal"] = par["eer_gpu"] == par["eer_cpu_ref"]
+                # how far the two sides' scores are from reordering a pair: the smallest gap between a target score and a
+                # non-target score of the CPU side, against the largest GPU - CPU score difference
+                tgt, non = np.sort(s_ref[lab > 0]), np.sort(s_ref[lab == 0])
+                near = np.abs(non[np.clip(np.searchsorted(non, tgt), 0, non.size - 1)] - tgt)
+                near = np.minimum(near, np.abs(non[np.clip(np.searchsorted(non, tgt) - 1, 0, non.size - 1)] - tgt))
+                par["min_target_nontarget_gap"] = float(near.min())
             # full-size check: oracle cosine + EER on the SAME embeddings must give the same EER
             fe = full[:n_test].cpu().numpy()
             s_or = scoring_ref.cosine_matrix(fe, fe[last]).astype(np.float64)

@@ -18,6 +18,6 @@ def pytest_configure(config):
 def golden():
     """name -> NpzFile of the committed reference outputs (tools/make_golden.py)."""
     out = {}
-    for name in ("speechpy", "vad", "c3d2_embed", "scoring", "round2"):
+    for name in ("speechpy", "vad", "c3d2_embed", "scoring", "round2", "round4"):
         out[name] = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return out

@@ -52,6 +52,44 @@ def test_two_rank_all_gather(tmp_path, n_items):
     assert b0[0] == 0 and b0[1] == b1[0] and b1[1] == n_items
 
 
+def _fake_embed4(rows):
+    rows = torch.as_tensor(rows, dtype=torch.float32)
+    return torch.stack([rows, torch.sin(rows), rows * 0.5 + 1.0, torch.cos(rows * 3.0)], dim=1)
+
+
+def _worker8(rank, world, port, n_items, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seen = []
+
+        def embed(items):
+            seen.append((int(items[0]), int(items[-1]) + 1) if len(items) else (0, 0))
+            return _fake_embed4(items)
+        full = svdist.sharded_embed(embed, torch.arange(n_items))
+        want = _fake_embed4(torch.arange(n_items))
+        ok = full.shape == want.shape and bool(torch.equal(full, want))
+        np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.array([int(ok), seen[0][0], seen[0][1], full.shape[0]]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_at_the_corpus_size(tmp_path):
+    """BASELINE config 5's exchange in full size on CPU: 148 642 items over EIGHT gloo ranks (shards of 18 581 x 7 + 18 575:
+    uneven, the last one zero-padded for the gather), 4-float rows: the gathered matrix equals the single-process one on
+    every rank, and every rank embedded exactly its contiguous range."""
+    n_items, world = 148642, 8
+    port = _free_port()
+    mp.spawn(_worker8, args=(world, port, n_items, str(tmp_path)), nprocs=world, join=True)
+    at = 0
+    for r in range(world):
+        ok, lo, hi, rows = (int(v) for v in np.load(tmp_path / f"ok{r}.npy"))
+        assert ok == 1 and rows == n_items, r
+        assert (lo, hi) == svdist.shard_bounds(n_items, world, r) and lo == at
+        at = hi
+    assert at == n_items and svdist.shard_bounds(n_items, world, 7) == (130067, 148642)
+
+
 def test_single_process_passthrough():
     x = _fake_embed(torch.arange(5))
     assert torch.equal(svdist.all_gather_embeddings(x, 5), x)

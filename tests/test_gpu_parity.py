@@ -1467,6 +1467,36 @@ def test_c3d2_embedding_on_gpu(eng, golden):
     torch.testing.assert_close(probs, want, rtol=1e-6, atol=1e-7)
 
 
+def test_trained_checkpoint_embeddings_against_the_reference(eng, golden):
+    """The committed trained checkpoint: PCM -> pre-emphasis -> log-mel -> CMVN -> cube -> C3D2 on the GPU against what the
+    REFERENCE's own speechpy + FeatureCube + load_checkpoint + forward produced for the same clips and crops
+    (tests/golden/round4.npz), through the production route (no cube in HBM), through `model(cube)` the way
+    evaluation.py:113-121 calls it, and the cosines evaluation.py:77 computes from them."""
+    from speaker_verification_amd.model import C3D2
+    from speaker_verification_amd.pipeline import VerificationPipeline
+    g = golden["round4"]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = torch.load(os.path.join(repo, "speaker_verification_amd", "checkpoints", "c3d2_synth.pt"), map_location="cpu",
+                    weights_only=True)
+    model = C3D2(100, 1).load_checkpoint(ck)                              # the reference's loading call (model.py:177-186)
+    assert next(model.parameters()).is_cuda
+    pcm = np.stack([synth.speaker_clip(int(s), int(u)) for s, u in g["clip_ids"]])
+    pipe = VerificationPipeline(model, use_vad=False, normalize=True, preemph_cof=0.98, micro_batch=3)
+    scale = float(np.abs(g["embed"]).max())
+    emb = pipe.embed(pcm, crop_idx=g["crop_idx"])
+    print("trained checkpoint, PCM -> embedding vs the reference: max |diff| / scale %.2e"
+          % (np.abs(emb.cpu().numpy() - g["embed"]).max() / scale))
+    np.testing.assert_allclose(emb.cpu().numpy(), g["embed"], rtol=0, atol=5e-5 * scale)
+    _, inter = pipe.embed(pcm, crop_idx=g["crop_idx"], return_intermediates=True)
+    cubes = torch.cat([d["cube"] for d in inter])
+    np.testing.assert_allclose([float(c_.abs().sum()) for c_ in cubes], g["cube_abssum"], rtol=1e-5)
+    via_model = model(cubes, development=False)
+    np.testing.assert_allclose(via_model.cpu().numpy(), g["embed"], rtol=0, atol=5e-5 * scale)
+    np.testing.assert_allclose(model(cubes).cpu().numpy()[:, :8], g["softmax_top"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(model.create_Speaker_Model(cubes[3:4]).cpu().numpy(), g["speaker_model"], rtol=0, atol=5e-5 * scale)
+    np.testing.assert_allclose(pipe.score(emb, emb).cpu().numpy(), g["cosine"], rtol=0, atol=1e-5)
+
+
 def test_reference_call_surface_runs_the_libsvk_network(eng):
     """Which code runs a forward (model.C3D2.forward): the libsvk kernels for inference calls on the device, the torch
     layers wherever autograd or another input layout needs them; and the inference snapshot follows the weights."""
@@ -1823,6 +1853,25 @@ def test_bench_four_ranks_uneven_shards_on_one_gpu():
     assert four["eer"]["eer"] == one["eer"]["eer"] and four["eer"]["auc"] == one["eer"]["auc"]
     assert four["eer"]["short_clips"] == one["eer"]["short_clips"]
     assert four["value"] == pytest.approx(20003 / (four["ms_per_step"] * 1e-3), rel=1e-6)
+
+
+def test_bench_parity_leg_at_the_trained_operating_point():
+    """bench.py's CPU-oracle leg (cpu_baseline + parity) on the first 492 clips (four speakers) of a 5 001-clip corpus with
+    the committed trained checkpoint: the production path's embeddings against the oracle's from the same PCM, and the EER
+    on both sides -- equal, at an operating point where the ROC is steep (not the diagonal of a random-init network)."""
+    rec = _bench_line(["--corpus", "5001", "--micro-batch", "1024", "--steps", "1", "--warmup", "0", "--parity-only",
+                       "--cpu-sample", "492"], timeout=1200)
+    par, base = rec["parity"], rec["cpu_baseline"]
+    assert par["sample_clips"] == 492 and par["embed_max_abs_diff"] <= 5e-5 * par["embed_scale"]
+    assert par["score_max_abs_diff"] <= 2e-5
+    assert par["eer_equal"] and par["eer_gpu"] == par["eer_cpu_ref"] and par["eer_gpu"] < 0.2
+    assert par["full_matrix_score_max_abs_diff"] <= 1e-5 and rec["eer"]["eer"] == pytest.approx(par["full_matrix_eer_cpu_ref"], abs=1e-9)
+    assert rec["eer"]["eer"] < 0.1
+    # the baseline's harness: chain and pair-by-pair scoring timed separately, every worker warmed before the clock starts
+    assert base["kind"] == "port" and base["unit"] == "utterances/s" and base["value"] > 0 and base["cores"] >= 1
+    for row in base["chain_by_workers"].values():
+        assert row["chain_utt_per_s"] >= row["utt_per_s"] > 0 and row["scoring_s"] >= 0 and row["warm_s"] > 0
+    assert "host_fed" not in rec and "ragged" not in rec                    # --parity-only: none of the side benches
 
 
 def test_network_block_error_paths(eng):

@@ -309,3 +309,34 @@ def test_file_driven_enrol_and_evaluate(golden, tmp_path):
     assert acc == pytest.approx(float(g["eval_accuracy_pct"][0]))
     assert eer * 100 == pytest.approx(float(g["eval_eer_pct"][0]), abs=1e-6)
     assert auc * 100 == pytest.approx(float(g["eval_auc_pct"][0]), abs=1e-6)
+
+
+def test_trained_checkpoint_through_the_reference(golden):
+    """tests/golden/round4.npz: the committed trained checkpoint through the REFERENCE's load_checkpoint + forward on four
+    synthetic clips (reference speechpy chain, reference FeatureCube).  The oracle's chain on the same clips, crops and
+    weights reproduces it; the file on disk is the one the fixture was made from."""
+    import hashlib
+    import os
+    from oracle import speechpy_ref
+    g = golden["round4"]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(repo, "speaker_verification_amd", "checkpoints", "c3d2_synth.pt")
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == str(g["checkpoint_sha256"][0])
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"state_dict", "meta"} and ck["state_dict"]["FC6.weight"].shape == (100, 128)
+    state = ck["state_dict"]
+    embs = []
+    for k, (spk, utt) in enumerate(g["clip_ids"]):
+        sig = synth.speaker_clip(int(spk), int(utt)) / 32768.0
+        feat = speechpy_ref.lmfe(speechpy_ref.preemphasis(sig, cof=0.98), 16000, 0.025, 0.01, 40, 1024)
+        feat = speechpy_ref.cmvn(feat, variance_normalization=True)
+        assert feat.shape[0] == int(g["feat_frames_sum_abssum"][k, 0])
+        np.testing.assert_allclose([feat.sum(), np.abs(feat).sum()], g["feat_frames_sum_abssum"][k, 1:], rtol=1e-9, atol=1e-6)
+        cube = model_ref.feature_cube(feat, g["crop_idx"][k])
+        assert float(np.abs(cube).sum()) == pytest.approx(float(g["cube_abssum"][k]), rel=1e-6)
+        embs.append(model_ref.c3d2_embed(state, cube[None]).numpy()[0])
+    embs = np.stack(embs)
+    scale = np.abs(g["embed"]).max()
+    np.testing.assert_allclose(embs, g["embed"], rtol=0, atol=1e-6 * scale)
+    np.testing.assert_allclose(scoring_ref.cosine_matrix(embs, embs), g["cosine"], rtol=0, atol=1e-6)
+    assert g["cosine"][0, 1] > 0.8 and g["cosine"][2, 3] > 0.8 and abs(g["cosine"][0, 2]) < 0.5    # a trained embedding

@@ -486,6 +486,54 @@ def round2_fixture(ref_vad, ref_eval, ref_model, ref_utils):
     print("round2.npz", sum(v.nbytes for v in g.values()) // 1024, "KiB raw")
 
 
+def round4_fixture(ref_model, ref_utils):
+    """The committed TRAINED checkpoint (speaker_verification_amd/checkpoints/c3d2_synth.pt, written by this build's
+    tools/train_synth_checkpoint.py; loaded weights-only) through the REFERENCE's own `C3D2(100, 1).load_checkpoint(...)`
+    (model.py:177-186) and forward, on four synthetic clips run through the reference's speechpy chain as the checkpoint
+    was trained: preemphasis(x / 32768, cof=0.98) -> lmfe(16000, 0.025, 0.01, 40, 1024) -> cmvn(variance) ->
+    utils.FeatureCube((80, 40, 20)) under a seeded global NumPy RNG."""
+    import hashlib
+    g = {"versions": versions()}
+    path = os.path.join(REPO, "speaker_verification_amd", "checkpoints", "c3d2_synth.pt")
+    g["checkpoint_sha256"] = np.array([hashlib.sha256(open(path, "rb").read()).hexdigest()])
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    sink = io.StringIO()
+    real_stdout, sys.stdout = sys.stdout, sink                      # C3D2.__init__ prints
+    try:
+        net = ref_model.C3D2(100, 1).load_checkpoint(ck)
+    finally:
+        sys.stdout = real_stdout
+    net.eval()
+    clips = [(3, 0), (3, 1), (4, 0), (4, 1)]                         # (synth speaker, utterance): synth.speaker_clip
+    g["clip_ids"] = np.array(clips)
+    g["np_seed"] = np.array([4242])
+    np.random.seed(4242)
+    cubes, idxs, sums = [], [], []
+    for spk, utt in clips:
+        sig = synth.speaker_clip(spk, utt) / 32768.0
+        feat = rf.lmfe(rp.preemphasis(sig, cof=0.98), sampling_frequency=16000, frame_length=0.025, frame_stride=0.01,
+                       num_filters=40, fft_length=1024)
+        feat = rp.cmvn(feat, variance_normalization=True)
+        state = np.random.get_state()
+        idxs.append(np.random.randint(feat.shape[0] - 80, size=20))   # the draw FeatureCube is about to make (utils.py:372)
+        np.random.set_state(state)
+        cubes.append(ref_utils.FeatureCube((80, 40, 20))({"feature": feat, "label": 0})["feature"])
+        sums.append([feat.shape[0], float(feat.sum()), float(np.abs(feat).sum())])
+    cubes = np.stack(cubes)                                          # (4, 1, 20, 80, 40) float32
+    g["crop_idx"] = np.stack(idxs).astype(np.int32)
+    g["feat_frames_sum_abssum"] = np.array(sums)
+    g["cube_abssum"] = np.array([float(np.abs(cubes[k]).sum()) for k in range(4)])
+    with torch.no_grad():
+        g["embed"] = net(torch.from_numpy(cubes), development=False).numpy()
+        g["softmax_top"] = net(torch.from_numpy(cubes), development=True).numpy()[:, :8]
+        g["speaker_model"] = net.create_Speaker_Model(torch.from_numpy(cubes[3:4])).numpy()
+    from sklearn.metrics.pairwise import cosine_similarity            # what evaluation.py:77 calls
+    g["cosine"] = cosine_similarity(g["embed"], g["embed"])
+    np.savez_compressed(os.path.join(OUT, "round4.npz"), **g)
+    print("round4.npz", sum(v.nbytes for v in g.values()) // 1024, "KiB raw; same / different speaker cosine:",
+          float(g["cosine"][0, 1]), float(g["cosine"][0, 2]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]                      # e.g. `python tools/make_golden.py round2`
@@ -500,6 +548,8 @@ def main():
         scoring_fixture(ref_eval, ref_siamese)
     if not only or "round2" in only:
         round2_fixture(ref_vad, ref_eval, ref_model, ref_utils)
+    if not only or "round4" in only:
+        round4_fixture(ref_model, ref_utils)
 
 
 if __name__ == "__main__":

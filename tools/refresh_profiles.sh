@@ -11,6 +11,9 @@ rp() { timeout -k 10 240 rocprofv3 "$@" || echo "profiler pass failed or timed o
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+# what every file of this pass was measured with: sha256 over the kernel sources and of the built library (bench.py marks a
+# roofline row `stale` when the committed counters come from other sources than the ones it runs)
+python3 -c "import sys, json; sys.path.insert(0, '$root'); from speaker_verification_amd import _lib; print(json.dumps(_lib.provenance()))" > $out/prof_provenance.json
 echo "[1/6] kernel trace + stats of the end-to-end bench"
 rp --kernel-trace --stats --output-format csv -d $out/prof_bench -- python3 $root/bench.py --steps 3 --warmup 1 --no-extras > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
 echo "[2/6] HBM read / write counters"

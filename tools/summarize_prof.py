@@ -18,10 +18,11 @@ import sys
 from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OURS = ("frontend_kernel", "cmvn_kernel", "vad_kernel", "cube_gather_kernel", "cosine_kernel", "cosine_tiled_kernel",
-        "inv_norm_kernel", "draw_crops_kernel", "cube_windows_kernel", "cube_windows_c3d2_kernel", "decimate_kernel", "resample_kernel",
-        "c3d2_stage1t_kernel", "c3d2_stage1w_kernel", "c3d2_stage1_kernel", "c3d2_conv21w_kernel", "c3d2_conv22w_kernel", "c3d2_conv31w_kernel", "c3d2_conv32w_kernel", "c3d2_conv21_kernel",
-        "c3d2_conv22_kernel", "bias_prelu_kernel", "cmvnw_kernel", "spectrum_pow2_kernel",
+OURS = ("frontend_kernel", "cmvn_kernel", "vad_kernel", "vad_small_kernel", "vad_flags_kernel", "vad_walk_kernel", "vad_copy_kernel",
+        "cube_gather_kernel", "cosine_kernel", "cosine_tiled_kernel",
+        "inv_norm_kernel", "draw_crops_kernel", "decimate_kernel", "resample_kernel",
+        "c3d2_stage1w_kernel", "c3d2_conv21w_kernel", "c3d2_conv22w_kernel", "c3d2_conv31w_kernel",
+        "cmvnw_kernel", "spectrum_pow2_kernel",
         "spectrum_dft_kernel", "spectrum_fft_kernel", "mel_features_kernel", "c3d2_tail_kernel", "fc5_reduce_kernel", "fc5_kernel")
 
 
@@ -29,8 +30,6 @@ def short(name):
     for k in OURS:
         if k in name:
             extra = ""
-            if k == "c3d2_stage1w_kernel" and ("<true, true>" in name or "<false, true>" in name):
-                extra = "<merged>"
             if k == "c3d2_tail_kernel":
                 extra = "<Conv41>" if "Conv41" in name else "<Conv42>" if "Conv42" in name else "<Conv32T>"
             if "frontend_kernel" in name:
@@ -89,6 +88,23 @@ def main():
             rec["lds_conflict_fraction"] = rec["SQ_LDS_BANK_CONFLICT"] / rec["SQ_LDS_IDX_ACTIVE"]
         result[k] = rec
     if result:
+        # what the counters were collected from (written on the GPU box by tools/refresh_profiles.sh) + the commit this summary
+        # is made at: bench.py compares csrc_sha with the sources it runs and marks its roofline rows `stale` when they differ
+        prov = {}
+        ppath = os.path.join(REPO, "gpurun_out", "prof_provenance.json")
+        if os.path.exists(ppath):
+            prov = json.load(open(ppath))
+        import subprocess as sp
+        try:
+            prov["git_head"] = sp.run(["git", "-C", REPO, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+            prov["git_dirty_csrc"] = bool(sp.run(["git", "-C", REPO, "status", "--porcelain", "--", "speaker_verification_amd/csrc", "include"],
+                                                 capture_output=True, text=True).stdout.strip())
+        except OSError:
+            pass
+        sys.path.insert(0, REPO)
+        from speaker_verification_amd import _lib
+        prov["csrc_sha_at_summary"] = _lib.provenance()["csrc_sha"]
+        result["_provenance"] = prov
         result["_note"] = ("per-launch averages from separate rocprofv3 --pmc passes over `bench.py --frontend-only` "
                            "(1024 x 3 s clips per launch) and, for the c3d2_* kernels, `bench.py --c3d2-only` (1024 cubes "
                            "per launch); FETCH_SIZE/WRITE_SIZE in KiB, read side doubled per the gfx950 correction")
