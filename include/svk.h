@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 106 /* 0.1.5: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone) */
+#define SVK_VERSION 107 /* 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -128,6 +128,12 @@ int svk_spectrum(svk_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t 
  * (NULL = max_frames) are normalised in place; variance != 0 divides by (std + 2^-30). */
 int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
              const int32_t* d_n_frames, int32_t variance);
+/* The same statistics WITHOUT applying them: d_stats float64 [n_utt][2][n_cols], [u][0][c] = mean, [u][1][c] =
+ * 1 / (std + 2^-30) (1 when variance == 0) over rows < n_frames[u]; clips with no rows are left untouched.  utils.py:382-397
+ * (CMVN) feeds utils.py:351-379 (FeatureCube), which reads 20 x 80 rows of a clip: svk_cube_gather_cmvn below applies the
+ * normalisation to just those rows on the way, instead of a pass over every row of a 145 s clip. */
+int svk_cmvn_stats(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                   const int32_t* d_n_frames, int32_t variance, double* d_stats);
 
 /* feature.py:202-217 and :146-153 on a power spectrum that is already on the device -- the general
  * (any fft_length, up to 1024 filters) counterpart of the fused front end, one workgroup per frame:
@@ -176,6 +182,12 @@ int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t* d_offsets,
  * d_out float32 [n_utt][1][n_crops][crop_frames][n_cols] (a torch tensor's data_ptr()). */
 int svk_cube_gather(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, float* d_out);
+/* utils.py:382-397 + :351-379 in one pass: the cube of svk_cmvn-normalised features from the RAW features and svk_cmvn_stats'
+ * d_stats: out = (float)(((double)feat - mean[c]) * inv[c]), the expression svk_cmvn applies (bit-identical to svk_cmvn followed
+ * by svk_cube_gather); too-short clips (crop -1) give zero cubes as there. */
+int svk_cube_gather_cmvn(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                         const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const double* d_stats,
+                         float* d_out);
 
 /* Crop starts drawn ON THE DEVICE (no host round trip for the per-clip frame count):
  * crop[u][c] = floor(uniform(seed, u, c) * (n_frames[u] - crop_frames)), a counter-based

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsvk.so")
 
 SVK_OK = 0
-VERSION = 106                      # include/svk.h SVK_VERSION
+VERSION = 107                      # include/svk.h SVK_VERSION
 SVK_ERR_BAD_ARG, SVK_ERR_UNSUPPORTED, SVK_ERR_HIP, SVK_ERR_NO_DEVICE, SVK_ERR_OOM, SVK_ERR_RCCL = -1, -2, -3, -4, -5, -6
 OUT_MFE, OUT_LMFE, OUT_MFCC = 0, 1, 2
 PCM_I16, PCM_F32 = 0, 1
@@ -62,6 +62,7 @@ SIGNATURES = {
     "svk_stack_frames": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "svk_spectrum": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "svk_cmvn": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32]),
+    "svk_cmvn_stats": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "svk_mel_features": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "svk_cmvnw": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "svk_derivative": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
@@ -70,6 +71,7 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _vp]),
     "svk_cube_draw_crops": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _i32, _i32, C.c_uint64, _vp, _vp]),
     "svk_cube_gather": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "svk_cube_gather_cmvn": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "svk_cosine_scores": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "svk_roc_workspace_bytes": (C.c_size_t, [_i64]),
     "svk_roc_eer": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_size_t, C.POINTER(C.c_double)]),

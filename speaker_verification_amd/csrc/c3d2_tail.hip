@@ -46,11 +46,11 @@ __device__ __forceinline__ float prelu_t(float v, float slope) {
 }
 
 constexpr int GROUP = 16;   // cubes per work item = rows of an M tile
-constexpr int NT = 9;       // M tiles (output positions) per work item
 
 // conv4_1: input [n][8 d][8 chunks][45 = 9 h x 5 w][8] (svk_c3d2_conv32 with the chunked-output flag), output
 // [n][6 d][16 chunks][27 = 9 h x 3 w][8].  Item = (group, pair P of 3, row block rb of 3): rows 3 rb .. 3 rb + 2, taps along w.
 struct Conv41 {
+  static constexpr int NT = 9;                         // M tiles (output positions) per work item
   static constexpr int TAPS = 3, TAP_PIX = 1;          // a tap moves one pixel (w)
   static constexpr int D_IN = 8, NCHUNK = 8, PIX_IN = 45, PIXN = 15;   // PIXN: staged pixels per plane (3 rows x 5)
   static constexpr int D_OUT = 6, PIX_OUT = 27;
@@ -63,6 +63,7 @@ struct Conv41 {
 };
 // conv4_2: input = conv4_1's output, output [n][4 d][16 chunks][9 = 3 h x 3 w][8].  Item = (group, pair P of 2), taps along h.
 struct Conv42 {
+  static constexpr int NT = 9;
   static constexpr int TAPS = 7, TAP_PIX = 3;          // a tap moves one row = 3 pixels
   static constexpr int D_IN = 6, NCHUNK = 16, PIX_IN = 27, PIXN = 27;
   static constexpr int D_OUT = 4, PIX_OUT = 9;
@@ -80,6 +81,7 @@ struct Conv42 {
 // (c3d2_conv32w_kernel: transform per fragment read, 45 positions padded to 48, 41 % LDS bank conflicts): no VALU in the
 // loop, no padding.
 struct Conv32T {
+  static constexpr int NT = 9;
   static constexpr int TAPS = 7, TAP_PIX = 1;
   static constexpr int D_IN = 10, NCHUNK = 8, PIX_IN = 75, PIXN = 15;
   static constexpr int D_OUT = 8, PIX_OUT = 45;
@@ -134,6 +136,7 @@ template <class L, bool SLOPE01>
 __global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const TailParams p) {
   using G = TailGeom<L>;
   constexpr int TAIL_THREADS = G::THREADS;
+  constexpr int NT = L::NT;
   extern __shared__ __attribute__((aligned(16))) float smem_tail[];
   __shared__ int q_next;
   const int lane = threadIdx.x & 63, nt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -328,6 +331,7 @@ int launch_tail(svk_ctx* ctx, const char* name, const float* d_in, int32_t n_utt
   using G = TailGeom<L>;
   if (!ctx) return SVK_ERR_BAD_ARG;
   SVK_REQUIRE(ctx, n_utt >= 0, "n_utt negative");
+  SVK_REQUIRE(ctx, (flags & ~2) == 0, "flags: only bit 1 (slopes in [0, 1]) is defined");
   if (n_utt == 0) return SVK_OK;
   SVK_REQUIRE(ctx, d_in && d_wfrag && d_bias && d_slope && d_out, "NULL buffer");
   SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_wfrag)) & 15) == 0,
@@ -375,8 +379,8 @@ int launch_tail(svk_ctx* ctx, const char* name, const float* d_in, int32_t n_utt
         const unsigned long long* e = &h[((size_t)b * L::NWAVES + w) * 4];
         s0 += (double)e[0]; s1 += (double)e[1]; s2 += (double)e[2]; n += (double)e[3];
       }
-      fprintf(stderr, "%s stamps wave %d (cycles per item; %d phases of %d steps x 18 MFMAs = %d MFMA cycles per wave): phases %.0f  barriers %.0f  epilogue %.0f\n",
-              name, w, G::NPH, G::STEPS, G::NPH * G::STEPS * 18 * 32, s0 / n, s1 / n, s2 / n);
+      fprintf(stderr, "%s stamps wave %d (cycles per item; %d phases of %d steps x %d MFMAs = %d MFMA cycles per wave): phases %.0f  barriers %.0f  epilogue %.0f\n",
+              name, w, G::NPH, G::STEPS, 2 * L::NT, G::NPH * G::STEPS * 2 * L::NT * 32, s0 / n, s1 / n, s2 / n);
     }
   }
 #endif

@@ -251,8 +251,12 @@ __global__ __launch_bounds__(256) void twiddle_table_kernel(cplx* __restrict__ t
 
 // ---- CMVN: one workgroup per clip ------------------------------------------------------
 // Threads form a [R rows][cb cols] grid over a column block; column sums are kept in float64.
+// APPLY = false: the clip's statistics only, stats[utt][0][c] = mean, stats[utt][1][c] = 1 / (std + 2^-30) (svk_cmvn_stats:
+// the normalisation is then applied where the rows are next read, svk_cube_gather_cmvn).
+template <bool APPLY>
 __global__ __launch_bounds__(256) void cmvn_kernel(float* __restrict__ feat, int max_frames, int ncols,
-                                                   const int32_t* __restrict__ n_frames, int variance) {
+                                                   const int32_t* __restrict__ n_frames, int variance,
+                                                   double* __restrict__ stats) {
   __shared__ double red[256];
   const int utt = blockIdx.x;
   int T = n_frames ? n_frames[utt] : max_frames;
@@ -264,11 +268,16 @@ __global__ __launch_bounds__(256) void cmvn_kernel(float* __restrict__ feat, int
     const int R = 256 / cb;               // row groups
     const int tc = threadIdx.x % cb, tr = threadIdx.x / cb;
     const bool active = tr < R;
-    // pass 1: mean
-    double s = 0.0;
+    // ONE pass: column sums and sums of squares in float64 (the long-clip path's formula: var = E[x^2] - mean^2; for log-mel /
+    // cepstral magnitudes the cancellation costs ~1e-14 relative in float64, far below the float32 the result is stored in)
+    double s1 = 0.0, s2 = 0.0;
     if (active)
-      for (int t = tr; t < T; t += R) s += (double)base[(int64_t)t * ncols + c0 + tc];
-    red[threadIdx.x] = active ? s : 0.0;
+      for (int t = tr; t < T; t += R) {
+        const double v = (double)base[(int64_t)t * ncols + c0 + tc];
+        s1 += v;
+        s2 += v * v;
+      }
+    red[threadIdx.x] = active ? s1 : 0.0;
     __syncthreads();
     double mean = 0.0;
     if (active) {
@@ -276,29 +285,29 @@ __global__ __launch_bounds__(256) void cmvn_kernel(float* __restrict__ feat, int
       mean /= (double)T;
     }
     __syncthreads();
-    // pass 2: population std of the centred values (processing.py:264)
     double inv = 1.0;
     if (variance) {
-      double q = 0.0;
-      if (active)
-        for (int t = tr; t < T; t += R) {
-          const double d = (double)base[(int64_t)t * ncols + c0 + tc] - mean;
-          q += d * d;
-        }
-      red[threadIdx.x] = active ? q : 0.0;
+      red[threadIdx.x] = active ? s2 : 0.0;
       __syncthreads();
       if (active) {
-        double var = 0.0;
-        for (int r = 0; r < R; ++r) var += red[r * cb + tc];
-        inv = 1.0 / (sqrt(var / (double)T) + 9.313225746154785e-10);  // + 2^-30, processing.py:250,266
+        double q = 0.0;
+        for (int r = 0; r < R; ++r) q += red[r * cb + tc];
+        double var = q / (double)T - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        inv = 1.0 / (sqrt(var) + 9.313225746154785e-10);  // + 2^-30, processing.py:250,266
       }
       __syncthreads();
     }
-    if (active)
-      for (int t = tr; t < T; t += R) {
-        const int64_t o = (int64_t)t * ncols + c0 + tc;
-        base[o] = (float)(((double)base[o] - mean) * inv);
-      }
+    if (APPLY) {
+      if (active)
+        for (int t = tr; t < T; t += R) {
+          const int64_t o = (int64_t)t * ncols + c0 + tc;
+          base[o] = (float)(((double)base[o] - mean) * inv);
+        }
+    } else if (active && tr == 0) {
+      stats[((int64_t)utt * 2) * ncols + c0 + tc] = mean;
+      stats[((int64_t)utt * 2 + 1) * ncols + c0 + tc] = inv;
+    }
     __syncthreads();
   }
 }
@@ -818,7 +827,10 @@ __global__ __launch_bounds__(256) void sub_max_kernel(float* __restrict__ p, int
 // ---- feature cube: each crop is one contiguous run of crop_frames * ncols floats ---------------
 __global__ __launch_bounds__(256) void cube_gather_kernel(const float* __restrict__ feat, int max_frames, int ncols,
                                                           const int32_t* __restrict__ crop, int n_crops,
-                                                          int crop_frames, int64_t n_jobs, float* __restrict__ out) {
+                                                          int crop_frames, int64_t n_jobs, const double* __restrict__ stats,
+                                                          float* __restrict__ out) {
+  // stats (svk_cube_gather_cmvn): [utt][2][ncols] mean and 1 / (std + 2^-30) of svk_cmvn_stats, applied to every copied value
+  // with cmvn_kernel's own expression -- the cube of normalised features without the pass that normalises ALL rows in place
   const int run = crop_frames * ncols;
   for (int64_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
     const int64_t utt = job / n_crops;
@@ -830,7 +842,26 @@ __global__ __launch_bounds__(256) void cube_gather_kernel(const float* __restric
     const int avail = (max_frames - start) * ncols;  // never read past the clip's rows
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 &&
                      (run & 3) == 0 && avail >= run;
-    if (vec) {
+    if (stats && !none) {
+      const double* st = stats + utt * 2 * ncols;
+      if (vec && (ncols & 3) == 0) {
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+        f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+        for (int i = threadIdx.x; i < run / 4; i += blockDim.x) {
+          const int c = (4 * i) % ncols;     // a 16-byte piece stays inside one row: ncols is a multiple of 4
+          const f32x4 v = s4[i];
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (float)(((double)v[e] - st[c + e]) * st[ncols + c + e]);
+          d4[i] = o;
+        }
+      } else {
+        for (int i = threadIdx.x; i < run; i += blockDim.x) {
+          const int c = i % ncols;
+          dst[i] = i < avail ? (float)(((double)src[i] - st[c]) * st[ncols + c]) : 0.f;
+        }
+      }
+    } else if (vec) {
       const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
       f32x4* d4 = reinterpret_cast<f32x4*>(dst);
       for (int i = threadIdx.x; i < run / 4; i += blockDim.x) d4[i] = s4[i];
@@ -984,8 +1015,9 @@ int svk_spectrum(svk_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t 
   return SVK_OK;
 }
 
-int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
-             const int32_t* d_n_frames, int32_t variance) {
+// svk_cmvn (d_stats_out == NULL: normalise in place) and svk_cmvn_stats (statistics only) share the two paths
+static int cmvn_launch(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                       const int32_t* d_n_frames, int32_t variance, double* d_stats_out) {
   if (!ctx) return SVK_ERR_BAD_ARG;
   SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 0 && n_cols >= 0, "negative shape");
   if (n_utt == 0 || max_frames == 0 || n_cols == 0) return SVK_OK;
@@ -1000,22 +1032,40 @@ int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int
     const int rc = svk_ensure_work(ctx, part_bytes + stats_bytes);
     if (rc != SVK_OK) return rc;
     double* part = reinterpret_cast<double*>(ctx->work);
-    double* stats = part + (size_t)n_utt * n_chunks * 2 * n_cols;
+    double* stats = d_stats_out ? d_stats_out : part + (size_t)n_utt * n_chunks * 2 * n_cols;
     hipLaunchKernelGGL(cmvn_partial_kernel, dim3(n_chunks, n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols,
                        d_n_frames, n_chunks, part);
     SVK_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(cmvn_stats_kernel, dim3(n_utt), dim3(256), 0, ctx->stream, part, max_frames, n_cols, d_n_frames, n_chunks,
                        variance, stats);
     SVK_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(cmvn_apply_kernel, dim3(n_chunks, n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols,
-                       d_n_frames, stats);
-    SVK_LAUNCH_CHECK(ctx);
+    if (!d_stats_out) {
+      hipLaunchKernelGGL(cmvn_apply_kernel, dim3(n_chunks, n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols,
+                         d_n_frames, stats);
+      SVK_LAUNCH_CHECK(ctx);
+    }
     return SVK_OK;
   }
-  hipLaunchKernelGGL(cmvn_kernel, dim3(n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols, d_n_frames,
-                     variance);
+  if (d_stats_out)
+    hipLaunchKernelGGL(cmvn_kernel<false>, dim3(n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols, d_n_frames,
+                       variance, d_stats_out);
+  else
+    hipLaunchKernelGGL(cmvn_kernel<true>, dim3(n_utt), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols, d_n_frames,
+                       variance, (double*)nullptr);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
+}
+
+int svk_cmvn(svk_ctx* ctx, float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+             const int32_t* d_n_frames, int32_t variance) {
+  return cmvn_launch(ctx, d_feat, n_utt, max_frames, n_cols, d_n_frames, variance, nullptr);
+}
+
+int svk_cmvn_stats(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                   const int32_t* d_n_frames, int32_t variance, double* d_stats) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, d_stats || n_utt == 0 || n_cols == 0 || max_frames == 0, "d_stats is NULL");
+  return cmvn_launch(ctx, const_cast<float*>(d_feat), n_utt, max_frames, n_cols, d_n_frames, variance, d_stats);
 }
 
 int svk_mel_features(svk_ctx* ctx, const float* d_power, int32_t n_frames, int32_t n_bins, const float* d_bank,
@@ -1136,8 +1186,8 @@ int svk_cube_draw_crops(svk_ctx* ctx, const int32_t* d_n_frames, int32_t n_utt, 
   return SVK_OK;
 }
 
-int svk_cube_gather(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
-                    const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, float* d_out) {
+static int cube_gather_launch(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                              const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const double* d_stats, float* d_out) {
   if (!ctx) return SVK_ERR_BAD_ARG;
   SVK_REQUIRE(ctx, n_utt >= 0 && n_crops >= 0 && crop_frames >= 0 && n_cols >= 0 && max_frames >= 0, "negative shape");
   const int64_t jobs = (int64_t)n_utt * n_crops;
@@ -1146,9 +1196,21 @@ int svk_cube_gather(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
   SVK_REQUIRE(ctx, crop_frames <= max_frames, "crop_frames exceeds max_frames");
   const unsigned grid = (unsigned)std::min<int64_t>(jobs, (int64_t)ctx->num_cu * 16);
   hipLaunchKernelGGL(cube_gather_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_feat, max_frames, n_cols,
-                     d_crop_idx, n_crops, crop_frames, jobs, d_out);
+                     d_crop_idx, n_crops, crop_frames, jobs, d_stats, d_out);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
+}
+
+int svk_cube_gather(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                    const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, float* d_out) {
+  return cube_gather_launch(ctx, d_feat, n_utt, max_frames, n_cols, d_crop_idx, n_crops, crop_frames, nullptr, d_out);
+}
+
+int svk_cube_gather_cmvn(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                         const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const double* d_stats, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, d_stats || n_utt == 0, "d_stats is NULL");
+  return cube_gather_launch(ctx, d_feat, n_utt, max_frames, n_cols, d_crop_idx, n_crops, crop_frames, d_stats, d_out);
 }
 
 }  // extern "C"

@@ -291,6 +291,20 @@ class Engine:
                                 int(bool(variance))), self.ctx)
         return feat
 
+    def cmvn_stats(self, feat, n_frames=None, variance=False):
+        """svk_cmvn_stats: per-clip mean and 1 / (std + 2^-30) of feat [n_utt, max_frames, cols] as float64 [n_utt, 2, cols],
+        without touching feat (cube_gather(..., stats=...) applies them to the rows it copies)."""
+        torch = _torch()
+        if not (isinstance(feat, torch.Tensor) and feat.is_cuda and feat.dtype == torch.float32 and feat.is_contiguous()
+                and feat.dim() == 3):
+            raise ValueError("cmvn_stats wants a contiguous float32 CUDA tensor [n_utt, max_frames, cols]")
+        nf = self.to_device(n_frames, torch.int32) if n_frames is not None else None
+        stats = torch.zeros((feat.shape[0], 2, feat.shape[2]), dtype=torch.float64, device=self.device)
+        self._stream()
+        check(self.lib.svk_cmvn_stats(self.ctx, self._ptr(feat), feat.shape[0], feat.shape[1], feat.shape[2], self._ptr(nf),
+                                      int(bool(variance)), self._ptr(stats)), self.ctx)
+        return stats
+
     def mel_features(self, power, bank, out_kind, num_ceps=13, dc_elimination=True, want_energy=False):
         """General mel / log / DCT stage on a device power spectrum [T, bins] (any fft length)."""
         torch = _torch()
@@ -402,8 +416,9 @@ class Engine:
                                            self._ptr(bad_count)), self.ctx)
         return idx
 
-    def cube_gather(self, feat, crop_idx, crop_frames=80, out=None):
-        """feat [n, T, C] + crop_idx [n, n_crops] -> [n, 1, n_crops, crop_frames, C] (utils.py:364-379)."""
+    def cube_gather(self, feat, crop_idx, crop_frames=80, out=None, stats=None):
+        """feat [n, T, C] + crop_idx [n, n_crops] -> [n, 1, n_crops, crop_frames, C] (utils.py:364-379).  `stats` (cmvn_stats):
+        the copied rows are CMVN-normalised on the way (svk_cube_gather_cmvn) -- feat itself stays raw."""
         torch = _torch()
         feat = self.to_device(feat, torch.float32)
         idx = self.to_device(crop_idx, torch.int32)
@@ -412,6 +427,12 @@ class Engine:
         if out is None:
             out = torch.empty((n, 1, n_crops, crop_frames, Cc), dtype=torch.float32, device=self.device)
         self._stream()
+        if stats is not None:
+            if stats.dtype != torch.float64 or tuple(stats.shape) != (n, 2, Cc) or not stats.is_contiguous():
+                raise ValueError("stats must be the float64 [n, 2, cols] tensor of cmvn_stats")
+            check(self.lib.svk_cube_gather_cmvn(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), n_crops, crop_frames,
+                                                self._ptr(stats), self._ptr(out)), self.ctx)
+            return out
         check(self.lib.svk_cube_gather(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), n_crops, crop_frames,
                                        self._ptr(out)), self.ctx)
         return out

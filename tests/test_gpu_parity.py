@@ -463,6 +463,40 @@ def test_cmvn_batched_ragged(eng, clip_paths):
 
 
 # ---- VAD: bit-exact ---------------------------------------------------------------------------------
+def test_cmvn_folded_into_the_cube_gather(eng, clip_paths):
+    """svk_cmvn_stats + svk_cube_gather_cmvn (utils.py:382-397 CMVN feeding utils.py:351-379 FeatureCube in one pass over the
+    20 x 80 rows the cube holds) against svk_cmvn in place followed by svk_cube_gather: bit-identical on every CMVN path,
+    ragged frame counts, a clip with no frames, a too-short clip (crop -1 -> zero cube), 40 and 13 columns; the statistics
+    against the float64 oracle."""
+    rng = np.random.default_rng(17)
+    for n, T, C in ((7, 300, 40), (5, 1500, 40), (4, 260, 13)):
+        feat = (rng.standard_normal((n, T, C)) * 3.0 - 5.0).astype(np.float32)
+        nf = rng.integers(100, T + 1, size=n).astype(np.int32)
+        nf[0], nf[1] = T, 0
+        crops = np.stack([rng.integers(0, max(1, int(t) - 80), size=20) for t in nf]).astype(np.int32)
+        crops[1] = -1
+        crops[2] = -1                                                   # declared too short although it has frames
+        raw = eng.to_device(feat)
+        stats = eng.cmvn_stats(raw, nf, variance=True)
+        assert torch.equal(raw, eng.to_device(feat))                    # the features stay raw
+        got = eng.cube_gather(raw, crops, 80, stats=stats)
+        want = eng.cube_gather(eng.cmvn_(raw.clone(), nf, variance=True), crops, 80)
+        assert torch.equal(got, want), (n, T, C, clip_paths)
+        assert not got[1].any() and not got[2].any()
+        for u in range(n):
+            if nf[u] > 0:
+                x = feat[u, :nf[u]].astype(np.float64)
+                np.testing.assert_allclose(stats[u, 0].cpu().numpy(), x.mean(0), rtol=1e-12, atol=1e-12)
+                np.testing.assert_allclose(stats[u, 1].cpu().numpy(), 1.0 / (x.std(0) + 2.0 ** -30), rtol=1e-9)
+        mean_only = eng.cmvn_stats(raw, nf, variance=False)
+        assert torch.equal(eng.cube_gather(raw, crops, 80, stats=mean_only),
+                           eng.cube_gather(eng.cmvn_(raw.clone(), nf, variance=False), crops, 80))
+    with pytest.raises(ValueError):
+        eng.cube_gather(raw, crops, 80, stats=stats[:, :1])
+    assert eng.lib.svk_cmvn_stats(eng.ctx, None, 1, 10, 4, None, 1, None) == -1
+    assert eng.lib.svk_cube_gather_cmvn(eng.ctx, None, 1, 100, 40, None, 20, 80, None, None) == -1
+
+
 def test_vad_bit_exact(eng, golden, clip_paths):
     g = golden["vad"]
     thr = int(g["threshold"][0])
@@ -1492,8 +1526,8 @@ def test_trained_checkpoint_embeddings_against_the_reference(eng, golden):
     np.testing.assert_allclose([float(c_.abs().sum()) for c_ in cubes], g["cube_abssum"], rtol=1e-5)
     via_model = model(cubes, development=False)
     np.testing.assert_allclose(via_model.cpu().numpy(), g["embed"], rtol=0, atol=5e-5 * scale)
-    np.testing.assert_allclose(model(cubes).cpu().numpy()[:, :8], g["softmax_top"], rtol=1e-3, atol=1e-6)
-    np.testing.assert_allclose(model.create_Speaker_Model(cubes[3:4]).cpu().numpy(), g["speaker_model"], rtol=0, atol=5e-5 * scale)
+    np.testing.assert_allclose(model(cubes).detach().cpu().numpy()[:, :8], g["softmax_top"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(model.create_Speaker_Model(cubes[3:4]).detach().cpu().numpy(), g["speaker_model"], rtol=0, atol=5e-5 * scale)
     np.testing.assert_allclose(pipe.score(emb, emb).cpu().numpy(), g["cosine"], rtol=0, atol=1e-5)
 
 

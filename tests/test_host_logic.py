@@ -166,7 +166,8 @@ def test_ragged_batches_sort_cap_and_merge_the_tail():
     fn = VerificationPipeline._ragged_batches
     me = types.SimpleNamespace(micro_batch=100)
     lens = [1000] * 270 + [50_000] * 3
-    out = fn(me, lens, max_batch_samples=200_000)
+    inf = float("inf")
+    out = fn(me, lens, max_batch_samples=200_000, max_padding=inf)
     flat = [k for b, _ in out for k in b]
     assert sorted(flat) == list(range(len(lens)))                        # every clip exactly once
     assert [lens[k] for k in flat] == sorted(lens)                       # ascending length
@@ -174,6 +175,11 @@ def test_ragged_batches_sort_cap_and_merge_the_tail():
     # greedy: 100 + 100 + (70 short + 2 long = 170 000 samples) + (1 long); the last, a single clip, joins its predecessor
     assert [len(b) for b, _ in out] == [100, 100, 73]
     assert out[2][1] == 70 * 1000 + 3 * 50_000
+    # with the padding cap: 70 short clips are not padded to the length of the long ones
+    out = fn(me, lens, max_batch_samples=200_000, max_padding=1.6)
+    assert [len(b) for b, _ in out] == [100, 100, 70, 3] and sorted(k for b, _ in out for k in b) == list(range(len(lens)))
+    for b, total in out:
+        assert len(b) * max(lens[k] for k in b) <= 1.6 * total
     # the sample cap; a short tail joins its predecessor up to 1.5 x the cap together, not beyond
     assert [len(b) for b, _ in fn(me, [60_000] * 5, max_batch_samples=130_000)] == [2, 3]
     assert [len(b) for b, _ in fn(me, [100_000] * 3, max_batch_samples=120_000)] == [1, 1, 1]
@@ -184,8 +190,19 @@ def test_ragged_batches_sort_cap_and_merge_the_tail():
     assert [len(b) for b, _ in fn(me, [1000] * 103, max_batch_samples=10**9)] == [100, 3]
     # ... nor multiplies its feature buffer: 5 clips of 145 s joined to 90 clips of 20 s make it 95 x 14 500 frames (220 MB)
     lens = [320_000] * 90 + [2_320_000] * 5
-    assert [len(b) for b, _ in fn(me, lens, max_batch_samples=30_000_000, max_feature_bytes=64 << 20)] == [90, 5]
-    assert [len(b) for b, _ in fn(me, lens, max_batch_samples=30_000_000)] == [95]
+    assert [len(b) for b, _ in fn(me, lens, max_batch_samples=30_000_000, max_feature_bytes=64 << 20, max_padding=inf)] == [90, 5]
+    assert [len(b) for b, _ in fn(me, lens, max_batch_samples=30_000_000, max_padding=inf)] == [95]
+    assert [len(b) for b, _ in fn(me, lens, max_batch_samples=30_000_000, max_padding=1.6)] == [90, 5]
+    # a VoxCeleb-like length distribution: every clip once, ascending, every batch within the caps
+    rng = np.random.default_rng(7)
+    lens = (np.minimum(4.0 + rng.lognormal(np.log(3.2), 0.85, 3000), 145.0) * 16000).astype(np.int64)
+    me = types.SimpleNamespace(micro_batch=1024)
+    out = fn(me, lens, max_batch_samples=64 << 20, max_padding=2.0)
+    flat = [k for b, _ in out for k in b]
+    assert sorted(flat) == list(range(3000)) and all(lens[a] <= lens[b] for a, b in zip(flat, flat[1:]))
+    for b, total in out:
+        assert len(b) <= 1024 and total == int(((lens[b] + 7) // 8 * 8).sum()) and (total <= 64 << 20 or len(b) == 1)
+        assert len(b) * ((int(lens[b].max()) + 7) // 8 * 8) <= 2.0 * total + 8
 
 
 def test_tail_operand_tables_against_naive_indexing():
@@ -275,7 +292,8 @@ def test_cube_ring_runs_every_clip_once_in_bounded_memory():
         device = torch.device("cpu")
 
         @staticmethod
-        def cube_gather(feat, idx, frames, out=None):
+        def cube_gather(feat, idx, frames, out=None, stats=None):
+            assert stats is None
             for u in range(feat.shape[0]):
                 for k in range(idx.shape[1]):
                     out[u, 0, k] = feat[u, idx[u, k]:idx[u, k] + frames]
