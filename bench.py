@@ -430,10 +430,10 @@ def stage_breakdown(pipe, eng, torch, chunk, first_utt):
         return float(np.median(ts)), out
 
     rows = {}
-    t, (voiced, vlen) = timed(lambda: pipe.voiced(chunk))
+    t, (vlen, gather) = timed(lambda: pipe.vad(chunk))
     kept = float(vlen.float().sum().item()) if vlen is not None else float(n * L)
-    rows["vad+compact"] = (t, n * L * 2 + kept * 2)
-    t, (feat, nf, _) = timed(lambda: eng.features(voiced, pipe.spec, lengths=vlen))
+    rows["vad (frame flags + hysteresis + index of the kept frames; no copy)"] = (t, n * L * 2)
+    t, (feat, nf, _) = timed(lambda: eng.features(chunk, pipe.spec, lengths=vlen, gather=gather))
     frames = float(nf.float().sum().item())
     rows["frontend (lmfe-40, nfft 1024)"] = (t, kept * 2 + frames * 40 * 4)
     t, _ = timed(lambda: eng.cmvn_(feat, nf, variance=True))
@@ -648,6 +648,20 @@ def cpu_child(sample_dir):
         cores = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         pass
+    # a container may see every hardware thread of the host and still be granted a fraction of them (cgroup CPU quota): pools
+    # sized by os.cpu_count() then time-slice, and "utt/s on N workers" says little about N cores
+    quota = None
+    try:
+        parts = open("/sys/fs/cgroup/cpu.max").read().split()
+        if parts[0] != "max":
+            quota = float(parts[0]) / float(parts[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            pass
     cpu_model = platform.processor() or ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -656,7 +670,7 @@ def cpu_child(sample_dir):
                 break
     except OSError:
         pass
-    out = {"cores": cores, "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model,
+    out = {"cores": cores, "os_cpu_count": os.cpu_count(), "cpu_quota_cores": quota, "cpu_model": cpu_model,
            "versions": {"python": platform.python_version(), "numpy": np.__version__, "scipy": scipy.__version__,
                         "torch": torch.__version__}, "sample_clips": n, "stages": {}}
 
@@ -677,7 +691,10 @@ def cpu_child(sample_dir):
     # ---- the whole per-utterance chain (batch 1, like evaluation.py:113-121), one single-threaded worker per slot, at
     # several pool sizes: with SMT and memory-bound batch-1 convolutions "one worker per hardware thread" is not the
     # fastest use of the host (1.6 utt/s per thread at 256 workers vs 115 on one).  `value` = the best. ----
-    sweep = sorted({max(1, cores // 4), max(1, cores // 2), cores})
+    sweep = {max(1, cores // 4), max(1, cores // 2), cores}
+    if quota:                       # the granted share of the host: pools of that many workers, and of twice as many
+        sweep = {w for w in sweep if w <= 4 * quota} | {max(1, int(round(quota))), max(1, int(round(2 * quota)))}
+    sweep = sorted(sweep)
     out["chain_sweep"] = {}
     best = None
     for workers in sweep:
@@ -846,8 +863,8 @@ def main():
         pcm, _ = synth.corpus_device(1024, dev, first_clip=0, utts_per_speaker=UTTS_PER_SPK)
         pipe = VerificationPipeline(bench_model()[0], use_vad=not args.no_vad, normalize=not args.no_cmvn,
                                     preemph_cof=None if args.no_preemph else 0.98, crop_rng="device", micro_batch=1024)
-        voiced, vlen = pipe.voiced(pcm)
-        feat, n_frames = pipe.features(voiced, vlen)
+        vlen, gather = pipe.vad(pcm)
+        feat, n_frames = pipe.features(pcm, vlen, gather)
         idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, 0, pipe.bad_clips)
         ms = _median_ms(torch, lambda: pipe.embed_features(feat, idx), max(args.steps, 5))
         print(json.dumps({"workload": "1024 cubes: svk_c3d2_stage1 + stage2 + conv31 + conv32t + conv41 + conv42 + fc5",
@@ -891,11 +908,11 @@ def main():
         local = torch.empty((n_local, 128), dtype=torch.float32, device=dev)
         for lo, hi in spans:
             chunk = pcm[lo:hi]
-            voiced, vlen = pipe.voiced(chunk)
+            vlen, gather = pipe.vad(chunk)
             if record:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-            feat, n_frames, _ = eng.features(voiced, pipe.spec, lengths=vlen)
+            feat, n_frames, _ = eng.features(chunk, pipe.spec, lengths=vlen, gather=gather)
             if record:
                 b.record()
                 fe_events.append((a, b))
@@ -946,7 +963,7 @@ def main():
         kept = torch.zeros((), dtype=torch.float64, device=dev)
         frames = torch.zeros((), dtype=torch.float64, device=dev)
         for lo, hi in spans:
-            _, vlen = pipe.voiced(pcm[lo:hi])
+            vlen, _ = pipe.vad(pcm[lo:hi])
             vl = vlen.to(torch.float64) if vlen is not None else torch.full((hi - lo,), float(pcm.shape[1]), device=dev,
                                                                            dtype=torch.float64)
             kept += vl.sum()
@@ -1173,9 +1190,11 @@ def main():
                 "sample": "the first %d clips of the corpus through oracle/ in a fresh process: vad -> /32768 -> preemph "
                           "-> lmfe -> cmvn -> cube -> C3D2 batch 1 -> per-pair cosine, single-threaded workers "
                           "(multiprocessing.Pool; every worker runs the chain once before the clock starts; scoring spread "
-                          "over the same workers): the best of %s workers = %d (%.1f s); the host shows %d hardware threads"
-                          % (ns, sorted(int(k) for k in rec["chain_sweep"]), rec["workers"], rec["seconds"], rec["cores"]),
-                "host_threads": rec["cores"], "chain_by_workers": rec["chain_sweep"],
+                          "over the same workers): the best of %s workers = %d (%.1f s); the host shows %d hardware threads, the "
+                          "container's CPU quota is %s"
+                          % (ns, sorted(int(k) for k in rec["chain_sweep"]), rec["workers"], rec["seconds"], rec["cores"],
+                             "%.1f cores" % rec["cpu_quota_cores"] if rec.get("cpu_quota_cores") else "unlimited"),
+                "host_threads": rec["cores"], "cpu_quota_cores": rec.get("cpu_quota_cores"), "chain_by_workers": rec["chain_sweep"],
                 "cpu_model": rec["cpu_model"], "os_cpu_count": rec["os_cpu_count"], "versions": rec["versions"],
                 "variants": rec["stages"], "child_wall_s": rec["wall_s"]}
     if rank == 0:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 107 /* 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
+#define SVK_VERSION 108 /* 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -105,11 +105,16 @@ int svk_frontend_num_cols(const svk_frontend_cfg* cfg);
  * d_feat     : [n_utt][max_frames][num_cols] float32; rows >= n_frames are zeroed
  * d_energy   : [n_utt][max_frames] float32 frame energies (after zero handling), or NULL
  * d_n_frames : [n_utt] int32 frames produced per clip, or NULL
+ * d_src_chunk: NULL, or GATHERED input (int16 PCM): clip u's signal is then the concatenation of chunks of chunk_samples
+ *              samples of its PCM, chunk q = PCM chunk d_src_chunk[u * chunk_stride + q], d_lengths[u] samples of it in
+ *              all (required) -- svk_vad_energy's d_src_frame with chunk_samples = frame_samples: the voiced frames of
+ *              vad.py:135-168 feed the front end where they lie, without the pass that copies them to the front of a
+ *              second buffer (same samples, bit-identical features).  chunk_samples a multiple of 8.
  */
 int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_pcm, int pcm_dtype,
                      const int64_t* d_offsets, const int32_t* d_lengths, int64_t clip_stride,
                      int32_t clip_len, int32_t n_utt, int32_t max_frames, float* d_feat, float* d_energy,
-                     int32_t* d_n_frames);
+                     int32_t* d_n_frames, const int32_t* d_src_chunk, int32_t chunk_samples, int32_t chunk_stride);
 
 /* ---- stage-level entry points (one speechpy function each) ----------------- */
 /* processing.py:45-58.  d_in int16/float32 [n]; d_out float32 [n]; circular. */
@@ -169,13 +174,16 @@ int svk_log_power(svk_ctx* ctx, float* d_power, int64_t n, int32_t normalize);
  * d_n_vad_frames: [n_utt] int32, or NULL
  * d_voiced     : int16, same offsets as d_pcm: kept frames packed to the front (the rest of a
  *                clip's slot is left untouched), or NULL
- * d_voiced_len : [n_utt] int32 samples kept (required when d_voiced != NULL)
+ * d_voiced_len : [n_utt] int32 samples kept (required when d_voiced or d_src_frame != NULL)
+ * d_src_frame  : [n_utt][max_vad_frames] int32 or NULL: the index form of the same compaction, d_src_frame[u][q] = the
+ *                frame that is the q-th kept one (entries past the kept count are left untouched); svk_frontend_run reads
+ *                the PCM through it (d_src_chunk) -- with d_voiced = NULL nothing is copied
  */
 int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t* d_offsets, const int32_t* d_lengths,
                    int64_t clip_stride, int32_t clip_len, int32_t n_utt, int32_t frame_samples,
                    int32_t ring_len, int32_t ring_thresh, int64_t threshold, int32_t max_vad_frames,
                    uint8_t* d_keep, int32_t* d_seg, int32_t* d_n_vad_frames, int16_t* d_voiced,
-                   int32_t* d_voiced_len);
+                   int32_t* d_voiced_len, int32_t* d_src_frame);
 
 /* ---- feature cube ------------------------------------------------------------
  * utils.py:351-379 (FeatureCube): out[u][0][c][r][:] = feat[u][crop[u][c] + r][:].

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsvk.so")
 
 SVK_OK = 0
-VERSION = 107                      # include/svk.h SVK_VERSION
+VERSION = 108                      # include/svk.h SVK_VERSION
 SVK_ERR_BAD_ARG, SVK_ERR_UNSUPPORTED, SVK_ERR_HIP, SVK_ERR_NO_DEVICE, SVK_ERR_OOM, SVK_ERR_RCCL = -1, -2, -3, -4, -5, -6
 OUT_MFE, OUT_LMFE, OUT_MFCC = 0, 1, 2
 PCM_I16, PCM_F32 = 0, 1
@@ -57,7 +57,7 @@ SIGNATURES = {
     "svk_frontend_plan_destroy": (None, [_vp]),
     "svk_frontend_num_frames": (_i64, [C.POINTER(FrontendCfg), _i64]),
     "svk_frontend_num_cols": (C.c_int, [C.POINTER(FrontendCfg)]),
-    "svk_frontend_run": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "svk_frontend_run": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32]),
     "svk_preemphasis": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _f32, _vp]),
     "svk_stack_frames": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "svk_spectrum": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -68,7 +68,7 @@ SIGNATURES = {
     "svk_derivative": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "svk_log_power": (C.c_int, [_vp, _vp, _i64, _i32]),
     "svk_vad_energy": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i64, _i32,
-                                  _vp, _vp, _vp, _vp, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp]),
     "svk_cube_draw_crops": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _i32, _i32, C.c_uint64, _vp, _vp]),
     "svk_cube_gather": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "svk_cube_gather_cmvn": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),

@@ -70,6 +70,12 @@ struct FrontendParams {
   const int32_t* lengths;
   int64_t clip_stride;
   int32_t clip_len;
+  // Gathered input (int16 PCM only): a clip's signal is the concatenation of CHUNKS of `chunk` samples of its PCM, chunk q of
+  // clip u = PCM chunk src_chunk[u * chunk_stride + q] -- the index form of svk_vad_energy's compaction (d_src_frame): the
+  // kept frames are read where they lie instead of being copied to the front of a second buffer first.  NULL = plain clips.
+  const int32_t* src_chunk;
+  int32_t chunk, chunk_stride;
+  float chunk_inv;   // 1 / chunk: sample index -> chunk without an integer division (indices stay below 2^24: exact in float)
   int32_t n_utt, max_frames, tiles_per_utt;
   int32_t flen, flen_eff, stride, nfilt, ncols, out_kind, dc_elim, preemph, pre_shift;
   float pre_cof;
@@ -142,22 +148,51 @@ __device__ __forceinline__ void stage_span(const FrontendParams& p, const PcmT* 
 // half the LDS of the f32 form) and pre-emphasise when a frame is read: x[n] - c * x[n-1] needs
 // one extra sample in front of the span (the clip's LAST sample when the span starts the clip:
 // np.roll wraps, Q5).
+// `tab` (gathered input, FrontendParams::src_chunk): sample j of the clip's signal = x[tab[j / chunk] * chunk + j % chunk]; chunk is a
+// multiple of 8 and every span starts on a multiple of 8, so a 16-byte vector never straddles two chunks.
+// q = j / chunk from a float reciprocal, corrected by one step either way (an integer division is ~40 vector instructions, four
+// of them per lane and tile were 8 % of this issue-bound kernel): j < 2^24 (the host checks), so (float)j is exact and the
+// estimate is off by at most one.
+__device__ __forceinline__ int64_t gathered_index(const int32_t* tab, int chunk, float chunk_inv, int64_t j) {
+  const int ji = (int)j;
+  int q = (int)((float)ji * chunk_inv);
+  int r = ji - q * chunk;
+  if (r < 0) { --q; r += chunk; }
+  if (r >= chunk) { ++q; r -= chunk; }
+  return (int64_t)tab[q] * chunk + r;
+}
+
 __device__ __forceinline__ void stage_raw16(bool pre, const int16_t* x, int64_t s0, int need, int len, int16_t* sigh,
-                                            int lane) {
+                                            int lane, const int32_t* tab = nullptr, int chunk = 0, float chunk_inv = 0.f) {
   typedef short vec_t __attribute__((ext_vector_type(8)));
   constexpr int NV = 3;  // 16-byte loads in flight per lane: an 8-frame tile at a 160-sample hop is 3 x 512 samples
-  if (lane == 0 && pre) sigh[RAW_OFF - 1] = s0 == 0 ? x[len - 1] : x[s0 - 1];
+  if (lane == 0 && pre) {
+    const int64_t jp = s0 == 0 ? (int64_t)len - 1 : s0 - 1;
+    sigh[RAW_OFF - 1] = x[tab ? gathered_index(tab, chunk, chunk_inv, jp) : jp];
+  }
   // wave-uniform: the span starts on a 16-byte boundary and its last vector ends inside the clip
   // (every tile of a clip but possibly the last one), so no load needs patching
-  const bool whole = (reinterpret_cast<uintptr_t>(x + s0) & 15) == 0 && s0 + ((need + 7) & ~7) <= len;
+  const bool whole = (tab ? (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (s0 & 7) == 0
+                          : (reinterpret_cast<uintptr_t>(x + s0) & 15) == 0) && s0 + ((need + 7) & ~7) <= len;
   if (whole) {
     for (int base = 0; base < need; base += NV * 512) {
       vec_t raw[NV];
       // all loads first (a load per loop trip followed by its own wait cost one HBM round trip EACH) ...
+      if (tab) {
+        int64_t src[NV];
 #pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const int i = base + k * 512 + lane * 8;
-        raw[k] = *reinterpret_cast<const vec_t*>(x + s0 + (i < need ? i : 0));  // clamped: always a valid aligned address
+        for (int k = 0; k < NV; ++k) {
+          const int i = base + k * 512 + lane * 8;
+          src[k] = gathered_index(tab, chunk, chunk_inv, s0 + (i < need ? i : 0));   // (the table entries first: dependent loads)
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) raw[k] = *reinterpret_cast<const vec_t*>(x + src[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          const int i = base + k * 512 + lane * 8;
+          raw[k] = *reinterpret_cast<const vec_t*>(x + s0 + (i < need ? i : 0));  // clamped: always a valid aligned address
+        }
       }
       // ... then the LDS writes
 #pragma unroll
@@ -170,7 +205,10 @@ __device__ __forceinline__ void stage_raw16(bool pre, const int16_t* x, int64_t 
     for (int i = lane * 8; i < need; i += 64 * 8) {
       vec_t raw;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) raw[e] = s0 + i + e < len ? x[s0 + i + e] : (short)0;
+      for (int e = 0; e < 8; ++e) {
+        const int64_t j = s0 + i + e;
+        raw[e] = j < len ? x[tab ? gathered_index(tab, chunk, chunk_inv, j) : j] : (short)0;
+      }
       *reinterpret_cast<vec_t*>(sigh + RAW_OFF + i) = raw;
     }
   }
@@ -423,7 +461,8 @@ __global__ __launch_bounds__(Spec::MAX_THREADS) void frontend_kernel(const Front
       wave_sync();  // previous tile's readers of sig / ptile are done
       if (SVK_ABLATE(p, 1)) {
       } else if constexpr (RAW16)
-        stage_raw16(c_preemph != 0, reinterpret_cast<const int16_t*>(x), (int64_t)f0 * c_stride, need, len, sigh, lane);
+        stage_raw16(c_preemph != 0, reinterpret_cast<const int16_t*>(x), (int64_t)f0 * c_stride, need, len, sigh, lane,
+                    p.src_chunk ? p.src_chunk + (int64_t)utt * p.chunk_stride : nullptr, p.chunk, p.chunk_inv);
       else
         stage_span<PcmT>(p, x, (int64_t)f0 * c_stride, need, len, sig, lane);
       wave_sync();
@@ -933,7 +972,8 @@ void svk_frontend_plan_destroy(svk_frontend_plan* plan) {
 
 int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_pcm, int pcm_dtype,
                      const int64_t* d_offsets, const int32_t* d_lengths, int64_t clip_stride, int32_t clip_len,
-                     int32_t n_utt, int32_t max_frames, float* d_feat, float* d_energy, int32_t* d_n_frames) {
+                     int32_t n_utt, int32_t max_frames, float* d_feat, float* d_energy, int32_t* d_n_frames,
+                     const int32_t* d_src_chunk, int32_t chunk_samples, int32_t chunk_stride) {
   if (!ctx || !plan) return SVK_ERR_BAD_ARG;
   SVK_REQUIRE(ctx, plan->device == ctx->device, "plan belongs to another device");
   SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 0, "n_utt / max_frames negative");
@@ -953,6 +993,17 @@ int svk_frontend_run(svk_ctx* ctx, const svk_frontend_plan* plan, const void* d_
   p.max_frames = max_frames;
   const bool raw16 = pcm_dtype == SVK_PCM_I16 && (!plan->cfg.preemph || plan->cfg.preemph_shift == 1) &&
                      !(getenv("SVK_FE_F32STAGE") && atoi(getenv("SVK_FE_F32STAGE")));
+  p.src_chunk = d_src_chunk;
+  p.chunk = chunk_samples;
+  p.chunk_stride = chunk_stride;
+  p.chunk_inv = chunk_samples > 0 ? 1.0f / (float)chunk_samples : 0.f;
+  if (d_src_chunk) {
+    SVK_REQUIRE(ctx, (int64_t)chunk_samples * chunk_stride < ((int64_t)1 << 24), "gathered clips of at most 2^24 samples");
+    SVK_REQUIRE(ctx, d_lengths, "gathered input needs d_lengths (the gathered length of every clip)");
+    if (!raw16 || chunk_samples < 8 || (chunk_samples & 7) || chunk_stride < 0)
+      return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "gathered input (d_src_chunk) is built for int16 PCM through the 16-bit staging path "
+                      "and chunks of a multiple of 8 samples (got dtype %d, chunk %d)", pcm_dtype, chunk_samples);
+  }
   const LdsLayout lds = lds_layout(plan, plan->tile, raw16, ctx->lds_per_cu);
   p.tiles_per_utt = (max_frames + plan->tile - 1) / plan->tile;
   p.flen = plan->cfg.frame_len;

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(VAD_THREADS) void vad_kernel(const int16_t* __restr
                                                   int clip_len, int fsamp, int ring_len, int ring_thresh,
                                                   long long threshold, int max_vf, uint8_t* __restrict__ keep_out,
                                                   int32_t* __restrict__ seg_out, int32_t* __restrict__ nvf_out,
-                                                  int16_t* __restrict__ voiced, int32_t* __restrict__ voiced_len) {
+                                                  int16_t* __restrict__ voiced, int32_t* __restrict__ voiced_len, int32_t* __restrict__ src_frame) {
   __shared__ uint8_t flag[MAX_VAD_FRAMES];
   __shared__ int32_t pos[MAX_VAD_FRAMES];  // packed frame index of a kept frame, or -1
   const int utt = blockIdx.x;
@@ -166,6 +166,8 @@ __global__ __launch_bounds__(VAD_THREADS) void vad_kernel(const int16_t* __restr
   for (int f = threadIdx.x; f < max_vf; f += VAD_THREADS) {
     keep_out[(int64_t)utt * max_vf + f] = (f < nf && pos[f] >= 0) ? 1 : 0;
     if (seg_out && f >= nf) seg_out[(int64_t)utt * max_vf + f] = -1;
+    // the index form of the compaction: src_frame[q] = the frame that is the q-th kept one (svk_frontend_run reads through it)
+    if (src_frame && f < nf && pos[f] >= 0) src_frame[(int64_t)utt * max_vf + pos[f]] = f;
   }
   if (voiced) {
     int16_t* dst = voiced + off;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(64) void vad_walk_kernel(const int32_t* __restrict_
                                                       int ring_thresh, int max_vf, const uint8_t* __restrict__ flag_g,
                                                       int32_t* __restrict__ pos_g, uint8_t* __restrict__ keep_out,
                                                       int32_t* __restrict__ seg_out, int32_t* __restrict__ nvf_out,
-                                                      int32_t* __restrict__ voiced_len) {
+                                                      int32_t* __restrict__ voiced_len, int32_t* __restrict__ src_frame) {
   __shared__ int32_t P[MAX_VAD_FRAMES + 1];   // P[f] = flags set in frames [0, f)
   __shared__ int16_t segm[MAX_VAD_FRAMES];    // segment of a kept frame, -1 otherwise
   const int utt = blockIdx.x, lane = threadIdx.x;
@@ -344,7 +346,8 @@ __global__ __launch_bounds__(64) void vad_walk_kernel(const int32_t* __restrict_
     const unsigned long long km = __ballot(k);
     if (g < max_vf) {
       const int pf = k ? kept + __popcll(km & ((1ull << lane) - 1ull)) : -1;
-      if (g < nf) pos_g[(int64_t)utt * max_vf + g] = pf;
+      if (g < nf && pos_g) pos_g[(int64_t)utt * max_vf + g] = pf;
+      if (src_frame && k) src_frame[(int64_t)utt * max_vf + pf] = g;
       keep_out[(int64_t)utt * max_vf + g] = k ? 1 : 0;
       if (seg_out) seg_out[(int64_t)utt * max_vf + g] = g < nf ? (int32_t)segm[g] : -1;
     }
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(VAD_THREADS) void vad_small_kernel(const int16_t* _
                                                                 int clip_len, int fsamp, int ring_len, int ring_thresh,
                                                                 long long threshold, int max_vf, uint8_t* __restrict__ keep_out,
                                                                 int32_t* __restrict__ seg_out, int32_t* __restrict__ nvf_out,
-                                                                int16_t* __restrict__ voiced, int32_t* __restrict__ voiced_len) {
+                                                                int16_t* __restrict__ voiced, int32_t* __restrict__ voiced_len, int32_t* __restrict__ src_frame) {
   __shared__ uint8_t flag[VAD_SMALL];
   __shared__ int32_t P[VAD_SMALL + 1];
   __shared__ int16_t segm[VAD_SMALL];
@@ -418,7 +421,9 @@ __global__ __launch_bounds__(VAD_THREADS) void vad_small_kernel(const int16_t* _
       const bool k = g < nf && segm[g] >= 0;
       const unsigned long long km = __ballot(k);
       if (g < max_vf) {
-        if (g < nf) pos[g] = (int16_t)(k ? kept + __popcll(km & ((1ull << lane) - 1ull)) : -1);
+        const int pf_s = k ? kept + __popcll(km & ((1ull << lane) - 1ull)) : -1;
+        if (g < nf) pos[g] = (int16_t)pf_s;
+        if (src_frame && k) src_frame[(int64_t)utt * max_vf + pf_s] = g;
         keep_out[(int64_t)utt * max_vf + g] = k ? 1 : 0;
         if (seg_out) seg_out[(int64_t)utt * max_vf + g] = g < nf ? (int32_t)segm[g] : -1;
       }
@@ -497,13 +502,14 @@ extern "C" int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t*
                               int64_t clip_stride, int32_t clip_len, int32_t n_utt, int32_t frame_samples,
                               int32_t ring_len, int32_t ring_thresh, int64_t threshold, int32_t max_vad_frames,
                               uint8_t* d_keep, int32_t* d_seg, int32_t* d_n_vad_frames, int16_t* d_voiced,
-                              int32_t* d_voiced_len) {
+                              int32_t* d_voiced_len, int32_t* d_src_frame) {
   if (!ctx) return SVK_ERR_BAD_ARG;
   SVK_REQUIRE(ctx, n_utt >= 0 && frame_samples >= 1 && ring_len >= 1 && ring_thresh >= 0 && max_vad_frames >= 0,
               "negative or zero geometry");
   if (n_utt == 0) return SVK_OK;
   SVK_REQUIRE(ctx, d_pcm && d_keep, "d_pcm / d_keep is NULL");
   SVK_REQUIRE(ctx, !d_voiced || d_voiced_len, "d_voiced needs d_voiced_len");
+  SVK_REQUIRE(ctx, !d_src_frame || d_voiced_len, "d_src_frame needs d_voiced_len");
   SVK_REQUIRE(ctx, d_voiced != d_pcm, "d_voiced must not alias d_pcm");
   if (max_vad_frames > MAX_VAD_FRAMES)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "at most %d VAD frames per clip, got %d", MAX_VAD_FRAMES,
@@ -514,17 +520,17 @@ extern "C" int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t*
   const bool split = usual && n_utt <= 65535 && (force ? force[0] == '1' : max_vad_frames > 512);
   if (split && max_vad_frames > 0) {
     const size_t flag_bytes = ((size_t)n_utt * max_vad_frames + 15) & ~(size_t)15;
-    const size_t pos_bytes = sizeof(int32_t) * (size_t)n_utt * max_vad_frames;
+    const size_t pos_bytes = d_voiced ? sizeof(int32_t) * (size_t)n_utt * max_vad_frames : 0;   // positions: only the copy reads them
     const int rc = svk_ensure_work(ctx, flag_bytes + pos_bytes);
     if (rc != SVK_OK) return rc;
     uint8_t* flag_g = reinterpret_cast<uint8_t*>(ctx->work);
-    int32_t* pos_g = reinterpret_cast<int32_t*>(flag_g + flag_bytes);
+    int32_t* pos_g = d_voiced ? reinterpret_cast<int32_t*>(flag_g + flag_bytes) : nullptr;
     const dim3 grid((max_vad_frames + VAD_CHUNK - 1) / VAD_CHUNK, n_utt);
     hipLaunchKernelGGL(vad_flags_kernel, grid, dim3(VAD_THREADS), 0, ctx->stream, d_pcm, d_offsets, d_lengths, clip_stride, clip_len,
                        frame_samples, (long long)threshold, max_vad_frames, flag_g);
     SVK_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(vad_walk_kernel, dim3(n_utt), dim3(64), 0, ctx->stream, d_lengths, clip_len, frame_samples, ring_len,
-                       ring_thresh, max_vad_frames, flag_g, pos_g, d_keep, d_seg, d_n_vad_frames, d_voiced_len);
+                       ring_thresh, max_vad_frames, flag_g, pos_g, d_keep, d_seg, d_n_vad_frames, d_voiced_len, d_src_frame);
     SVK_LAUNCH_CHECK(ctx);
     if (d_voiced) {
       hipLaunchKernelGGL(vad_copy_kernel, grid, dim3(VAD_THREADS), 0, ctx->stream, d_pcm, d_offsets, d_lengths, clip_stride, clip_len,
@@ -536,13 +542,13 @@ extern "C" int svk_vad_energy(svk_ctx* ctx, const int16_t* d_pcm, const int64_t*
   if (usual && max_vad_frames <= VAD_SMALL && !(force && force[0] == '2')) {   // (SVK_VAD_SPLIT=2 forces the general one-kernel path)
     hipLaunchKernelGGL(vad_small_kernel, dim3(n_utt), dim3(VAD_THREADS), 0, ctx->stream, d_pcm, d_offsets, d_lengths, clip_stride,
                        clip_len, frame_samples, ring_len, ring_thresh, (long long)threshold, max_vad_frames, d_keep, d_seg,
-                       d_n_vad_frames, d_voiced, d_voiced_len);
+                       d_n_vad_frames, d_voiced, d_voiced_len, d_src_frame);
     SVK_LAUNCH_CHECK(ctx);
     return SVK_OK;
   }
   hipLaunchKernelGGL(vad_kernel, dim3(n_utt), dim3(VAD_THREADS), 0, ctx->stream, d_pcm, d_offsets, d_lengths, clip_stride,
                      clip_len, frame_samples, ring_len, ring_thresh, (long long)threshold, max_vad_frames, d_keep,
-                     d_seg, d_n_vad_frames, d_voiced, d_voiced_len);
+                     d_seg, d_n_vad_frames, d_voiced, d_voiced_len, d_src_frame);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }

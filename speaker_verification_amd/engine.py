@@ -145,19 +145,21 @@ class Engine:
         return hit
 
     def features(self, pcm, spec, lengths=None, offsets=None, clip_len=None, max_frames=None,
-                 want_energy=False):
+                 want_energy=False, gather=None):
         """Batched front end.
 
         pcm     : [n_utt, L] (uniform clips) or, with `offsets`, a 1-D concatenation;
                   int16 or float32, NumPy or CUDA tensor
         lengths : optional [n_utt] int32 samples per clip (device or host)
+        gather  : (src_frame [n_utt, F] i32, frame_samples) of vad_energy(..., compact="index"): the clips' VOICED frames
+                  are read where they lie in `pcm` (lengths = voiced_len), nothing was copied (int16 PCM, fused kernel only)
         returns (feat [n_utt, max_frames, cols] f32, n_frames [n_utt] i32, energy or None)
         """
         torch = _torch()
         try:
             handle, _ = self.plan(spec)
         except _lib.SvkError as err:
-            if err.code != _lib.SVK_ERR_UNSUPPORTED:
+            if err.code != _lib.SVK_ERR_UNSUPPORTED or gather is not None:
                 raise
             # what the fused kernel does not cover (other fft lengths, > 64 filters, a bank past bin
             # nfft/4 of 1024 or nfft/2 of 512, frames too long for a CU's LDS): the same stages as
@@ -190,10 +192,17 @@ class Engine:
         feat = torch.empty((n_utt, max_frames, cols), dtype=torch.float32, device=self.device)
         n_frames = torch.empty((n_utt,), dtype=torch.int32, device=self.device)
         energy = torch.empty((n_utt, max_frames), dtype=torch.float32, device=self.device) if want_energy else None
+        src, chunk, cstride = None, 0, 0
+        if gather is not None:
+            src, chunk = gather
+            if lengths is None or src.dtype != torch.int32 or src.dim() != 2 or src.shape[0] != n_utt or not src.is_contiguous():
+                raise ValueError("gather wants (src_frame [n_utt, F] int32, frame_samples) and the voiced lengths")
+            cstride = int(src.shape[1])
         self._stream()
         check(self.lib.svk_frontend_run(self.ctx, handle, self._ptr(pcm), kind, self._ptr(offsets),
                                         self._ptr(lengths), stride, length, n_utt, max_frames,
-                                        self._ptr(feat), self._ptr(energy), self._ptr(n_frames)), self.ctx)
+                                        self._ptr(feat), self._ptr(energy), self._ptr(n_frames),
+                                        self._ptr(src), int(chunk), cstride), self.ctx)
         return feat, n_frames, energy
 
     def _features_staged(self, pcm, spec, lengths, offsets, clip_len, max_frames, want_energy):
@@ -353,7 +362,9 @@ class Engine:
                    want_segments=False, frame_samples=None, ring_len=None, offsets=None, voiced_out=None, longest=None):
         """pcm [n_utt, L] int16 (or, with `offsets` + `lengths`, a 1-D concatenation of ragged clips) ->
         dict(keep [n, F] u8, n_vad_frames [n] i32, voiced (same layout as pcm; a clip's samples past its
-        voiced_len are unspecified) i16, voiced_len [n] i32, seg [n, F] i32).  `longest`: the longest clip in samples when
+        voiced_len are unspecified) i16, voiced_len [n] i32, seg [n, F] i32, src_frame).  compact=True copies the kept
+        frames to the front of `voiced`; compact="index" copies nothing and returns src_frame [n, F] i32 instead (entry q =
+        the q-th kept frame: `features(pcm, ..., lengths=voiced_len, gather=(src_frame, frame_samples))` reads through it).  `longest`: the longest clip in samples when
         the caller knows it (device-side lengths would otherwise cost a host round trip to size the outputs)."""
         torch = _torch()
         x = self.to_device(pcm)
@@ -388,19 +399,23 @@ class Engine:
         seg = torch.empty((n_utt, max_vf), dtype=torch.int32, device=self.device) if want_segments else None
         # only [:voiced_len] of a clip is defined (no 98 MB memset); `voiced_out`: a caller-owned buffer of pcm's shape,
         # reused across batches that address ONE resident concatenation through offsets
-        if compact and voiced_out is not None:
+        index = compact == "index"
+        if index:
+            voiced = None
+        elif compact and voiced_out is not None:
             if voiced_out.shape != x.shape or voiced_out.dtype != torch.int16 or not voiced_out.is_contiguous():
                 raise ValueError("voiced_out must be a contiguous int16 tensor of pcm's shape")
             voiced = voiced_out
         else:
             voiced = torch.empty_like(x) if compact else None
         vlen = torch.empty((n_utt,), dtype=torch.int32, device=self.device) if compact else None
+        src = torch.empty((n_utt, max_vf), dtype=torch.int32, device=self.device) if index else None
         self._stream()
         check(self.lib.svk_vad_energy(self.ctx, self._ptr(x), self._ptr(offs), self._ptr(lens), stride, longest, n_utt,
                                       fsamp, ring_len, ring_thresh, int(threshold), max_vf, self._ptr(keep),
-                                      self._ptr(seg), self._ptr(nvf), self._ptr(voiced), self._ptr(vlen)), self.ctx)
+                                      self._ptr(seg), self._ptr(nvf), self._ptr(voiced), self._ptr(vlen), self._ptr(src)), self.ctx)
         return {"keep": keep, "n_vad_frames": nvf, "voiced": voiced, "voiced_len": vlen, "seg": seg,
-                "frame_samples": fsamp}
+                "frame_samples": fsamp, "src_frame": src}
 
     def draw_crops(self, n_frames, n_crops=20, crop_frames=80, seed=12345, first_utt=0, bad_count=None,
                    utt_index=None):

@@ -95,8 +95,18 @@ class VerificationPipeline:
                                   padding_ms=c.VAD_PADDING_MS, compact=True)
         return res["voiced"], res["voiced_len"]
 
-    def features(self, pcm, lengths=None):
-        feat, n_frames, _ = self.eng.features(pcm, self.spec, lengths=lengths)
+    def vad(self, pcm, lengths=None, offsets=None, longest=None):
+        """The energy VAD WITHOUT the compaction copy: (voiced_len [n] i32, gather) where gather = (src_frame, frame_samples)
+        lets the front end read the kept frames where they lie (`features(pcm, voiced_len, gather)`); (None, None) when the
+        pipeline runs without VAD.  `voiced()` is the copying form (packed samples, for callers that want them)."""
+        if not self.use_vad:
+            return (None if lengths is None else lengths), None
+        res = self.eng.vad_energy(pcm, self.vad_threshold, fs=c.SAMPLE_RATE, frame_ms=c.VAD_FRAME_MS, padding_ms=c.VAD_PADDING_MS,
+                                  lengths=lengths, offsets=offsets, compact="index", longest=longest)
+        return res["voiced_len"], (res["src_frame"], res["frame_samples"])
+
+    def features(self, pcm, lengths=None, gather=None):
+        feat, n_frames, _ = self.eng.features(pcm, self.spec, lengths=lengths, gather=gather)
         if self.normalize:                                 # utils.CMVN with c.NORMALIZE (utils.py:394-395)
             self.eng.cmvn_(feat, n_frames, variance=True)
         return feat, n_frames
@@ -121,8 +131,8 @@ class VerificationPipeline:
         pcm = self.eng.to_device(pcm)
         crops, cubes = [], []
         for lo, hi in self.chunks(pcm.shape[0]):
-            voiced, vlen = self.voiced(pcm[lo:hi])
-            feat, n_frames = self.features(voiced, vlen)
+            vlen, gather = self.vad(pcm[lo:hi])
+            feat, n_frames = self.features(pcm[lo:hi], vlen, gather)
             if self.crop_rng == "device":
                 idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo, self.bad_clips)
             else:
@@ -169,8 +179,12 @@ class VerificationPipeline:
             return self._embed_overlapped(pcm, spans, emb, first_utt)
         for lo, hi in spans:
             chunk = pcm[lo:hi]
-            voiced, vlen = self.voiced(chunk)
-            feat, n_frames = self.features(voiced, vlen)
+            if return_intermediates:                       # the packed voiced samples are part of what is handed back
+                voiced, vlen = self.voiced(chunk)
+                feat, n_frames = self.features(voiced, vlen)
+            else:
+                vlen, gather = self.vad(chunk)
+                feat, n_frames = self.features(chunk, vlen, gather)
             if crop_idx is None and self.crop_rng == "device":
                 idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed,
                                           first_utt + lo, self.bad_clips)
@@ -200,8 +214,8 @@ class VerificationPipeline:
         def stage(k):
             lo, hi = spans[k]
             with torch.cuda.stream(side):
-                voiced, vlen = self.voiced(pcm[lo:hi])
-                feat, n_frames = self.features(voiced, vlen)
+                vlen, gather = self.vad(pcm[lo:hi])
+                feat, n_frames = self.features(pcm[lo:hi], vlen, gather)
                 idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo,
                                           self.bad_clips)
                 done = torch.cuda.Event()
@@ -285,12 +299,13 @@ class VerificationPipeline:
                 lo, first = hi, q + 1
         return groups, pieces
 
-    def _ragged_front(self, dev_buf, offs, lens, longest, rows, voiced_out=None, spans=None):
-        """VAD -> front end -> CMVN -> crop draw of one batch of clips addressed through offsets / lengths (device slices)
-        into `dev_buf`; `longest`: the batch's longest clip in samples (host int); rows: the clips' global indices (they key
-        the crop draw).  Returns (RAW features [n, T, 40], crop starts [n, 20], CMVN statistics or None): the normalisation
-        (utils.py:382-397) is applied by the cube gather to the 20 x 80 rows the network reads, not to every row of a clip.
-        Nothing here touches the host."""
+    def _ragged_front(self, dev_buf, offs, lens, longest, rows, spans=None):
+        """VAD -> front end -> CMVN statistics -> crop draw of one batch of clips addressed through offsets / lengths (device
+        slices) into `dev_buf`; `longest`: the batch's longest clip in samples (host int); rows: the clips' global indices
+        (they key the crop draw).  Returns (RAW features [n, T, 40], crop starts [n, 20], CMVN statistics or None): the VAD
+        copies nothing (the front end reads the kept frames where they lie, svk_frontend_run's d_src_chunk) and the
+        normalisation (utils.py:382-397) is applied by the cube gather to the 20 x 80 rows the network reads, not to every row
+        of a clip.  Nothing here touches the host."""
         def timed(name, fn):
             if spans is None:
                 return fn()
@@ -301,14 +316,11 @@ class VerificationPipeline:
             spans.append((name, a, b))
             return out
 
-        buf, dev_lens = dev_buf, lens
+        dev_lens, gather = lens, None
         if self.use_vad:
-            res = timed("vad", lambda: self.eng.vad_energy(dev_buf, self.vad_threshold, fs=c.SAMPLE_RATE, frame_ms=c.VAD_FRAME_MS,
-                                                           padding_ms=c.VAD_PADDING_MS, lengths=lens, offsets=offs, compact=True,
-                                                           voiced_out=voiced_out, longest=longest))
-            buf, dev_lens = res["voiced"], res["voiced_len"]
-        feat, n_frames, _ = timed("frontend", lambda: self.eng.features(buf, self.spec, lengths=dev_lens, offsets=offs,
-                                                                         max_frames=self.spec.num_frames(int(longest))))
+            dev_lens, gather = timed("vad", lambda: self.vad(dev_buf, lengths=lens, offsets=offs, longest=longest))
+        feat, n_frames, _ = timed("frontend", lambda: self.eng.features(dev_buf, self.spec, lengths=dev_lens, offsets=offs,
+                                                                         max_frames=self.spec.num_frames(int(longest)), gather=gather))
         stats = timed("cmvn", lambda: self.eng.cmvn_stats(feat, n_frames, variance=True)) if self.normalize else None
         idx = timed("crops", lambda: self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, 0, self.bad_clips,
                                                          utt_index=rows))
@@ -393,7 +405,6 @@ class VerificationPipeline:
             self._rag_pinned = [torch.empty((cap,), dtype=torch.int16).pin_memory() for _ in range(2)]
             self._rag_np = [t.numpy() for t in self._rag_pinned]
             self._rag_dev = [torch.empty((cap,), dtype=torch.int16, device=dev) for _ in range(2)]
-            self._rag_voiced = torch.empty((cap,), dtype=torch.int16, device=dev) if self.use_vad else None
             self._rag_stream = torch.cuda.Stream(device=dev)
             from concurrent.futures import ThreadPoolExecutor
             self._rag_threads = int(os.environ.get("SVK_RAGGED_THREADS", "8"))
@@ -446,9 +457,8 @@ class VerificationPipeline:
             slot = k & 1
             main.wait_event(copied[slot])
             sl = slice(int(starts[k]), int(starts[k + 1]))
-            voiced = self._rag_voiced[:total] if self.use_vad else None
             feat, idx, stats = self._ragged_front(self._rag_dev[slot][:total], offs_dev[sl], lens_dev[sl], int(lens_sorted[sl].max()),
-                                           keys_dev[sl], voiced_out=voiced, spans=spans)
+                                                  keys_dev[sl], spans=spans)
             consumed[slot].record(main)
             # the network runs as soon as a full micro-batch of cubes has gathered: its kernels then cover the host-side
             # packing of the next batch
@@ -462,8 +472,8 @@ class VerificationPipeline:
         """`embed_ragged` for audio that is ALREADY in one buffer: `buf` is one 1-D int16 array holding every clip, clip k at
         samples [offsets[k], offsets[k] + lengths[k]) (offsets multiples of 8: 16-byte aligned; host arrays; clips may
         overlap, e.g. windows over one recording).
-          * a DEVICE tensor: batches are lists of clip indices into that one buffer -- nothing is copied or packed; the VAD
-            writes its voiced samples into one scratch buffer of the same shape, reused by every batch;
+          * a DEVICE tensor: batches are lists of clip indices into that one buffer -- nothing is copied or packed, not even
+            the voiced frames (the VAD hands the front end an index of them);
           * a HOST NumPy array (a loader that decodes into one arena): uploaded as it is, no per-clip packing on the host
             (the list form, `embed_ragged`, is bound by that packing: ~20 GB/s of host copy against 54 GB/s of pageable
             upload on the GPU box).  Arenas larger than two batches go up in pieces of ~`max_batch_samples` on a side
@@ -535,7 +545,6 @@ class VerificationPipeline:
             worker = threading.Thread(target=upload, daemon=True)
             worker.start()
             buf = dev_buf
-        voiced = torch.empty_like(buf) if self.use_vad else None
         # with pieces still travelling the network runs per micro-batch of gathered cubes (it covers the next piece's upload);
         # otherwise over micro-batches as large as the main path's
         step = self.micro_batch if len(groups) > 1 else max(self.micro_batch, 4096)
@@ -551,7 +560,7 @@ class VerificationPipeline:
                 main.wait_event(events[g])
                 seen = g
             sl = slice(pos, pos + len(ids))
-            feat, idx, stats = self._ragged_front(buf, offs_dev[sl], lens_dev[sl], longest, keys_dev[sl], voiced_out=voiced, spans=spans)
+            feat, idx, stats = self._ragged_front(buf, offs_dev[sl], lens_dev[sl], longest, keys_dev[sl], spans=spans)
             ring.push(feat, idx, stats)
             pos += len(ids)
         if worker is not None:
@@ -618,8 +627,8 @@ class VerificationPipeline:
                     raise failure[0]
                 main.wait_event(copied[k])
                 chunk = staged[k & 1][:hi - lo]
-                voiced, vlen = self.voiced(chunk)
-                feat, n_frames = self.features(voiced, vlen)
+                vlen, gather = self.vad(chunk)
+                feat, n_frames = self.features(chunk, vlen, gather)
                 idx = self.eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, self.crop_seed, first_utt + lo,
                                           self.bad_clips)
                 emb[lo:hi] = self.embed_features(feat, idx)

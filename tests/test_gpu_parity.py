@@ -463,6 +463,62 @@ def test_cmvn_batched_ragged(eng, clip_paths):
 
 
 # ---- VAD: bit-exact ---------------------------------------------------------------------------------
+def test_front_end_reads_voiced_frames_through_the_index(eng, clip_paths):
+    """svk_vad_energy's index output (d_src_frame) + svk_frontend_run's gathered input (d_src_chunk): the front end reads the
+    kept 30 ms frames where they lie -- the same keep mask and lengths as the copying form, src_frame = the kept frames in
+    order, and BIT-IDENTICAL features to those computed from the compacted copy (same samples, same arithmetic); fixed-length
+    and ragged batches, all three VAD paths, both fused configurations, with pre-emphasis (its circular wrap reads the LAST
+    voiced sample), a silent clip, a clip that is kept whole and a 70 s clip."""
+    from speaker_verification_amd import _lib
+    from speaker_verification_amd.engine import spec_from_seconds
+    thr = c.VAD_ENERGY_THRESHOLD
+    specs = (spec_from_seconds(16000, 0.025, 0.01, 1024, 40, 40, _lib.OUT_LMFE, preemph=True, preemph_cof=0.98, input_scale=1.0 / 32768.0),
+             spec_from_seconds(16000, 0.020, 0.01, 512, 40, 13, _lib.OUT_MFCC))
+    pcm, _ = synth.corpus(3, 3)
+    pcm[4] = 0                                                              # a silent clip: nothing kept
+    pcm[5] = synth.noise_clip(5)                                            # loud throughout: every frame kept
+    dev = eng.to_device(pcm)
+    res_c = eng.vad_energy(dev, thr, compact=True)
+    res_i = eng.vad_energy(dev, thr, compact="index")
+    assert res_i["voiced"] is None and torch.equal(res_c["keep"], res_i["keep"]) and torch.equal(res_c["voiced_len"], res_i["voiced_len"])
+    keep, src = res_i["keep"].cpu().numpy(), res_i["src_frame"].cpu().numpy()
+    vlen = res_i["voiced_len"].cpu().numpy()
+    assert vlen[4] == 0 and vlen[5] == keep.shape[1] * res_i["frame_samples"]
+    for u in range(pcm.shape[0]):
+        kept = np.nonzero(keep[u])[0]
+        np.testing.assert_array_equal(src[u, :kept.size], kept)
+    for spec in specs:
+        f_c, n_c, _ = eng.features(res_c["voiced"], spec, lengths=res_c["voiced_len"])
+        f_i, n_i, _ = eng.features(dev, spec, lengths=res_i["voiced_len"], gather=(res_i["src_frame"], res_i["frame_samples"]))
+        assert torch.equal(n_c, n_i) and torch.equal(f_c, f_i), spec.key()
+        assert int(n_i[4]) == 0 and not bool(f_i[4].any())
+    # ragged: clips of 1.3 .. 70 s back to back at 16-byte-aligned offsets
+    rng = np.random.default_rng(23)
+    lens = np.array([20800, 48000, 1120000, 64007, 333333, 9000], dtype=np.int32)
+    clips = [np.tile(synth.speaker_clip(7 + k, k), -(-int(n) // 48000))[:n] for k, n in enumerate(lens)]
+    slots = (lens.astype(np.int64) + 7) // 8 * 8
+    offs = np.concatenate([[0], np.cumsum(slots)[:-1]]).astype(np.int64)
+    buf = np.zeros(int(slots.sum()), dtype=np.int16)
+    for o, x in zip(offs, clips):
+        buf[o:o + x.size] = x
+    dbuf = eng.to_device(buf)
+    r_c = eng.vad_energy(dbuf, thr, lengths=lens, offsets=offs, compact=True)
+    r_i = eng.vad_energy(dbuf, thr, lengths=lens, offsets=offs, compact="index")
+    assert torch.equal(r_c["keep"], r_i["keep"]) and torch.equal(r_c["voiced_len"], r_i["voiced_len"])
+    spec = specs[0]
+    T = spec.num_frames(int(lens.max()))
+    f_c, n_c, _ = eng.features(r_c["voiced"], spec, lengths=r_c["voiced_len"], offsets=offs, max_frames=T)
+    f_i, n_i, _ = eng.features(dbuf, spec, lengths=r_i["voiced_len"], offsets=offs, max_frames=T, gather=(r_i["src_frame"], r_i["frame_samples"]))
+    assert torch.equal(n_c, n_i) and torch.equal(f_c, f_i) and int(n_i.max()) > 3000
+    # what the gathered form is not built for is refused, not silently computed from something else
+    with pytest.raises(_lib.SvkError):
+        eng.features(dev.to(torch.float32), specs[0], lengths=res_i["voiced_len"], gather=(res_i["src_frame"], res_i["frame_samples"]))
+    with pytest.raises(_lib.SvkError):
+        eng.features(dev, specs[0], lengths=res_i["voiced_len"], gather=(res_i["src_frame"], 484))
+    with pytest.raises(ValueError):
+        eng.features(dev, specs[0], gather=(res_i["src_frame"], res_i["frame_samples"]))
+
+
 def test_cmvn_folded_into_the_cube_gather(eng, clip_paths):
     """svk_cmvn_stats + svk_cube_gather_cmvn (utils.py:382-397 CMVN feeding utils.py:351-379 FeatureCube in one pass over the
     20 x 80 rows the cube holds) against svk_cmvn in place followed by svk_cube_gather: bit-identical on every CMVN path,
