@@ -7,7 +7,7 @@ import os
 import sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
-KEEP = ("c3d2_", "frontend_kernel", "cosine", "cmvn", "vad_kernel", "cube_", "draw_crops", "inv_norm", "decimate",
+KEEP = ("c3d2_", "frontend_kernel", "cosine", "cmvn", "vad_", "cube_", "draw_crops", "inv_norm", "decimate",
         "resample_kernel", "spectrum_", "mel_features", "roc", "l2_dist", "fc5_")
 for path in glob.glob(os.path.join(root, "**", "*_kernel_trace.csv"), recursive=True):
     os.remove(path)

@@ -29,6 +29,8 @@ rp --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_c3d2 --
 rp --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_c3d2 -- python3 $root/bench.py --c3d2-only > $out/pmc_write_c3d2.log 2>&1
 bash $root/tools/pmc_stalls.sh c3d2 bench.py --c3d2-only
 cd /tmp
+echo "[5b] the reference's file-driven entry points (create_speaker_models() + evaluate()) under the kernel trace"
+rp --kernel-trace --stats --output-format csv -d $out/prof_evaluate -- python3 $root/tools/profile_evaluate.py > $out/prof_evaluate.log 2>&1
 echo "[6/6] the bench itself + the stage-level kernels"
 python3 $root/bench.py --steps 3 --warmup 1 > $out/bench_final.json 2> $out/bench_final.err
 python3 $root/bench.py --stages-only > $out/stages_final.json 2> $out/stages_final.err

@@ -54,6 +54,17 @@ def main():
         with open(os.path.join(out_dir, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as fh:
             csv.writer(fh).writerows(keep)
         print("wrote", f"profiles/{tag}_bench_kernel_stats.csv", len(keep) - 1, "kernels")
+    ev = sorted(glob.glob(os.path.join(REPO, "gpurun_out", "prof_evaluate", "**", "*_kernel_stats.csv"), recursive=True),
+                key=os.path.getmtime)
+    if ev:                                                   # tools/profile_evaluate.py: every kernel create_speaker_models() + evaluate() ran
+        rows = list(csv.reader(open(ev[-1])))
+        for r in rows[1:]:
+            if len(r[0]) > 160:
+                r[0] = r[0][:157] + "..."
+        with open(os.path.join(out_dir, f"{tag}_evaluate_kernel_stats.csv"), "w", newline="") as fh:
+            csv.writer(fh).writerows(rows)
+        bad = [r[0] for r in rows[1:] if any(k in r[0] for k in ("ck::", "naive_conv", "miopen", "MIOpen", "Cijk_")) or ("at::native" in r[0] and "conv" in r[0].lower())]
+        print("wrote", f"profiles/{tag}_evaluate_kernel_stats.csv", len(rows) - 1, "kernels;", "framework convolution / GEMM rows:", bad or "none")
     summary = defaultdict(lambda: defaultdict(list))
     meta = {}
     # (c3d2_1 .. c3d2_3: the three stall-composition passes over `bench.py --c3d2-only`; they carry SQ_INSTS_MFMA, which
