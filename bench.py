@@ -684,10 +684,11 @@ def cpu_child(sample_dir):
     r, _ = rate(lambda: [_cpu_features(i) for i in range(n1)], n1)
     out["stages"]["frontend_1core"] = {"utt_per_s": r, "clips": n1, "cores": 1}
     ctx = mp.get_context("fork")               # this process has never touched the GPU: fork is safe
-    with ctx.Pool(cores) as pool:
-        pool.map(_cpu_count_frames, range(min(n, 2 * cores)), chunksize=1)            # warm the workers
-        r, _ = rate(lambda: pool.map(_cpu_count_frames, range(n), chunksize=max(1, n // (8 * cores))), n)
-        out["stages"]["frontend_allcores"] = {"utt_per_s": r, "clips": n, "cores": cores, "how": "multiprocessing.Pool"}
+    n_par = max(1, int(round(quota))) if quota else cores     # "all cores" = what the container is granted
+    with ctx.Pool(n_par) as pool:
+        pool.map(_cpu_count_frames, range(min(n, 2 * n_par)), chunksize=1)            # warm the workers
+        r, _ = rate(lambda: pool.map(_cpu_count_frames, range(n), chunksize=max(1, n // (8 * n_par))), n)
+        out["stages"]["frontend_allcores"] = {"utt_per_s": r, "clips": n, "cores": n_par, "how": "multiprocessing.Pool"}
     # ---- the whole per-utterance chain (batch 1, like evaluation.py:113-121), one single-threaded worker per slot, at
     # several pool sizes: with SMT and memory-bound batch-1 convolutions "one worker per hardware thread" is not the
     # fastest use of the host (1.6 utt/s per thread at 256 workers vs 115 on one).  `value` = the best. ----
@@ -736,7 +737,7 @@ def cpu_child(sample_dir):
             calls += 1
         return per_call * calls / (time.perf_counter() - t0), per_call * calls
 
-    for threads in (1, cores):
+    for threads in (1, n_par):
         torch.set_num_threads(threads)
         tag = "1thread" if threads == 1 else "allthreads"
         k = [0]
