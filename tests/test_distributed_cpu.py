@@ -169,6 +169,25 @@ def test_bench_self_launch_two_ranks():
         assert rec["backend"] == ("gloo" if n > 1 else None)
 
 
+def test_bench_selftest_under_torch_distributed_run():
+    """The driver's launch form for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...`): every process is one rank and reads RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* from the environment -- no self-launch; rank 0 alone prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(repo, "bench.py"), "--gpus", "4", "--selftest"],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert proc.returncode == 0, proc.stderr.decode()[-2000:]
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, proc.stdout.decode()
+    rec = json.loads(lines[0])
+    assert rec["ranks_seen"] == 4 and rec["n_gpus"] == 4 and rec["gathered_ok"] and rec["max_over_ranks"] == 4 and rec["backend"] == "gloo"
+
+
 def test_bench_launcher_reports_a_failed_rank(tmp_path):
     """A rank that dies makes the launcher exit non-zero (it never re-execs itself: plain child processes)."""
     import subprocess

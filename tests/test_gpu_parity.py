@@ -1945,6 +1945,33 @@ def test_bench_four_ranks_uneven_shards_on_one_gpu():
     assert four["value"] == pytest.approx(20003 / (four["ms_per_step"] * 1e-3), rel=1e-6)
 
 
+def test_bench_under_torch_distributed_run():
+    """The launch form the driver uses for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...` -- this process is then ONE rank (RANK / LOCAL_RANK / WORLD_SIZE from the
+    environment, no self-launch); here with `--backend gloo` so that both ranks can share this one GPU.  One JSON line from
+    rank 0, the same numbers as the self-launched run."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    common = ["--corpus", "5001", "--micro-batch", "1024", "--steps", "1", "--warmup", "0", "--no-extras"]
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                           "127.0.0.1", "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--backend", "gloo"]
+                          + common, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert proc.returncode == 0, proc.stderr.decode()[-2000:]
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, proc.stdout.decode()[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["ranks_seen"] == 2 and rec["n_gpus"] == 2 and rec["config"]["clips_per_rank"] == 2501
+    one = _bench_line(common)
+    assert rec["eer"]["eer"] == one["eer"]["eer"] and rec["eer"]["auc"] == one["eer"]["auc"]
+
+
 def test_bench_parity_leg_at_the_trained_operating_point():
     """bench.py's CPU-oracle leg (cpu_baseline + parity) on the first 492 clips (four speakers) of a 5 001-clip corpus with
     the committed trained checkpoint: the production path's embeddings against the oracle's from the same PCM, and the EER
