@@ -6,22 +6,26 @@
 One STEP = one pass of the whole path over BASELINE.json's corpus, 148 642 synthetic 3 s / 16 kHz clips,
 sharded over the N ranks (rank r owns the contiguous range of ceil(148 642 / N) clips; STRONG scaling:
 the total is fixed), PCM resident in HBM:
-    int16 PCM -> energy VAD -> fused pre-emphasis + log-mel(40) front end -> CMVN -> 20x80x40 cube
-    -> C3D2 embedding (f32 MFMA, seven libsvk kernels: svk_c3d2_stage1 / stage2 / conv31 / conv32 / conv41 / conv42 / fc5)
-    -> all-gather of the [clips,128] shards (RCCL) -> 4 874 x 40 cosine score matrix (MFMA).
+    int16 PCM -> energy VAD (an index of the voiced frames) -> fused pre-emphasis + log-mel(40) front end reading through it
+    -> CMVN -> 20x80x40 cube (never materialised) -> C3D2 embedding (f32 MFMA, seven libsvk kernels: svk_c3d2_stage1 / stage2 /
+    conv31 / conv32t / conv41 / conv42 / fc5) -> all-gather of the [clips,128] shards (RCCL) -> 4 874 x 40 cosine score matrix (MFMA).
 value = 148 642 clips x steps / max-over-ranks time.  Nothing in the step is a framework operator: torch supplies
-device memory, streams, events and torch.distributed.
+device memory, streams, events and torch.distributed.  Weights: the committed checkpoint trained on synthetic speakers that
+are not in the corpus (speaker_verification_amd/checkpoints/c3d2_synth.pt; EER 1.7 % on the verification block), or with
+--random-init the seeded random-init network of rounds 1 - 3 (EER ~ 0.5).
 
 Launch: with WORLD_SIZE in the environment (torch.distributed.run) this process is one rank; without it
 and --gpus N > 1 this process only starts N fresh rank processes of itself (RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), polls them, ends the others when one dies, relays rank 0's JSON line.
 
 The JSON line also carries
-  roofline      -- the dominant kernel, c3d2_stage1w_kernel (cube + conv1_1 + conv1_2 + pool1, ~43 % of the step), bound
+  roofline      -- the dominant kernel, c3d2_stage1w_kernel (cube + conv1_1 + conv1_2 + pool1, ~44 % of the step), bound
                    MFMA: frac = ISSUED matrix work (SQ_INSTS_MFMA per cube from the committed PMC pass x 2 048 FLOP x
                    cubes per launch) / the HIP-event duration of each launch in the timed region / 157.3 TFLOP/s -- a
                    share of the f32 matrix pipe's issue slots, never above 1; algorithmic_frac = SURVEY 8(d)'s direct-form
                    multiply-adds instead (what Winograd F(2,3) along depth saves shows as algorithmic_frac > frac);
+                   counters_from / stale: what the committed counters were collected from (sha256 of the kernel sources,
+                   of libsvk.so, git HEAD) and whether that differs from the sources this run uses;
   roofline_network -- the same two fractions for EVERY network kernel (stage2 = conv2_1 + conv2_2, conv3_1, conv3_2,
                    conv4_1, conv4_2, fc5) with each one's share of the step; roofline_stage2 = its stage2 row;
                    valu_per_mfma / fp32_lanes_busy: the other vector instructions per MFMA (committed SQ_INSTS_VALU)
@@ -31,13 +35,17 @@ The JSON line also carries
                    ran (VAD-shortened clips) over their HIP-event durations;
   roofline_e2e  -- the whole step against the f32 matrix peak: frac from the issued MFMA work per utterance,
                    algorithmic_frac from SURVEY 8(d)'s 676.6 MFLOP (ceiling 232 k utt/s/GPU);
-  ranks_seen / backend / allgather_us / per_rank_ms -- what torch.distributed reports, the HIP-event time of the
-                   embedding all-gather, every rank's own step time;
+  ranks_seen / backend / allgather_us / per_rank_ms / slowest_rank / fastest_rank / scaling_efficiency_vs -- what
+                   torch.distributed reports, the HIP-event time of the embedding all-gather, every rank's own step time,
+                   N x the committed 1-GPU value for reference;
   frontend_A, cosine_mfma, stage_kernels, ingest_resample, ragged -- the other hand-written kernels / workloads on their own;
   cpu_baseline  -- the CPU oracle (NumPy/torch-CPU restatement of the reference, kind "port") timed in a
                    fresh child process on rank 0, N = 1 only: the per-utterance chain on single-threaded workers at
-                   three pool sizes (`value` = the best), plus 1-core / all-core and batch-1 / batch-64 variants per stage;
-  parity        -- the PRODUCTION path (libsvk end to end) vs the oracle on that sample + EER of the 4 874 x 40 matrix.
+                   pool sizes around the container's CPU quota (`value` = the best; every worker warmed before the clock
+                   starts; chain and pair-by-pair scoring timed separately), plus 1-core / all-core and batch-1 / batch-64
+                   variants per stage;
+  parity        -- the PRODUCTION path (libsvk end to end) vs the oracle on that sample: embeddings, scores, the EER on
+                   both sides (eer_equal) + the EER of the 4 874 x 40 matrix through host sklearn, svk_roc_eer and the oracle.
 """
 import argparse
 import json
@@ -920,7 +928,7 @@ def main():
             if pipe.normalize:
                 eng.cmvn_(feat, n_frames, variance=True)
             idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, lo_r + lo, pipe.bad_clips)
-            local[lo:hi] = pipe.embed_features(feat, idx)      # cube (as the first layer's patch matrix) -> C3D2
+            local[lo:hi] = pipe.embed_features(feat, idx)      # feature rows + crop starts -> the seven network kernels
         if record:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
