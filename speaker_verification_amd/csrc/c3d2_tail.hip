@@ -141,7 +141,16 @@ __global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const Tail
   __shared__ int q_next;
   const int lane = threadIdx.x & 63, nt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
-  const float b = p.bias[16 * nt + i], sl = p.slope[16 * nt + i];
+  // The MFMA's M side is the CHANNEL (A = the streamed weight fragment), its N side the cube (B = the staged activations): a lane
+  // ends up with channels 16 nt + 4 kk .. + 3 of cube i -- 16 contiguous bytes of the chunked output, one 16-byte store per
+  // (tile, depth) where the other order (M = cube) issued four 4-byte stores (round 4: 72 -> 18 store instructions per item and
+  // wave in conv4_1; the same products in the same order: bit-identical)
+  f32x4 bias4, slope4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    bias4[r] = p.bias[16 * nt + 4 * kk + r];
+    slope4[r] = p.slope[16 * nt + 4 * kk + r];
+  }
   const int n_groups = (p.n_utt + GROUP - 1) / GROUP;
   const int n_items = n_groups * G::ITEMS_PER_GROUP;
 
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const Tail
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[t][k] = k == 1 ? (f32x4){b, b, b, b} : (f32x4){0.f, 0.f, 0.f, 0.f};   // a1 carries the bias
+      for (int k = 0; k < 4; ++k) acc[t][k] = k == 1 ? bias4 : (f32x4){0.f, 0.f, 0.f, 0.f};   // a1 carries the bias
 #pragma unroll 1
     for (int ph = 0; ph < G::NPH; ++ph) {
       TAIL_STAMP(tp0);
@@ -254,12 +263,12 @@ __global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const Tail
         __builtin_amdgcn_sched_barrier(0);   // those loads are issued in front of this step's MFMAs
         const f32x2 bv = b0;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][0], bv[0], acc[t][k], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[0], a[t][0], acc[t][k], 0, 0, 0);
         // second K pair; tile t's fragment of the NEXT step is read as soon as this step's last MFMA on it has issued
         // (nine MFMAs = 288 cycles before its first use: no second fragment set in registers)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          acc[t][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][1], bv[1], acc[t][k], 0, 0, 0);
+          acc[t][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[1], a[t][1], acc[t][k], 0, 0, 0);
           if (s + 1 < G::STEPS) {
             const int s1 = s + 1, k1 = s1 & 3, tap1 = (s1 >> 2) % L::TAPS, sub1 = (s1 >> 2) / L::TAPS;
             __builtin_amdgcn_sched_barrier(0);
@@ -284,25 +293,28 @@ __global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const Tail
       // (the phase loop above ended with a barrier: q_next's previous value has been read by every thread)
       if (threadIdx.x == 0) q_next = (int)q_ticket + (int)gridDim.x;
     }
-    // ---- output transform, PReLU, stores: rows 4 kk + r = cube, column i = channel 16 nt + i ----
+    // ---- output transform, PReLU, stores: rows 4 kk + r = channel 16 nt + 4 kk + r, column i = cube ----
     {
       const int g = item / G::ITEMS_PER_GROUP, rem = item - g * G::ITEMS_PER_GROUP;
       const int P = rem / L::BLOCKS, blk = rem - P * L::BLOCKS;
       const int n_here = min(GROUP, p.n_utt - GROUP * g);
-      // chunked output: [cube][depth][chunk = 2 nt + (i >> 3)][pixel][i & 7]
+      // chunked output: [cube][depth][chunk = 2 nt + (kk >> 1)][pixel][4 (kk & 1) .. + 3]
       float* const o = p.out + (int64_t)g * GROUP * G::OUT_CUBE +
                        ((int64_t)(2 * P) * G::OUT_CHUNKS + 2 * nt) * (L::PIX_OUT * 8);   // wave-uniform
-      const int olane = 4 * kk * (int)G::OUT_CUBE + (i >> 3) * (L::PIX_OUT * 8) + (i & 7);
+      const int olane = i * (int)G::OUT_CUBE + (kk >> 1) * (L::PIX_OUT * 8) + 4 * (kk & 1);
+      if (i < n_here) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const f32x4 y0 = acc[t][0] + acc[t][1] + acc[t][2], y1 = acc[t][1] - acc[t][2] - acc[t][3];
-        const int opix = L::out_pix(t, blk) * 8;
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 y0 = acc[t][0] + acc[t][1] + acc[t][2], y1 = acc[t][1] - acc[t][2] - acc[t][3];
+          const int opix = L::out_pix(t, blk) * 8;
+          f32x4 o0, o1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (4 * kk + r < n_here) {
-            o[olane + r * (int)G::OUT_CUBE + opix] = prelu_t<SLOPE01>(y0[r], sl);
-            o[olane + r * (int)G::OUT_CUBE + opix + G::OUT_CHUNKS * L::PIX_OUT * 8] = prelu_t<SLOPE01>(y1[r], sl);
+          for (int r = 0; r < 4; ++r) {
+            o0[r] = prelu_t<SLOPE01>(y0[r], slope4[r]);
+            o1[r] = prelu_t<SLOPE01>(y1[r], slope4[r]);
           }
+          *reinterpret_cast<f32x4*>(o + olane + opix) = o0;
+          *reinterpret_cast<f32x4*>(o + olane + opix + G::OUT_CHUNKS * L::PIX_OUT * 8) = o1;
         }
       }
     }
