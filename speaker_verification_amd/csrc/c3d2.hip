@@ -642,12 +642,17 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
       G[nt][2][kw] = 0.5f * ((g0 + g2) - g1);
       G[nt][3][kw] = g2;
     }
-  float b[2], sl[2];
+  // M = channel (A = the weights G), N = output column w' (B = the transformed fragments): a lane ends up with channels
+  // 16 nt + 4 kk .. + 3 of column i -- 16 contiguous bytes of the channels-last output: one 16-byte store per (N tile, depth)
+  // where M = position issued four 4-byte stores (round 4; the same products in the same order: bit-identical)
+  f32x4 b4[2], sl4[2];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    b[nt] = p.bias[16 * nt + i];
-    sl[nt] = p.slope[16 * nt + i];
-  }
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      b4[nt][r] = p.bias[16 * nt + 4 * kk + r];
+      sl4[nt][r] = p.slope[16 * nt + 4 * kk + r];
+    }
   constexpr int BLOCKS = S2_H / C21W_TH;   // 9 row blocks per cube
   const int n_items = p.n_utt * BLOCKS;
   // Work items come from a device-wide counter, not from a fixed stride: of the two workgroups that share a CU the older
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[nt][k] = k == 1 ? (f32x4){b[nt], b[nt], b[nt], b[nt]} : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 4; ++k) acc[nt][k] = k == 1 ? b4[nt] : (f32x4){0.f, 0.f, 0.f, 0.f};
       f32x4 x[4];
       f32x2 t[4][2];
 #pragma unroll
@@ -728,34 +733,33 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              acc[nt][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e >> 1][e & 1], G[nt][k][kw][e], acc[nt][k], 0, 0, 0);
+              acc[nt][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[nt][k][kw][e], t[k][e >> 1][e & 1], acc[nt][k], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // rows 4 kk + r = output column w'; column i = channel 16 nt + i; depths 2 P and 2 P + 1
+      // rows 4 kk + r = channel 16 nt + 4 kk + r; column i = output column w' (15 is the dummy); depths 2 P and 2 P + 1
       // (wave-uniform 64-bit bases + one 32-bit lane offset + immediates: the stores need no per-store address VALU)
       float* const o0 = p.out + (((int64_t)u * A2_D + 2 * P) * S2_H + hb + hl) * (A2_W * 32);
       float* const o1 = o0 + (int64_t)S2_H * (A2_W * 32);
-      const int lo = 4 * kk * 32 + i;
+      const int lo = i * 32 + 4 * kk;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         // y0 = (a0 + a1) + a2, y1 = (a1 - a2) - a3 as packed adds (every VALU instruction here is paid in MFMA slots)
-        f32x2 y0[2], y1[2];
+        f32x4 y0, y1;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const f32x2 a0 = hf ? __builtin_shufflevector(acc[nt][0], acc[nt][0], 2, 3) : __builtin_shufflevector(acc[nt][0], acc[nt][0], 0, 1);
           const f32x2 a1 = hf ? __builtin_shufflevector(acc[nt][1], acc[nt][1], 2, 3) : __builtin_shufflevector(acc[nt][1], acc[nt][1], 0, 1);
           const f32x2 a2 = hf ? __builtin_shufflevector(acc[nt][2], acc[nt][2], 2, 3) : __builtin_shufflevector(acc[nt][2], acc[nt][2], 0, 1);
           const f32x2 a3 = hf ? __builtin_shufflevector(acc[nt][3], acc[nt][3], 2, 3) : __builtin_shufflevector(acc[nt][3], acc[nt][3], 0, 1);
-          y0[hf] = pk_add(pk_add(a0, a1), a2);
-          y1[hf] = pk_sub(pk_sub(a1, a2), a3);
+          const f32x2 s0 = pk_add(pk_add(a0, a1), a2), s1 = pk_sub(pk_sub(a1, a2), a3);
+          y0[2 * hf] = prelu_t<SLOPE01>(s0[0], sl4[nt][2 * hf]);
+          y0[2 * hf + 1] = prelu_t<SLOPE01>(s0[1], sl4[nt][2 * hf + 1]);
+          y1[2 * hf] = prelu_t<SLOPE01>(s1[0], sl4[nt][2 * hf]);
+          y1[2 * hf + 1] = prelu_t<SLOPE01>(s1[1], sl4[nt][2 * hf + 1]);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int wq = 4 * kk + r;
-          if (wq < A2_W) {
-            o0[lo + r * 32 + 16 * nt] = prelu_t<SLOPE01>(y0[r >> 1][r & 1], sl[nt]);
-            o1[lo + r * 32 + 16 * nt] = prelu_t<SLOPE01>(y1[r >> 1][r & 1], sl[nt]);
-          }
+        if (i < A2_W) {
+          *reinterpret_cast<f32x4*>(o0 + lo + 16 * nt) = y0;
+          *reinterpret_cast<f32x4*>(o1 + lo + 16 * nt) = y1;
         }
       }
     }
@@ -988,8 +992,15 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
       G[2][kw][ch] = 0.5f * ((g0 + g2) - g1);
       G[3][kw][ch] = g2;
     }
-  const float b = p.bias[16 * nt + i], sl = p.slope[16 * nt + i];
-  // A row of this lane: position m = i -> (row hl = m / 5, column w' = m % 5); m = 15 is a dummy (reads position 14)
+  // M = channel (A = the weights G), N = position (B = the transformed fragments): a lane ends up with channels 16 nt + 4 kk .. + 3
+  // of ONE position -- 16 contiguous bytes of the chunked output (round 4, as in c3d2_conv21w_kernel; bit-identical)
+  f32x4 b4, sl4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    b4[r] = p.bias[16 * nt + 4 * kk + r];
+    sl4[r] = p.slope[16 * nt + 4 * kk + r];
+  }
+  // B column of this lane: position m = i -> (row hl = m / 5, column w' = m % 5); m = 15 is a dummy (reads position 14)
   const int mi = i < 15 ? i : 14;
   const float* const a0 = reg + C31_PIXF * ((mi / 5) * 7 + mi % 5) + 4 * kk;
   const int n_items = p.n_utt * 5;
@@ -1035,7 +1046,7 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
       const float* ap = a0 + 2 * C31_PLANE * P;
       f32x4 acc[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = k == 1 ? (f32x4){b, b, b, b} : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < 4; ++k) acc[k] = k == 1 ? b4 : (f32x4){0.f, 0.f, 0.f, 0.f};
       f32x4 x[4];
       f32x2 t[4][2];
 #pragma unroll
@@ -1056,36 +1067,31 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e >> 1][e & 1], G[k][kw][ch][e], acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[k][kw][ch][e], t[k][e >> 1][e & 1], acc[k], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // rows 4 kk + r = position m -> (row 3 rb + m / 5, column m % 5); column i = channel 16 nt + i; depths 2 P, 2 P + 1
+      // rows 4 kk + r = channel 16 nt + 4 kk + r; column i = position m -> (row 3 rb + m / 5, column m % 5); depths 2 P, 2 P + 1.
+      // Chunked, column-major output [d][chunk = 2 nt + (kk >> 1)][w][h][8]: the lane's position offset (m % 5) * 15 + m / 5 is a
+      // per-lane constant (the M = position order needed a byte table per store)
       float* const o = p.out + (((int64_t)u * 10 + 2 * P) * 8 + 2 * nt) * (5 * 15 * 8);   // wave-uniform
-      const int olane = (i >> 3) * (5 * 15 * 8) + (i & 7) + 3 * rb * 8;
+      const int olane = (kk >> 1) * (5 * 15 * 8) + 4 * (kk & 1) + ((mi % 5) * 15 + mi / 5 + 3 * rb) * 8;
       constexpr int ostep = 8 * 5 * 15 * 8;   // one output depth further
+      f32x4 y0, y1;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const f32x2 c0 = hf ? __builtin_shufflevector(acc[0], acc[0], 2, 3) : __builtin_shufflevector(acc[0], acc[0], 0, 1);
         const f32x2 c1 = hf ? __builtin_shufflevector(acc[1], acc[1], 2, 3) : __builtin_shufflevector(acc[1], acc[1], 0, 1);
         const f32x2 c2 = hf ? __builtin_shufflevector(acc[2], acc[2], 2, 3) : __builtin_shufflevector(acc[2], acc[2], 0, 1);
         const f32x2 c3 = hf ? __builtin_shufflevector(acc[3], acc[3], 2, 3) : __builtin_shufflevector(acc[3], acc[3], 0, 1);
-        const f32x2 y0 = pk_add(pk_add(c0, c1), c2), y1 = pk_sub(pk_sub(c1, c2), c3);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int m = 4 * kk + 2 * hf + q;
-          if (m < 15) {
-            // column m % 5 outermost, then row m / 5:
-            // (m % 5) * 15 + m / 5 for m = 4 kk + r as byte kk of a per-r constant (a division per store cost 10 % of the kernel)
-            int kk_e = kk;
-            asm volatile("" : "+v"(kk_e));   // (keeps the eight per-lane offsets out of registers this kernel spills)
-            auto cpos = [](int m2) { return (m2 % 5) * 15 + m2 / 5; };
-            const unsigned tab = (unsigned)cpos(2 * hf + q) | ((unsigned)cpos(4 + 2 * hf + q) << 8) |
-                                 ((unsigned)cpos(8 + 2 * hf + q) << 16) | ((unsigned)cpos(12 + 2 * hf + q < 15 ? 12 + 2 * hf + q : 0) << 24);
-            const int opos = (int)((tab >> (8 * kk_e)) & 255u) * 8;
-            o[olane + opos] = prelu_t<SLOPE01>(y0[q], sl);
-            o[ostep + olane + opos] = prelu_t<SLOPE01>(y1[q], sl);
-          }
-        }
+        const f32x2 s0 = pk_add(pk_add(c0, c1), c2), s1 = pk_sub(pk_sub(c1, c2), c3);
+        y0[2 * hf] = prelu_t<SLOPE01>(s0[0], sl4[2 * hf]);
+        y0[2 * hf + 1] = prelu_t<SLOPE01>(s0[1], sl4[2 * hf + 1]);
+        y1[2 * hf] = prelu_t<SLOPE01>(s1[0], sl4[2 * hf]);
+        y1[2 * hf + 1] = prelu_t<SLOPE01>(s1[1], sl4[2 * hf + 1]);
+      }
+      if (i < 15) {
+        *reinterpret_cast<f32x4*>(o + olane) = y0;
+        *reinterpret_cast<f32x4*>(o + ostep + olane) = y1;
       }
     }
     __syncthreads();
