@@ -163,13 +163,15 @@ def corpus_device(n_clips, device, first_clip=0, utts_per_speaker=123, n_samples
 # --------------------------------------------------------------------------------------
 # A small file tree in the layout the reference's file-driven entry points read
 # --------------------------------------------------------------------------------------
-def write_verification_tree(root, n_speakers=3, utts_per_speaker=3, n_samples=24000, model_seed=11, n_labels=100):
+def write_verification_tree(root, n_speakers=3, utts_per_speaker=3, n_samples=24000, model_seed=11, n_labels=100, checkpoint=None):
     """Everything `evaluation.evaluate()` / `model.create_speaker_models()` look for
     (/root/reference/evaluation.py:90-101, model.py:351-361), synthetic and seeded:
         root/50_first_ids.txt                       one relative WAV path per line
         root/50_first_ids.npy (+ .json)             {speaker id: class index}
         root/Models/model_14_percent_best_so_far.pt {"state_dict": seeded C3D2 weights}
         root/data/idNNNNN/rec/0000U.wav             16 kHz mono 16-bit `speaker_clip`s
+    `checkpoint`: a {"state_dict": ...} file (e.g. speaker_verification_amd/checkpoints/c3d2_synth.pt, loaded weights-only)
+    whose weights go into the tree instead of the seeded random-init ones.
     Returns (data_dir, relative paths, state_dict)."""
     import json
     import os
@@ -196,8 +198,11 @@ def write_verification_tree(root, n_speakers=3, utts_per_speaker=3, n_samples=24
     np.save(os.path.join(root, "50_first_ids.npy"), table, allow_pickle=True)
     with open(os.path.join(root, "50_first_ids.json"), "w") as fh:
         json.dump(table, fh)
-    model = seeded_model(model_seed, n_labels=n_labels)
-    state = perturb_inference_state(model.state_dict(), model_seed + 1)
+    if checkpoint is not None:
+        state = torch.load(checkpoint, map_location="cpu", weights_only=True)["state_dict"]
+    else:
+        model = seeded_model(model_seed, n_labels=n_labels)
+        state = perturb_inference_state(model.state_dict(), model_seed + 1)
     os.makedirs(os.path.join(root, "Models"), exist_ok=True)
     torch.save({"state_dict": state}, os.path.join(root, "Models", "model_14_percent_best_so_far.pt"))
     return data, rel, state

@@ -1322,6 +1322,45 @@ def test_file_driven_enrol_and_evaluate(eng, golden, tmp_path, monkeypatch, caps
     np.testing.assert_array_equal(sig, evaluation_ref.load_wav(os.path.join(data_dir, rel[0])))
 
 
+def test_file_driven_evaluate_with_the_trained_checkpoint(eng, tmp_path, monkeypatch, capsys):
+    """The reference's no-argument `create_speaker_models()` + `evaluate()` (model.py:351-388, evaluation.py:90-146) on a tree
+    that carries the committed TRAINED checkpoint, with `constants.NORMALIZE` on (the checkpoint saw CMVN-normalised features):
+    10 speakers the network never saw, 4 files each -- an operating point (accuracy, EER) instead of a coin flip, and the
+    scores row by row against the oracle's per-utterance chain on the same tree, seeds and weights."""
+    from oracle import evaluation_ref
+    from speaker_verification_amd import constants, evaluation, model as model_mod
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = str(tmp_path)
+    data_dir, rel, state = synth.write_verification_tree(
+        root, n_speakers=10, utts_per_speaker=4, n_samples=40000,
+        checkpoint=os.path.join(repo, "speaker_verification_amd", "checkpoints", "c3d2_synth.pt"))
+    monkeypatch.setattr(constants, "ROOT", root)
+    monkeypatch.setattr(constants, "DATA_ORIGIN", data_dir)
+    monkeypatch.setattr(constants, "NORMALIZE", True)
+    monkeypatch.chdir(tmp_path)
+    np.random.seed(31)
+    store = model_mod.create_speaker_models()
+    np.random.seed(32)
+    res = evaluation.evaluate()
+    capsys.readouterr()
+    assert len(store) == 10 and res["scores"].shape == (40, 10)
+    assert res["accuracy"] >= 75.0 and res["eer"] < 0.2 and res["auc"] > 0.9, (res["accuracy"], res["eer"], res["auc"])
+    order = res["speaker_ids"]
+    np.random.seed(31)
+    o_store = evaluation_ref.create_speaker_models(data_dir, rel, state, normalize=True)
+    np.random.seed(32)
+    o_scores, o_labels, o_acc, o_eer, o_auc = evaluation_ref.evaluate(data_dir, rel, state, o_store, order, normalize=True)
+    scale = max(float(np.abs(v).max()) for v in o_store.values())
+    for sid in order:
+        np.testing.assert_allclose(store[sid].numpy(), o_store[sid], rtol=0, atol=5e-5 * scale)
+    np.testing.assert_allclose(res["scores"], o_scores, rtol=0, atol=2e-5)
+    np.testing.assert_array_equal(res["labels"], o_labels)
+    flat = np.sort(o_scores.flatten())
+    if np.diff(flat).min() > 4e-5:                       # no near-tie that a 2e-5 difference could reorder
+        assert res["eer"] == pytest.approx(o_eer, abs=1e-9) and res["auc"] == pytest.approx(o_auc, abs=1e-9)
+        assert res["accuracy"] == pytest.approx(o_acc)
+
+
 @pytest.mark.parametrize("nfft", [8, 64, 128, 256, 2048, 4096, 8192, 300, 400, 1000, 1023])
 def test_spectrum_any_length(sp, nfft):
     """processing.fft_spectrum / power_spectrum for every fft_points (processing.py:142-174): powers of two run the
