@@ -168,15 +168,102 @@ __device__ __forceinline__ void dma_patch_w(const Stage1Params& p, int item, int
 // Input transform of the depth-Winograd form for one element pair (hf = 0: elements 0, 1; 1: elements 2, 3) of the four
 // depth fragments x: t0 = x0 - x2, t1 = x1 + x2, t2 = x2 - x1, t3 = x1 - x3, as four v_pk_add_f32 (written out: the
 // compiler emits the packed form now and then for sums and never for differences, which use the negate modifiers).
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
   f32x2 d;
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
-  f32x2 d;
-  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+// prelu for 0 <= slope <= 1 straight off MFMA accumulators: fmaxf() on a value the compiler cannot prove canonical costs a
+// third instruction (v_max x, x in front of the real one) and the product is one v_mul per value; written as vectors it is one
+// v_pk_mul_f32 per PAIR + one v_max_f32 per value (12 -> 6 instructions per conv1_1 tile; the same product, the same
+// maximum: bit-identical for every finite and infinite input, NaN stays NaN).
+// (the product is left to the compiler -- it selects v_pk_mul_f32 for a two-float vector product and, unlike for an asm
+// statement, counts the wait states between an MFMA and the first instruction that reads its result; the v_max behind it
+// depends on that product, so it is issued later still)
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { return a * b; }
+__device__ __forceinline__ float max_raw(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
+}
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+template <bool SLOPE01>
+__device__ __forceinline__ f32x4 prelu4(f32x4 v, f32x4 slope) {
+  f32x4 o;
+  if (SLOPE01) {
+    const f32x2 m0 = pk_mul(__builtin_shufflevector(v, v, 0, 1), __builtin_shufflevector(slope, slope, 0, 1));
+    const f32x2 m1 = pk_mul(__builtin_shufflevector(v, v, 2, 3), __builtin_shufflevector(slope, slope, 2, 3));
+    o[0] = max_raw(v[0], m0[0]);
+    o[1] = max_raw(v[1], m0[1]);
+    o[2] = max_raw(v[2], m1[0]);
+    o[3] = max_raw(v[3], m1[1]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = prelu(v[r], slope[r]);
+  }
+  return o;
+}
+// The packed product on values a VALU instruction produced (never straight off an MFMA: see pk_mul): as an asm statement it is
+// ONE v_pk_mul_f32 whatever pair of registers the allocator picked (the compiler's own choice falls back to two v_mul_f32 now and
+// then).
+__device__ __forceinline__ f32x2 pk_mul_valu(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+// The output transform y(2 P) = (a0 + a1) + a2, y(2 P + 1) = (a1 - a2) - a3 of four accumulators as eight packed adds in TWO
+// rounds of four independent ones: the compiler puts a wait state in front of an asm statement that reads the register the
+// instruction before it wrote, so a dependent chain written link by link costs an s_nop per link.
+__device__ __forceinline__ void wino_output(const f32x4 (&a)[4], f32x2 (&y0)[2], f32x2 (&y1)[2]) {
+  const f32x2 u0 = pk_add(lo2(a[0]), lo2(a[1])), u1 = pk_add(hi2(a[0]), hi2(a[1]));
+  const f32x2 w0 = pk_sub(lo2(a[1]), lo2(a[2])), w1 = pk_sub(hi2(a[1]), hi2(a[2]));
+  y0[0] = pk_add(u0, lo2(a[2]));
+  y0[1] = pk_add(u1, hi2(a[2]));
+  y1[0] = pk_sub(w0, lo2(a[3]));
+  y1[1] = pk_sub(w1, hi2(a[3]));
+}
+// PReLU of the two outputs of wino_output() with a lane's four slopes: four packed products, then eight v_max_f32 (12
+// instructions for 8 values; fmaxf(v, slope * v) compiled to 24: a product and a canonicalising v_max x, x per value on top)
+template <bool SLOPE01>
+__device__ __forceinline__ void prelu_pairs(f32x2 (&y0)[2], f32x2 (&y1)[2], f32x4 slope, f32x4& o0, f32x4& o1) {
+  if (SLOPE01) {
+    const f32x2 m00 = pk_mul_valu(y0[0], lo2(slope)), m01 = pk_mul_valu(y0[1], hi2(slope));
+    const f32x2 m10 = pk_mul_valu(y1[0], lo2(slope)), m11 = pk_mul_valu(y1[1], hi2(slope));
+    o0[0] = max_raw(y0[0][0], m00[0]);
+    o0[1] = max_raw(y0[0][1], m00[1]);
+    o0[2] = max_raw(y0[1][0], m01[0]);
+    o0[3] = max_raw(y0[1][1], m01[1]);
+    o1[0] = max_raw(y1[0][0], m10[0]);
+    o1[1] = max_raw(y1[0][1], m10[1]);
+    o1[2] = max_raw(y1[1][0], m11[0]);
+    o1[3] = max_raw(y1[1][1], m11[1]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o0[r] = prelu(y0[r >> 1][r & 1], slope[r]);
+      o1[r] = prelu(y1[r >> 1][r & 1], slope[r]);
+    }
+  }
+}
+// max(prelu(a), prelu(b)) with one slope (the pool over a column pair): one packed product + v_max3 + v_max
+template <bool SLOPE01>
+__device__ __forceinline__ float prelu_max2(f32x2 v, f32x2 slope2) {
+  if (SLOPE01) {
+    const f32x2 m = pk_mul(v, slope2);
+    return max_raw(max3_raw(v[0], m[0], v[1]), m[1]);
+  }
+  return fmaxf(prelu(v[0], slope2[0]), prelu(v[1], slope2[1]));
 }
 __device__ __forceinline__ void wino_input_pair(const f32x4 (&x)[4], int hf, f32x2 (&t)[4][2]) {
   f32x2 xh[4];
@@ -290,39 +377,43 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       // 16 contiguous bytes of the act1 tile: ONE ds_write_b128 per tile (round 4; with M = pixel a lane held one channel of four
       // pixels: four ds_write_b32 per tile; the same products in the same order, bit-identical output, phase 5.8 k -> 5.5 k cycles)
       float* const al = act + 16 * WPIXF * wave + 68 * (i >> 2) + 16 * (i & 3) + 4 * kk;
+      // Fragments a step ahead: step = (tap quarter jj, tile pair): one ds_read2st64_b32 = the pair's two values, read while the
+      // previous step's two MFMAs run (left to the scheduler, every read sat directly in front of its MFMAs with a full
+      // lgkmcnt(0) wait: the LDS round trip per 64 cycles of matrix work, covered only by the SIMD's other wave)
+      float av[2][2];
+      av[0][0] = pl[0][0];
+      av[0][1] = pl[0][64 * WPW];
 #pragma unroll
       for (int g4 = 0; g4 < 3; ++g4) {
-        float av[4][4];
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) av[q4][jj] = pl[jj][64 * WPW * (4 * g4 + q4)];
         f32x4 acc1[4];
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) acc1[q4] = b1v;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) acc1[q4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[jj], av[q4][jj], acc1[q4], 0, 0, 0);
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          f32x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = prelu_t<SLOPE01>(acc1[q4][r], sl1v[r]);
-          *reinterpret_cast<f32x4*>(al + 128 * WPIXF * (4 * g4 + q4)) = o;
+        for (int step = 0; step < 8; ++step) {
+          const int jj = step >> 1, qp = 2 * (step & 1), cur = step & 1, nxt = cur ^ 1;
+          const int ns = step + 1, njj = (ns & 7) >> 1, nt = 4 * (g4 + (ns >> 3)) + 2 * (ns & 1);   // the next step's tap quarter / first tile
+          if (nt < 12) {
+            av[nxt][0] = pl[njj][64 * WPW * nt];
+            av[nxt][1] = pl[njj][64 * WPW * (nt + 1)];
+          } else if (part == 0) {   // behind the last group: the single tile 96 + wave of the older waves
+            av[nxt][0] = pl[0][64 * WPW * 12];
+            av[nxt][1] = pl[1][64 * WPW * 12];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc1[qp] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[jj], av[cur][0], jj ? acc1[qp] : b1v, 0, 0, 0);
+          acc1[qp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[jj], av[cur][1], jj ? acc1[qp + 1] : b1v, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        // (all sixteen MFMAs first: the epilogue then starts on the tile whose last MFMA is three MFMAs old)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          *reinterpret_cast<f32x4*>(al + 128 * WPIXF * (4 * g4 + q4)) = prelu4<SLOPE01>(acc1[q4], sl1v);
       }
-      if (part == 0) {   // tile 96 + wave
-        float av[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) av[jj] = pl[jj][64 * WPW * 12];
-        f32x4 acc1 = b1v;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[jj], av[jj], acc1, 0, 0, 0);
-        f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = prelu_t<SLOPE01>(acc1[r], sl1v[r]);
-        *reinterpret_cast<f32x4*>(al + 128 * WPIXF * 12) = o;
+      if (part == 0) {   // tile 96 + wave (its first two fragments came with the last group's final step)
+        const float a2 = pl[2][64 * WPW * 12], a3 = pl[3][64 * WPW * 12];
+        f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[0], av[0][0], b1v, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[1], av[0][1], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[2], a2, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[3], a3, acc1, 0, 0, 0);
+        *reinterpret_cast<f32x4*>(al + 128 * WPIXF * 12) = prelu4<SLOPE01>(acc1, sl1v);
       }
     }
     SVK_STAMP(ts2);
@@ -357,6 +448,8 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
         f32x4 acc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (the tile's first tap is read HERE, its round trip in the open: reading it under the previous tile's last tap -- as the
+        // second block's kernels do -- measured 1.4 % SLOWER in this kernel, 7.34 -> 7.55 ms: 252 VGPRs and a branch in the tap loop)
         f32x4 x[4];
         f32x2 t[4][2];   // [k][element pair]
 #pragma unroll
@@ -394,8 +487,8 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
         // rows 4 kk + r of the tile: output row h0 + 2 kk + (r >> 1), column r & 1: pool = max over r pairs
         {
           // (packed, written out: the compiler emits scalar subtractions for the differences)
-          f32x4 y0, y1;
-          const f32x2 b22 = (f32x2){b2, b2};
+          f32x2 y0[2], y1[2];
+          const f32x2 b22 = (f32x2){b2, b2}, sl22 = (f32x2){sl2, sl2};
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
             const f32x2 c0 = hf ? __builtin_shufflevector(acc[0], acc[0], 2, 3) : __builtin_shufflevector(acc[0], acc[0], 0, 1);
@@ -403,19 +496,17 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
             const f32x2 c2 = hf ? __builtin_shufflevector(acc[2], acc[2], 2, 3) : __builtin_shufflevector(acc[2], acc[2], 0, 1);
             const f32x2 c3 = hf ? __builtin_shufflevector(acc[3], acc[3], 2, 3) : __builtin_shufflevector(acc[3], acc[3], 0, 1);
             const f32x2 s0 = pk_add(pk_add(pk_add(c0, c1), c2), b22), s1 = pk_add(pk_sub(pk_sub(c1, c2), c3), b22);
-            y0[2 * hf] = s0[0];
-            y0[2 * hf + 1] = s0[1];
-            y1[2 * hf] = s1[0];
-            y1[2 * hf + 1] = s1[1];
+            y0[hf] = s0;
+            y1[hf] = s1;
           }
           float* const o00 = obase + (int64_t)(h0 / 2) * p.s_hp;
           float* const o01 = o00 + p.s_par;
           float* const o10 = o00 + p.s_d;
           float* const o11 = o10 + p.s_par;
-          o00[olane] = fmaxf(prelu_t<SLOPE01>(y0[0], sl2), prelu_t<SLOPE01>(y0[1], sl2));
-          o01[olane] = fmaxf(prelu_t<SLOPE01>(y0[2], sl2), prelu_t<SLOPE01>(y0[3], sl2));
-          o10[olane] = fmaxf(prelu_t<SLOPE01>(y1[0], sl2), prelu_t<SLOPE01>(y1[1], sl2));
-          o11[olane] = fmaxf(prelu_t<SLOPE01>(y1[2], sl2), prelu_t<SLOPE01>(y1[3], sl2));
+          o00[olane] = prelu_max2<SLOPE01>(y0[0], sl22);
+          o01[olane] = prelu_max2<SLOPE01>(y0[1], sl22);
+          o10[olane] = prelu_max2<SLOPE01>(y1[0], sl22);
+          o11[olane] = prelu_max2<SLOPE01>(y1[1], sl22);
         }
       }
     }
@@ -698,24 +789,33 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
     if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + (int)gridDim.x : item + (int)gridDim.x;
     __syncthreads();
     const int item_next = q_next;
-    // M tiles = (pair P, row hl): 16 pixels w' = 0 .. 15 (15 is a dummy), tile = 4 P + hl
-#pragma unroll 1
-    for (int tile = wave; tile < 7 * C21W_TH; tile += 4) {
-      const int P = tile >> 2, hl = tile & 3;
-      const int p0 = (2 * P * C21W_TH + hl) * S2_W + i;
-      const float* ab[4];
+    // M tiles = (pair P, row hl): 16 pixels w' = 0 .. 15 (15 is a dummy), tile = 4 P + hl = 4 P + wave: this wave's seven tiles
+    // differ in P alone, and pixel 144 P + r sits at 2 448 P + 16 r + 4 (r >> 2) -- the four tap addresses of a lane are those
+    // of its first tile plus 2 448 floats per tile (four adds per tile; recomputed from the tile index they were 22 vector
+    // instructions per 128 MFMAs, none of which an MFMA hides)
+    int ao[4];   // (offsets into `reg`, not pointers: a pointer carried round the loop loses its LDS address space -- flat loads)
+    {
+      int il = i;
+      asm volatile("" : "+v"(il));   // (inside the item loop: hoisted out of it, the four addresses cost registers all kernel long)
 #pragma unroll
-      for (int kw = 0; kw < 4; ++kw) ab[kw] = reg + 16 * (p0 + kw) + 4 * ((p0 + kw) >> 2) + 4 * kk;
+      for (int kw = 0; kw < 4; ++kw) {
+        const int r = S2_W * wave + il + kw;
+        ao[kw] = 16 * r + 4 * (r >> 2) + 4 * kk;
+      }
+    }
+    // the first tile's first tap; every later tile's is read under the previous tile's last 32 MFMAs
+    f32x4 x[4];
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(reg + ao[0] + C21W_DSTEP * dd);
+#pragma unroll 1
+    for (int P = 0; P < 7; ++P) {
       // (a1 enters both outputs with a plus sign: the bias rides in its accumulator)
       f32x4 acc[2][4];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[nt][k] = k == 1 ? b4[nt] : (f32x4){0.f, 0.f, 0.f, 0.f};
-      f32x4 x[4];
       f32x2 t[4][2];
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ab[0] + C21W_DSTEP * dd);
 #pragma unroll
       for (int kw = 0; kw < 4; ++kw) {
         // this tap's transformed fragments (8 packed adds, one burst), the next tap's reads, 32 MFMAs
@@ -724,7 +824,10 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
         __builtin_amdgcn_sched_barrier(0);
         if (kw + 1 < 4) {
 #pragma unroll
-          for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ab[kw + 1] + C21W_DSTEP * dd);
+          for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(reg + ao[kw + 1] + C21W_DSTEP * dd);
+        } else if (P + 1 < 7) {
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(reg + ao[0] + 2 * C21W_DSTEP + C21W_DSTEP * dd);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -736,27 +839,20 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
               acc[nt][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[nt][k][kw][e], t[k][e >> 1][e & 1], acc[nt][k], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw) ao[kw] += 2 * C21W_DSTEP;
       // rows 4 kk + r = channel 16 nt + 4 kk + r; column i = output column w' (15 is the dummy); depths 2 P and 2 P + 1
       // (wave-uniform 64-bit bases + one 32-bit lane offset + immediates: the stores need no per-store address VALU)
-      float* const o0 = p.out + (((int64_t)u * A2_D + 2 * P) * S2_H + hb + hl) * (A2_W * 32);
+      float* const o0 = p.out + (((int64_t)u * A2_D + 2 * P) * S2_H + hb + wave) * (A2_W * 32);
       float* const o1 = o0 + (int64_t)S2_H * (A2_W * 32);
       const int lo = i * 32 + 4 * kk;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         // y0 = (a0 + a1) + a2, y1 = (a1 - a2) - a3 as packed adds (every VALU instruction here is paid in MFMA slots)
+        f32x2 s0[2], s1[2];
+        wino_output(acc[nt], s0, s1);
         f32x4 y0, y1;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const f32x2 a0 = hf ? __builtin_shufflevector(acc[nt][0], acc[nt][0], 2, 3) : __builtin_shufflevector(acc[nt][0], acc[nt][0], 0, 1);
-          const f32x2 a1 = hf ? __builtin_shufflevector(acc[nt][1], acc[nt][1], 2, 3) : __builtin_shufflevector(acc[nt][1], acc[nt][1], 0, 1);
-          const f32x2 a2 = hf ? __builtin_shufflevector(acc[nt][2], acc[nt][2], 2, 3) : __builtin_shufflevector(acc[nt][2], acc[nt][2], 0, 1);
-          const f32x2 a3 = hf ? __builtin_shufflevector(acc[nt][3], acc[nt][3], 2, 3) : __builtin_shufflevector(acc[nt][3], acc[nt][3], 0, 1);
-          const f32x2 s0 = pk_add(pk_add(a0, a1), a2), s1 = pk_sub(pk_sub(a1, a2), a3);
-          y0[2 * hf] = prelu_t<SLOPE01>(s0[0], sl4[nt][2 * hf]);
-          y0[2 * hf + 1] = prelu_t<SLOPE01>(s0[1], sl4[nt][2 * hf + 1]);
-          y1[2 * hf] = prelu_t<SLOPE01>(s1[0], sl4[nt][2 * hf]);
-          y1[2 * hf + 1] = prelu_t<SLOPE01>(s1[1], sl4[nt][2 * hf + 1]);
-        }
+        prelu_pairs<SLOPE01>(s0, s1, sl4[nt], y0, y1);
         if (i < A2_W) {
           *reinterpret_cast<f32x4*>(o0 + lo + 16 * nt) = y0;
           *reinterpret_cast<f32x4*>(o1 + lo + 16 * nt) = y1;
@@ -863,6 +959,10 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
     SVK_STAMP(ts2);
     const int item_next = q_next;
     f32x4 own[2][2];   // [column][y]: the partial sums of the pair this wave finishes
+    // the first tile's first tap; every later tile's is read under the previous tile's last 16 MFMAs
+    f32x4 x[4];
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(a0 + 2 * C22W_PLANE * (1 - ch) + C22W_PLANE * dd);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       const int P = pass ? ch : 1 - ch;   // the partner's pair first
@@ -872,10 +972,7 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
         f32x4 acc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = k == 1 ? (f32x4){b, b, b, b} : (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 x[4];
         f32x2 t[4][2];
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C22W_PLANE * dd);
 #pragma unroll
         for (int kh = 0; kh < 8; ++kh) {
 #pragma unroll
@@ -885,6 +982,12 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
             const int off = 32 * (kh + 1) + 4 * ((kh + 1) >> 1);
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C22W_PLANE * dd + off);
+          } else if (wq == 0) {          // the pair's second column
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C22W_COL + C22W_PLANE * dd);
+          } else if (pass == 0) {        // the second pass's pair (ch), column 0
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(a0 + 2 * C22W_PLANE * ch + C22W_PLANE * dd);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -894,19 +997,9 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
               acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e >> 1][e & 1], G[k][kh][e], acc[k], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        f32x4 y0, y1;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const f32x2 c0 = hf ? __builtin_shufflevector(acc[0], acc[0], 2, 3) : __builtin_shufflevector(acc[0], acc[0], 0, 1);
-          const f32x2 c1 = hf ? __builtin_shufflevector(acc[1], acc[1], 2, 3) : __builtin_shufflevector(acc[1], acc[1], 0, 1);
-          const f32x2 c2 = hf ? __builtin_shufflevector(acc[2], acc[2], 2, 3) : __builtin_shufflevector(acc[2], acc[2], 0, 1);
-          const f32x2 c3 = hf ? __builtin_shufflevector(acc[3], acc[3], 2, 3) : __builtin_shufflevector(acc[3], acc[3], 0, 1);
-          const f32x2 s0 = pk_add(pk_add(c0, c1), c2), s1 = pk_sub(pk_sub(c1, c2), c3);
-          y0[2 * hf] = s0[0];
-          y0[2 * hf + 1] = s0[1];
-          y1[2 * hf] = s1[0];
-          y1[2 * hf + 1] = s1[1];
-        }
+        f32x2 s0[2], s1[2];
+        wino_output(acc, s0, s1);
+        const f32x4 y0 = __builtin_shufflevector(s0[0], s0[1], 0, 1, 2, 3), y1 = __builtin_shufflevector(s1[0], s1[1], 0, 1, 2, 3);
         if (pass == 0) {
           float* xo = exch + ((((nt * 2 + P) * 2 + wq) * 2) * 64 + lane) * 4;
           *reinterpret_cast<f32x4*>(xo) = y0;
@@ -1041,16 +1134,17 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
     if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + (int)gridDim.x : item + (int)gridDim.x;
     __syncthreads();
     const int item_next = q_next;
+    // the first pair's first fragments; every later pair's are read under the previous pair's last 16 MFMAs
+    f32x4 x[4];
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(a0 + C31_PLANE * dd);
 #pragma unroll 1
     for (int P = 0; P < 5; ++P) {
       const float* ap = a0 + 2 * C31_PLANE * P;
       f32x4 acc[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] = k == 1 ? b4 : (f32x4){0.f, 0.f, 0.f, 0.f};
-      f32x4 x[4];
       f32x2 t[4][2];
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C31_PLANE * dd);
 #pragma unroll
       for (int st = 0; st < 6; ++st) {   // step = (column tap kw, 16-channel chunk)
         const int kw = st >> 1, ch = st & 1;
@@ -1061,6 +1155,9 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
           const int off = C31_PIXF * ((st + 1) >> 1) + 16 * ((st + 1) & 1);
 #pragma unroll
           for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C31_PLANE * dd + off);
+        } else if (P + 1 < 5) {
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + 2 * C31_PLANE + C31_PLANE * dd);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1076,19 +1173,10 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
       float* const o = p.out + (((int64_t)u * 10 + 2 * P) * 8 + 2 * nt) * (5 * 15 * 8);   // wave-uniform
       const int olane = (kk >> 1) * (5 * 15 * 8) + 4 * (kk & 1) + ((mi % 5) * 15 + mi / 5 + 3 * rb) * 8;
       constexpr int ostep = 8 * 5 * 15 * 8;   // one output depth further
+      f32x2 s0[2], s1[2];
+      wino_output(acc, s0, s1);
       f32x4 y0, y1;
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const f32x2 c0 = hf ? __builtin_shufflevector(acc[0], acc[0], 2, 3) : __builtin_shufflevector(acc[0], acc[0], 0, 1);
-        const f32x2 c1 = hf ? __builtin_shufflevector(acc[1], acc[1], 2, 3) : __builtin_shufflevector(acc[1], acc[1], 0, 1);
-        const f32x2 c2 = hf ? __builtin_shufflevector(acc[2], acc[2], 2, 3) : __builtin_shufflevector(acc[2], acc[2], 0, 1);
-        const f32x2 c3 = hf ? __builtin_shufflevector(acc[3], acc[3], 2, 3) : __builtin_shufflevector(acc[3], acc[3], 0, 1);
-        const f32x2 s0 = pk_add(pk_add(c0, c1), c2), s1 = pk_sub(pk_sub(c1, c2), c3);
-        y0[2 * hf] = prelu_t<SLOPE01>(s0[0], sl4[2 * hf]);
-        y0[2 * hf + 1] = prelu_t<SLOPE01>(s0[1], sl4[2 * hf + 1]);
-        y1[2 * hf] = prelu_t<SLOPE01>(s1[0], sl4[2 * hf]);
-        y1[2 * hf + 1] = prelu_t<SLOPE01>(s1[1], sl4[2 * hf + 1]);
-      }
+      prelu_pairs<SLOPE01>(s0, s1, sl4, y0, y1);
       if (i < 15) {
         *reinterpret_cast<f32x4*>(o + olane) = y0;
         *reinterpret_cast<f32x4*>(o + ostep + olane) = y1;

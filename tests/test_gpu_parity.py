@@ -17,6 +17,8 @@ torch = pytest.importorskip("torch")
 
 from oracle import model_ref, scoring_ref, speechpy_ref as ref, vad_ref   # noqa: E402
 from speaker_verification_amd import constants as c, synth                  # noqa: E402
+from speaker_verification_amd import utils as _utils                        # noqa: E402,F401  (like the reference's utils.py:15 it seeds
+#   the global NumPy RNG AT IMPORT: imported here, so that no test's own np.random.seed() is undone by a lazy first import)
 
 FEAT_TOL = dict(rtol=1e-4, atol=1e-4)
 
