@@ -44,6 +44,21 @@ constexpr int TD = 8;                                // conv1_2 output depths pe
 constexpr int DIN = TD + 2;                          // act1 depths per item
 constexpr int PD = TD + 4;                           // cube patch depths per item
 constexpr int OD = 16, OH = 36, OWP = 18;            // output: depths, rows, pooled columns
+// output strides (floats) of [n][16 d][36 h][18 w][16 c] (channels-last memory of a (n, 16, 16, 36, 18) tensor): pooled column,
+// row parity, row pair, depth, cube.  Compile-time: as kernel parameters they were 64-bit scalar multiplies per item
+constexpr int S_W = 16, S_PAR = OWP * 16, S_HP = 2 * OWP * 16, S_D = OH * OWP * 16, S_N = OD * OH * OWP * 16;
+// A work item (cube u, rem = 18 q + j: half q of the output depths, pooled column j), decoded ONCE when its index is known (two
+// items ahead) and handed down: item / 36, % 36, / 18 for the item, the next one (patch fetch) and the one after (crop starts)
+// were three division chains of scalar instructions per item, in front of the barrier where nothing hides them.
+struct ItemPos {
+  int u, rem;
+  __device__ __forceinline__ int q() const { return rem >= 18 ? 1 : 0; }
+  __device__ __forceinline__ int j() const { return rem >= 18 ? rem - 18 : rem; }
+  __device__ static __forceinline__ ItemPos of(int item) {
+    const int u = item / 36;
+    return ItemPos{u, item - 36 * u};
+  }
+};
 
 struct Stage1Params {
   const float* feat;
@@ -56,7 +71,7 @@ struct Stage1Params {
   const float* bias2;    // [16]
   const float* slope2;   // [16]
   float* out;
-  int64_t s_n, s_d, s_hp, s_par, s_w;  // output strides (floats) of [n][16 d][36 h][18 w][16 c]: cube, depth, row pair, row parity, pooled column
+  unsigned* queue;                     // work-item counter (zeroed by the host before the launch), or NULL = items at a fixed stride
   unsigned long long* stamps;          // tuning builds only (-DSVK_TUNING): [grid][4 waves][6] summed phase cycles
 };
 
@@ -81,9 +96,8 @@ __device__ __forceinline__ float prelu_t(float v, float slope) {
 // (a VECTOR load by lanes 0 .. 11, not twelve scalar loads: scalar loads return out of order, so while any is in
 // flight every LDS wait of the wave becomes lgkmcnt(0) -- the first gather read of the conv1_1 phase then stalled for
 // the crop table's whole L2 round trip, 2 500 cycles per item by the in-kernel stamps)
-__device__ __forceinline__ int fetch_starts(const Stage1Params& p, int item, int lane) {
-  const int u = item / 36, rem = item - u * 36, q = rem / 18;
-  const int32_t* cr = p.crop + (int64_t)u * NCROP + TD * q;
+__device__ __forceinline__ int fetch_starts(const Stage1Params& p, ItemPos it, int lane) {
+  const int32_t* cr = p.crop + (int64_t)it.u * NCROP + TD * it.q();
   return cr[lane < PD ? lane : 0];
 }
 
@@ -144,9 +158,8 @@ __device__ __forceinline__ void patch_piece_issue(const Stage1Params& p, const P
 }
 // the nine pieces of wave `pair` (a part-0 wave).  Every crop start is read BEFORE the first DMA: with one in flight the
 // compiler drains vmcnt in front of any use of an ordinary load's result -- `starts_v` is one -- which would serialise them.
-__device__ __forceinline__ void dma_patch_w(const Stage1Params& p, int item, int starts_v, int pair, int lane, float* patch) {
-  const int u = item / 36, rem = item - u * 36, j = rem % 18;
-  const float* base = p.feat + (int64_t)u * p.max_frames * NCOEF + 2 * j;
+__device__ __forceinline__ void dma_patch_w(const Stage1Params& p, ItemPos it, int starts_v, int pair, int lane, float* patch) {
+  const float* base = p.feat + (int64_t)it.u * ((int64_t)p.max_frames * NCOEF) + 2 * it.j();
   int st[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) st[g] = __builtin_amdgcn_readlane(starts_v, pair + 4 * g);
@@ -320,6 +333,9 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
   const int i = lane & 15, kk = lane >> 4;
   const int pair = wave & 3, part = wave >> 2;
   const int n_items = p.n_utt * 36;
+#ifdef SVK_TUNING
+  const unsigned long long clk_entry = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one counter for the whole chip
+#endif
 
   f32x4 G[36];   // [k][kh]
 #pragma unroll
@@ -342,11 +358,17 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
   const float b2 = p.bias2[i], sl2 = p.slope2[i];
 
   int starts = 0;
-  int item = blockIdx.x;
+  // Items: the first three of a workgroup at a fixed stride, every later one drawn from a device-wide counter TWO items ahead (the
+  // crop starts of item k + 2 and the patch of item k + 1 are fetched during item k).  The CUs of this chip do not run at one
+  // clock (2 344 .. 2 390 MHz across the 256 workgroups of one launch, in-kernel stamps): with equal shares the slowest XCD's
+  // workgroups left the loop 166 us after the fastest one's, 2.3 % of the kernel.
+  __shared__ int q_item3;
+  int item = blockIdx.x, item1 = item + (int)gridDim.x, item2 = item1 + (int)gridDim.x;
+  ItemPos cur = ItemPos::of(item), nx = ItemPos::of(item1), nx2 = ItemPos::of(item2);
   if (item < n_items) {
-    starts = fetch_starts(p, item, lane);
-    if (part == 0) dma_patch_w(p, item, starts, pair, lane, patch);
-    if (item + (int)gridDim.x < n_items) starts = fetch_starts(p, item + gridDim.x, lane);
+    starts = fetch_starts(p, cur, lane);
+    if (part == 0) dma_patch_w(p, cur, starts, pair, lane, patch);
+    if (item1 < n_items) starts = fetch_starts(p, nx, lane);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed (the compiler emits this wait too; spelt out: the barrier relies on it)
   __syncthreads();
@@ -355,9 +377,11 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
   // the clock the chip holds under this kernel's load: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime) over the loop
   const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (; item < n_items; item += gridDim.x) {
+  while (item < n_items) {
     SVK_STAMP(ts0);
-    const int next = item + gridDim.x;
+    const int next = item1;
+    unsigned q_ticket = 0;   // (requested here, published with barrier 1: the round trip runs under the conv1_1 phase)
+    if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
     SVK_STAMP(ts1);
 
     // ---- conv1_1 + PReLU: 100 tiles of 16 pixels, tile tt = wave + 8 m: 13 for waves 0 .. 3, 12 for the others, four at
@@ -417,17 +441,19 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       }
     }
     SVK_STAMP(ts2);
+    if (threadIdx.x == 0) q_item3 = p.queue ? (int)q_ticket + 3 * (int)gridDim.x : item2 + (int)gridDim.x;
     __syncthreads();  // act1 is complete; the patch buffer is free
+    const int item3 = q_item3;
     SVK_STAMP(ts3);
 
     // ---- conv1_2, depth-transformed ----
     {
-      const int u = item / 36, rem = item - u * 36, q = rem / 18, j = rem - q * 18;
+      const int u = cur.u, q = cur.q(), j = cur.j();
       const int hl = i >> 1, wc = i & 1;
       const float* const wbase = act + 2 * (160 * WPIXF) * pair + 68 * hl + 16 * wc + 4 * kk;
       // (wave-uniform 64-bit bases + one 32-bit lane offset: the stores need no per-store address VALU)
-      float* const obase = p.out + (int64_t)u * p.s_n + (int64_t)(TD * q + 2 * pair) * p.s_d + (int64_t)j * p.s_w;
-      const int olane = kk * (int)p.s_hp + i;
+      float* const obase = p.out + (int64_t)u * S_N + (TD * q + 2 * pair) * S_D + j * S_W;
+      const int olane = kk * S_HP + i;
       // (the SIMD's two waves do not share its issue slots evenly -- the older one, part 0, gets about two in three, and
       // s_setprio changes nothing, measured -- but the younger one fills what the older leaves: the phase lasts the SUM
       // of both waves' MFMA + VALU time whichever way the five tiles are split, so 3 + 2 it is)
@@ -438,8 +464,8 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
         // the next item's patch (LDS-DMA), by the older waves in front of their first tile (behind barrier 1: conv1_1 has
         // read the patch buffer); one piece every other row tap instead of one burst: measured 2.7 % SLOWER
         if (part == 0 && tl == tl0 && next < n_items) {
-          dma_patch_w(p, next, starts, pair, lane, patch);
-          if (next + (int)gridDim.x < n_items) starts = fetch_starts(p, next + gridDim.x, lane);
+          dma_patch_w(p, nx, starts, pair, lane, patch);
+          if (item2 < n_items) starts = fetch_starts(p, nx2, lane);
         }
         const int h0 = 8 * tl;
         const float* pb[5];
@@ -499,10 +525,10 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
             y0[hf] = s0;
             y1[hf] = s1;
           }
-          float* const o00 = obase + (int64_t)(h0 / 2) * p.s_hp;
-          float* const o01 = o00 + p.s_par;
-          float* const o10 = o00 + p.s_d;
-          float* const o11 = o10 + p.s_par;
+          float* const o00 = obase + (h0 / 2) * S_HP;
+          float* const o01 = o00 + S_PAR;
+          float* const o10 = o00 + S_D;
+          float* const o11 = o10 + S_PAR;
           o00[olane] = prelu_max2<SLOPE01>(y0[0], sl22);
           o01[olane] = prelu_max2<SLOPE01>(y0[1], sl22);
           o10[olane] = prelu_max2<SLOPE01>(y1[0], sl22);
@@ -535,7 +561,7 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
     if (pair == 0) {
       // waves 0 and 4 finish merged tile m = part: rows 4 kk + r = (pair 2 m + (kk >> 1), output row 32 + 2 (kk & 1) + (r >> 1),
       // column r & 1); the exchange buffer is written again behind the next item's first barrier
-      const int u = item / 36, rem = item - u * 36, q = rem / 18, j = rem - q * 18;
+      const int u = cur.u, q = cur.q(), j = cur.j();
       int lane_f = lane;
       asm volatile("" : "+v"(lane_f));   // (keeps the address arithmetic below INSIDE the loop: hoisted, it costs registers this kernel spills)
       const int i_f = lane_f & 15, kk_f = lane_f >> 4;
@@ -543,12 +569,11 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(xe), a1 = *reinterpret_cast<const f32x4*>(xe + 256),
                   a2 = *reinterpret_cast<const f32x4*>(xe + 512), a3 = *reinterpret_cast<const f32x4*>(xe + 768);
       const f32x4 y0 = a0 + a1 + a2 + b2, y1 = a1 - a2 - a3 + b2;
-      float* const o0 = p.out + (int64_t)u * p.s_n + (int64_t)(TD * q + 2 * (2 * part + (kk_f >> 1))) * p.s_d + (int64_t)j * p.s_w +
-                        (int64_t)(16 + (kk_f & 1)) * p.s_hp + i_f;
+      float* const o0 = p.out + (int64_t)u * S_N + (TD * q + 2 * (2 * part + (kk_f >> 1))) * S_D + j * S_W + (16 + (kk_f & 1)) * S_HP + i_f;
       o0[0] = fmaxf(prelu_t<SLOPE01>(y0[0], sl2), prelu_t<SLOPE01>(y0[1], sl2));
-      o0[p.s_par] = fmaxf(prelu_t<SLOPE01>(y0[2], sl2), prelu_t<SLOPE01>(y0[3], sl2));
-      o0[p.s_d] = fmaxf(prelu_t<SLOPE01>(y1[0], sl2), prelu_t<SLOPE01>(y1[1], sl2));
-      o0[p.s_d + p.s_par] = fmaxf(prelu_t<SLOPE01>(y1[2], sl2), prelu_t<SLOPE01>(y1[3], sl2));
+      o0[S_PAR] = fmaxf(prelu_t<SLOPE01>(y0[2], sl2), prelu_t<SLOPE01>(y0[3], sl2));
+      o0[S_D] = fmaxf(prelu_t<SLOPE01>(y1[0], sl2), prelu_t<SLOPE01>(y1[1], sl2));
+      o0[S_D + S_PAR] = fmaxf(prelu_t<SLOPE01>(y1[2], sl2), prelu_t<SLOPE01>(y1[3], sl2));
     }
     SVK_STAMP_ADD(0, ts0, ts1);
     SVK_STAMP_ADD(1, ts1, ts2);
@@ -556,14 +581,24 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
     SVK_STAMP_ADD(3, ts3, ts4);
     SVK_STAMP_ADD(4, ts4, ts5);
     SVK_STAMP_ADD(5, ts5, ts6);
+    item = item1;
+    item1 = item2;
+    item2 = item3;
+    cur = nx;
+    nx = nx2;
+    nx2 = ItemPos::of(item3);
   }
 #ifdef SVK_TUNING
   if (p.stamps && lane == 0) {
     for (int k = 0; k < 6; ++k) p.stamps[((size_t)blockIdx.x * 8 + wave) * 6 + k] = stamp_acc[k];
     if (wave == 0) {
-      unsigned long long* clk = p.stamps + (size_t)gridDim.x * 8 * 6 + (size_t)blockIdx.x * 2;
+      unsigned long long* clk = p.stamps + (size_t)gridDim.x * 8 * 6 + (size_t)blockIdx.x * 5;
+      const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
       clk[0] = __builtin_amdgcn_s_memtime() - clk_c0;
-      clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+      clk[1] = r1 - clk_r0;
+      clk[2] = clk_entry;   // absolute: when this workgroup entered the kernel, reached its loop, left it
+      clk[3] = clk_r0;
+      clk[4] = r1;
     }
   }
 #endif
@@ -607,12 +642,6 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
   p.bias2 = d_bias2;
   p.slope2 = d_slope2;
   p.out = d_out;
-  // [n][16 d][36 h][18 w][16 c]: channels-last memory of a (n, 16, 16, 36, 18) tensor
-  p.s_w = 16;
-  p.s_par = (int64_t)OWP * 16;
-  p.s_hp = 2 * (int64_t)OWP * 16;
-  p.s_d = (int64_t)OH * OWP * 16;
-  p.s_n = (int64_t)OD * OH * OWP * 16;
   const size_t lds = svk_c3d2_stage1_lds_bytes();
   if (lds > (size_t)ctx->lds_per_cu)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage1 needs %zu bytes of LDS per workgroup (device: %d)", lds,
@@ -622,10 +651,13 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t items = (int64_t)n_utt * 36;
   const unsigned grid = (unsigned)std::min<int64_t>(items, ctx->num_cu);  // one persistent workgroup per CU
+  // (the work-item counter: a slot of the handle's 256-byte scratch, zeroed in stream order; SVK_C3D2_STATIC_ITEMS: a fixed stride)
+  p.queue = getenv("SVK_C3D2_STATIC_ITEMS") ? nullptr : reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 112);
+  if (p.queue) SVK_HIP(ctx, hipMemsetAsync(p.queue, 0, 4, ctx->stream));
   p.stamps = nullptr;
 #ifdef SVK_TUNING
   const bool want_stamps = getenv("SVK_C3D2_STAMPS") != nullptr;
-  const size_t stamp_bytes = ((size_t)grid * n_waves * 6 + (size_t)grid * 2) * sizeof(unsigned long long);
+  const size_t stamp_bytes = ((size_t)grid * n_waves * 6 + (size_t)grid * 5) * sizeof(unsigned long long);
   if (want_stamps) {
     const int rc = svk_ensure_work(ctx, stamp_bytes);
     if (rc != SVK_OK) return rc;
@@ -637,7 +669,7 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
   SVK_LAUNCH_CHECK(ctx);
 #ifdef SVK_TUNING
   if (want_stamps) {  // phase cycles (s_memtime, 100 MHz-independent shader clock), averaged over workgroups, per wave
-    std::vector<unsigned long long> h((size_t)grid * n_waves * 6 + (size_t)grid * 2);
+    std::vector<unsigned long long> h((size_t)grid * n_waves * 6 + (size_t)grid * 5);
     SVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SVK_HIP(ctx, hipMemcpy(h.data(), p.stamps, stamp_bytes, hipMemcpyDeviceToHost));
     const char* names[6] = {"issue next patch loads", "conv1_1 phase", "barrier 1", "conv1_2 phase + epilogue", "park", "barrier 2"};
@@ -665,8 +697,26 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
     {   // in-kernel clock: median over workgroups of shader cycles per 100 MHz reference tick
       std::vector<double> mhz;
       for (unsigned b = 0; b < grid; ++b) {
-        const unsigned long long c = h[(size_t)grid * n_waves * 6 + 2 * b], r = h[(size_t)grid * n_waves * 6 + 2 * b + 1];
+        const unsigned long long c = h[(size_t)grid * n_waves * 6 + 5 * b], r = h[(size_t)grid * n_waves * 6 + 5 * b + 1];
         if (r) mhz.push_back(100.0 * (double)c / (double)r);
+      }
+      {   // the launch on the chip-wide 100 MHz counter: when workgroups enter, reach their loop, leave it (microseconds from the first entry)
+        std::vector<double> ent, beg, end;
+        for (unsigned b = 0; b < grid; ++b) {
+          const unsigned long long* c = &h[(size_t)grid * n_waves * 6 + 5 * b];
+          ent.push_back((double)c[2]);
+          beg.push_back((double)c[3]);
+          end.push_back((double)c[4]);
+        }
+        const double t0 = *std::min_element(ent.begin(), ent.end());
+        auto us = [&](std::vector<double>& v, const char* what) {
+          std::sort(v.begin(), v.end());
+          fprintf(stderr, "stage1 %s: first %.1f  median %.1f  last %.1f us after the first workgroup's entry\n", what, (v.front() - t0) / 100.0,
+                  (v[v.size() / 2] - t0) / 100.0, (v.back() - t0) / 100.0);
+        };
+        us(ent, "kernel entry");
+        us(beg, "loop start");
+        us(end, "loop end");
       }
       if (!mhz.empty()) {
         std::sort(mhz.begin(), mhz.end());
@@ -897,6 +947,9 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
   const int nt = wave & 1, ch = wave >> 1;
+#ifdef SVK_TUNING
+  const unsigned long long clk_entry = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one counter for the whole chip
+#endif
   f32x4 G[4][8];   // [k][kh], this wave's N tile and K chunk
 #pragma unroll
   for (int kh = 0; kh < 8; ++kh) {
@@ -931,6 +984,8 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
     // A0 + 544 k + 1 224 dl: for a compile-time k, dl is a constant plus ONE comparison of t >> 4 with the window's depth
     // boundary -- two vector instructions per piece where the general form (a division by 36, the pixel, the pad) took a dozen
     // (a fifth of this kernel's vector instructions, none of which overlaps an MFMA).
+    // (Measured, round 4: the loads of the NEXT item issued right behind the second barrier, in front of the epilogue's stores --
+    // 8 of the 14 pieces, more spills -- move 2.3 k cycles from this stamp into the epilogue and leave the kernel where it was.)
     {
       int tl = threadIdx.x;
       asm volatile("" : "+v"(tl));   // (keeps this arithmetic inside the item loop: hoisted, it costs registers the kernel spills)
@@ -1040,8 +1095,10 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
     for (int k = 0; k < 2; ++k) p.stamps[((size_t)blockIdx.x * 4 + wave) * 4 + k] = stamp_acc[k];
     p.stamps[((size_t)blockIdx.x * 4 + wave) * 4 + 2] = stamp_acc[2] + stamp_acc[3];   // (MFMA passes + barrier 2 in one slot;
     // slot 3 of wave 0 / 1 carries the clock pair: shader cycles and 100 MHz ticks over the loop)
+    // (waves 2 / 3: the absolute 100 MHz time of the workgroup's entry into the kernel / of its leaving the loop)
     p.stamps[((size_t)blockIdx.x * 4 + wave) * 4 + 3] = wave == 0 ? __builtin_amdgcn_s_memtime() - clk_c0
-                                                                    : wave == 1 ? __builtin_amdgcn_s_memrealtime() - clk_r0 : 0ull;
+                                                        : wave == 1 ? __builtin_amdgcn_s_memrealtime() - clk_r0
+                                                        : wave == 2 ? clk_entry : __builtin_amdgcn_s_memrealtime();
   }
 #endif
 }
@@ -1269,6 +1326,24 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
           std::sort(mhz.begin(), mhz.end());
           fprintf(stderr, "conv22w in-kernel clock: median %.0f MHz (min %.0f, max %.0f)\n", mhz[mhz.size() / 2], mhz.front(), mhz.back());
         }
+      }
+      {   // the launch on the chip-wide 100 MHz counter (microseconds from the first workgroup's entry)
+        std::vector<double> ent, beg, end;
+        for (unsigned b = 0; b < gridw; ++b) {
+          const double e = (double)h[((size_t)b * 4 + 2) * 4 + 3], x = (double)h[((size_t)b * 4 + 3) * 4 + 3];
+          ent.push_back(e);
+          end.push_back(x);
+          beg.push_back(x - (double)h[((size_t)b * 4 + 1) * 4 + 3]);
+        }
+        const double t0 = *std::min_element(ent.begin(), ent.end());
+        auto us = [&](std::vector<double>& v, const char* what) {
+          std::sort(v.begin(), v.end());
+          fprintf(stderr, "conv22w %s: first %.1f  median %.1f  last %.1f us after the first workgroup's entry\n", what, (v.front() - t0) / 100.0,
+                  (v[v.size() / 2] - t0) / 100.0, (v.back() - t0) / 100.0);
+        };
+        us(ent, "kernel entry");
+        us(beg, "loop start");
+        us(end, "loop end");
       }
       {   // spread over workgroups of the loop's total cycles (wave 0): static item assignment makes the slowest one the kernel's time
         std::vector<double> tot;
