@@ -262,19 +262,25 @@ class VerificationPipeline:
             hi = int(k[np.nonzero(ok)[0][-1]])
             out.append((order[pos:hi].tolist(), int(cum[hi] - cum[pos])))
             pos = hi
-        # the longest clips would otherwise end up as a batch of a handful: a dozen-workgroup front end for a few clips.  A last
-        # batch of fewer than 64 clips joins its predecessor -- when the merged batch stays within `micro_batch` clips, 1.5 x
-        # the sample cap, the padding cap, and a feature buffer (clips x the LONGEST clip's frames x 40 floats) of
-        # `max_feature_bytes`: joining 145 s clips to a full batch of 20 s ones would multiply that buffer instead
-        if len(out) >= 2 and len(out[-1][0]) < 64:
+        # the longest clips would otherwise end up as batches of a handful: a dozen-workgroup front end for a few clips, and every
+        # batch has fixed costs (measured, `tools/time_ragged_front.py`: the ONE 145 s clip of the benchmark's 2 048 cost 0.15 ms
+        # of VAD + front end + CMVN, as much as 300 clips of 7 s).  A last batch of fewer than 64 clips joins its predecessor
+        # (repeatedly) -- when the merged batch stays within `micro_batch` clips, 1.5 x the sample cap, a feature buffer (clips x
+        # the LONGEST clip's frames x 40 floats) of `max_feature_bytes` (joining 145 s clips to a full batch of 20 s ones would
+        # multiply that buffer), and either the padding cap or a padded size no larger than a full batch's REAL size: tiles past
+        # a clip's end leave the front end at once, and a small batch's padding is cheaper than a batch of its own
+        while len(out) >= 2 and len(out[-1][0]) < 64:
             merged = len(out[-2][0]) + len(out[-1][0])
             longest = int(lengths[out[-1][0][-1]])
             feat_bytes = merged * max(1, longest // 160) * 40 * 4
             total = out[-2][1] + out[-1][1]
+            padded = merged * ((longest + 7) // 8 * 8)
             if (merged <= self.micro_batch and total <= max_batch_samples * 3 // 2 and feat_bytes <= max_feature_bytes
-                    and merged * ((longest + 7) // 8 * 8) <= max_padding * total):
+                    and (padded <= max_padding * total or padded <= max_batch_samples)):
                 tail = out.pop()
                 out[-1] = (out[-1][0] + tail[0], out[-1][1] + tail[1])
+            else:
+                break
         return out
 
     @staticmethod
