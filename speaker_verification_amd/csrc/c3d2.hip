@@ -604,11 +604,296 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
 #endif
 }
 
+
+// =====================================================================================================
+// The first block on the F16 matrix pipe through TWO-PIECE products (round 4, second half).  An f32 value x is carried as
+// the pair (h, l) of halves with h = f16(x), l = f16(x - h): 22 significant bits in the same four bytes, and
+//     x w  =  h_x h_w + l_x h_w + h_x l_w      (+ l_x l_w, 2^-22 of the product: dropped)
+// is three f16 products, exact in the f32 the MFMA accumulates in.  Measured on this network's layers (CPU emulation with
+// the trained checkpoint): 0.9 - 4.6e-7 of the activation scale from the f64 convolution -- the f32 direct form itself is
+// 1.8 - 7.9e-7 (its error is the accumulation's).  `v_mfma_f32_16x16x32_f16` issues every 16 cycles with K = 32: 16 x the
+// multiply-adds per cycle of `v_mfma_f32_16x16x4_f32`, so three piece products cost 3 / 16 of one f32 product, and
+//   * the pieces are made where a value is PRODUCED (conv1_1's epilogue: 2.5 vector instructions per value with
+//     v_cvt_pk_f16_f32; the patch is converted in place once per item), never at a fragment read;
+//   * the depth transform is gone (its adds do not distribute over pieces): the direct form's 27 taps, two taps per K = 32
+//     block -- [h_a | h_b] x [H_a | H_b],  [l_a | l_b] x [H_a | H_b],  [h_a | h_b] x [L_a | L_b] -- 42 MFMAs of 16 cycles per
+//     tile of 16 output positions where the f32 kernel issues 144 of 32;
+//   * act1 = 64 bytes per pixel as before, as FOUR planes of 16-byte slots (h c0-7, h c8-15, l c0-7, l c8-15), each split by
+//     the parity of the row: slot ((quarter * 2 + (r & 1)) * 10 + dd) * 80 + (r >> 1) * 2 + col.  A B fragment is one
+//     ds_read_b128, and the 16 positions of a tile (8 output rows x 2 columns, input rows 2 apart: one parity) are 16
+//     CONSECUTIVE slots for every lane group of the LDS (the channel half and the tap of a K = 32 block pick planes, not
+//     slots): conflict-free.  (Pixels as 64-byte records put eight rows of a tile on the same banks: 8-way conflicts.);
+//   * a tile is ANY 16 positions (the operand address is per lane): the 576 positions of an item are 36 full tiles, no
+//     remainder tiles, no exchange buffer.
+// Same boundary as svk_c3d2_stage1 (f32 feature rows + crop starts in, f32 pooled activation out).
+// =====================================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HACT_WORDS = 16 * DIN * NFRAME * 2;            // 25 600 32-bit words = 6 400 slots of 16 bytes
+constexpr int HPLANE = DIN * NFRAME;                         // slots per (quarter, row parity) plane: [10 dd][40 r / 2][2 col]
+constexpr int HPAIRS = 14;                                   // tap pairs of conv1_2 (27 taps + one empty)
+
+struct Stage1hParams {
+  const float* feat;
+  const int32_t* crop;
+  int32_t n_utt, max_frames;
+  const u32x4* w1blk;    // [2][64]: conv1_1's A blocks (8 halves per lane): [H taps 0-15 | H taps 0-15], [L taps 0-15 | 0]
+  const float* bias1;
+  const float* slope1;
+  const u32x4* w2blk;    // [14 pairs][2][64]: [H_a | H_b], [L_a | L_b]; lane (co = l & 15, kk): ci = 8 (kk & 1) + e, tap a (kk < 2) / b
+  const float* bias2;
+  const float* slope2;
+  float* out;
+  unsigned* queue;
+};
+
+// (h, l) of two f32 values as two packed-half words: {h0, h1}, {l0, l1}
+__device__ __forceinline__ void split2(f32x2 v, unsigned& h, unsigned& l) {
+  const f16x2 hh = __builtin_convertvector(v, f16x2);
+  const f32x2 back = __builtin_convertvector(hh, f32x2);
+  const f16x2 ll = __builtin_convertvector(v - back, f16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  l = __builtin_bit_cast(unsigned, ll);
+}
+
+// max(x, x of lane ^ 1) as ONE instruction (DPP quad_perm [1, 0, 3, 2] on the first source).  Written out: four calls of
+// __builtin_amdgcn_mov_dpp on the four registers of an accumulator came back as one v_mov_b32_dpp of the first (ROCm 7.2).
+// (the s_nop: a DPP read of a register the previous vector instruction wrote needs two wait states, and the compiler does not
+// count them for asm statements)
+__device__ __forceinline__ float max_with_lane_xor1(float x) {
+  float d;
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(x));
+  return d;
+}
+
+template <bool SLOPE01>
+__global__ __launch_bounds__(512) void c3d2_stage1h_kernel(const Stage1hParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_c3d2[];
+  unsigned* const act = reinterpret_cast<unsigned*>(smem_c3d2);   // [HACT_WORDS]
+  float* const patch = smem_c3d2 + HACT_WORDS;                    // [WP_FLOATS]: [12 dd][80 h][8], f32 from the DMA, then (l << 16 | h) words
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  const int pair = wave & 3, part = wave >> 2;
+  const int n_items = p.n_utt * 36;
+
+  u32x4 W2[HPAIRS][2];
+#pragma unroll
+  for (int pr = 0; pr < HPAIRS; ++pr) {
+    W2[pr][0] = p.w2blk[(2 * pr) * 64 + lane];
+    W2[pr][1] = p.w2blk[(2 * pr + 1) * 64 + lane];
+  }
+  const u32x4 W1a = p.w1blk[lane], W1b = p.w1blk[64 + lane];
+  f32x4 b1v, sl1v, b2v, sl2v;   // a lane holds channels 4 kk .. 4 kk + 3 of ONE position (A = the weights)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    b1v[r] = p.bias1[4 * kk + r];
+    sl1v[r] = p.slope1[4 * kk + r];
+    b2v[r] = p.bias2[4 * kk + r];
+    sl2v[r] = p.slope2[4 * kk + r];
+  }
+
+  int starts = 0;
+  __shared__ int q_item3;
+  int item = blockIdx.x, item1 = item + (int)gridDim.x, item2 = item1 + (int)gridDim.x;
+  ItemPos cur = ItemPos::of(item), nx = ItemPos::of(item1), nx2 = ItemPos::of(item2);
+  Stage1Params pf;   // (what the patch fetch reads of the parameters)
+  pf.feat = p.feat;
+  pf.crop = p.crop;
+  pf.n_utt = p.n_utt;
+  pf.max_frames = p.max_frames;
+  if (item < n_items) {
+    starts = fetch_starts(pf, cur, lane);
+    if (part == 0) dma_patch_w(pf, cur, starts, pair, lane, patch);
+    if (item1 < n_items) starts = fetch_starts(pf, nx, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  while (item < n_items) {
+    const int next = item1;
+    unsigned q_ticket = 0;
+    if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
+
+    // ---- (0) the patch in place: f32 -> (l << 16 | h) words, 7 680 of them, 16 bytes per thread and trip ----
+    for (int w = 4 * (int)threadIdx.x; w < WP_FLOATS; w += 4 * 512) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(patch + w);
+      unsigned h0, l0, h1, l1;
+      split2(__builtin_shufflevector(v, v, 0, 1), h0, l0);
+      split2(__builtin_shufflevector(v, v, 2, 3), h1, l1);
+      u32x4 o;   // word = the value's own pair: low half h, high half l
+      o[0] = __builtin_amdgcn_perm(l0, h0, 0x05040100u);
+      o[1] = __builtin_amdgcn_perm(l0, h0, 0x07060302u);
+      o[2] = __builtin_amdgcn_perm(l1, h1, 0x05040100u);
+      o[3] = __builtin_amdgcn_perm(l1, h1, 0x07060302u);
+      *reinterpret_cast<u32x4*>(patch + w) = o;
+    }
+    __syncthreads();
+
+    // ---- (1) conv1_1 + PReLU -> act1 as (h, l): 100 tiles of 16 pixels, tile tt = wave + 8 m ----
+    {
+      // B = [h taps 0-7 | h taps 8-15 | l taps 0-7 | l taps 8-15] by kk; tap t = (kd, kw) = (t / 5, t % 5), t = 15: the zero column
+      const unsigned* pw[8];
+      const unsigned* const pbase = reinterpret_cast<const unsigned*>(patch) + 8 * WPW * wave + (i >> 1) * WPW;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int t0 = e, t1 = 8 + e;                                  // kk & 1 = 0 / 1
+        const int o0 = (t0 / 5) * (NFRAME * WPW), c0 = t0 % 5;
+        const int o1 = t1 < 15 ? (t1 / 5) * (NFRAME * WPW) : 0, c1 = t1 < 15 ? t1 % 5 : 0;
+        const int colA = (i & 1) + c0, colB = (i & 1) + c1;
+        const int offA = o0 + colA + (colA >= 3 ? 1 : 0), offB = o1 + colB + (colB >= 3 ? 1 : 0);
+        pw[e] = pbase + ((kk & 1) ? offB : offA);
+      }
+      const unsigned sel = kk < 2 ? 0x05040100u : 0x07060302u;         // the h halves / the l halves of two words
+      // pixel 16 tt + i = (dd = tt / 10, r = 8 (tt % 10) + (i >> 1), col = i & 1): slot 8 tt + 2 (i >> 2) + (i & 1) of the plane
+      // (quarter kk >> 1 [+ 2 for l], parity (i >> 1) & 1); the lane's four channels are bytes 8 (kk & 1) .. + 7 of the slot
+      unsigned* const aw = act + 4 * ((((kk >> 1) * 2 + ((i >> 1) & 1)) * HPLANE) + 8 * wave + 2 * (i >> 2) + (i & 1)) + 2 * (kk & 1);
+      auto tile_group = [&](auto nt_tag, int m0) {
+        constexpr int NT = decltype(nt_tag)::value;
+        unsigned w[NT][8];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[t][e] = pw[e][64 * WPW * (m0 + t)];
+        f32x4 acc[NT];
+        u32x4 B[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx) B[t][jx] = __builtin_amdgcn_perm(w[t][2 * jx + 1], w[t][2 * jx], sel);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W1a), __builtin_bit_cast(f16x8, B[t]), b1v, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W1b), __builtin_bit_cast(f16x8, B[t]), acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 y = prelu4<SLOPE01>(acc[t], sl1v);
+          unsigned h0, l0, h1, l1;
+          split2(__builtin_shufflevector(y, y, 0, 1), h0, l0);
+          split2(__builtin_shufflevector(y, y, 2, 3), h1, l1);
+          *reinterpret_cast<u32x2*>(aw + 4 * 64 * (m0 + t)) = (u32x2){h0, h1};
+          *reinterpret_cast<u32x2*>(aw + 4 * 64 * (m0 + t) + 4 * 4 * HPLANE) = (u32x2){l0, l1};
+        }
+      };
+#pragma unroll
+      for (int m0 = 0; m0 < 12; m0 += 4) tile_group(std::integral_constant<int, 4>{}, m0);
+      if (wave < 4) tile_group(std::integral_constant<int, 1>{}, 12);
+    }
+    if (threadIdx.x == 0) q_item3 = p.queue ? (int)q_ticket + 3 * (int)gridDim.x : item2 + (int)gridDim.x;
+    __syncthreads();   // act1 is complete; the patch buffer is free
+    const int item3 = q_item3;
+
+    // ---- (2) conv1_2 + PReLU + pool: 36 tiles of 16 positions, position P = 16 t + i -> (depth P / 72, row, column) ----
+    {
+      if (part == 0 && next < n_items) {
+        dma_patch_w(pf, nx, starts, pair, lane, patch);
+        if (item2 < n_items) starts = fetch_starts(pf, nx2, lane);
+      }
+      const int u = cur.u, q = cur.q(), j = cur.j();
+      float* const obase = p.out + (int64_t)u * S_N + (TD * q) * S_D + j * S_W + 4 * kk;
+#pragma unroll 1
+      for (int t = wave; t < 36; t += 8) {
+        const int P = 16 * t + i;
+        const int dq = (P * 911) >> 16, rem = P - 72 * dq, row = rem >> 1;          // P / 72 for P < 576
+        // pixel (dd = dq + kd, r = 2 row + kh, col), channels 8 (kk & 1) .. + 7: slot (((kk & 1) * 2 + (kh & 1)) * 10 + dd) * 80 +
+        // (row + kh / 2) * 2 + col of the h planes; the l planes 4 HPLANE slots on.  The taps of a pair (kd, 2 m), (kd, 2 m + 1)
+        // differ by the parity plane; the pair (0, 8) | (1, 8) by one depth
+        const int base = 16 * (((kk & 1) * 2) * HPLANE + dq * 80 + 2 * row + (i & 1));
+        const char* const a2 = reinterpret_cast<const char*>(act) + base + (kk >= 2 ? 16 * HPLANE : 0);
+        const char* const a3 = reinterpret_cast<const char*>(act) + base + (kk >= 2 ? 16 * 80 : 0);
+        f32x4 acc = b2v;
+        // pair pr: 0 .. 11 = (kd = pr / 4, kh = 2 (pr % 4) | + 1) off a2; 12 = taps (0, 8) | (1, 8) off a3; 13 = tap (2, 8) | none
+        auto rd = [&](int pr, int piece) -> u32x4 {
+          const char* ad = pr < 12 ? a2 + 1280 * (pr / 4) + 32 * (pr % 4) : pr == 12 ? a3 + 32 * 4 : a3 + 2 * 1280 + 32 * 4 - (kk >= 2 ? 16 * 80 : 0);
+          return *reinterpret_cast<const u32x4*>(ad + 16 * 4 * HPLANE * piece);
+        };
+        u32x4 bh = rd(0, 0), bl = rd(0, 1);
+#pragma unroll
+        for (int pr = 0; pr < HPAIRS; ++pr) {
+          u32x4 nh = bh, nl = bl;
+          if (pr + 1 < HPAIRS) {
+            nh = rd(pr + 1, 0);
+            nl = rd(pr + 1, 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][0]), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][0]), __builtin_bit_cast(f16x8, bl), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][1]), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          bh = nh;
+          bl = nl;
+        }
+        // PReLU, max over the column pair (lanes i, i ^ 1: the same depth and row), the even lane stores its four channels
+        const f32x4 y = prelu4<SLOPE01>(acc, sl2v);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = max_with_lane_xor1(y[r]);
+        if ((i & 1) == 0) *reinterpret_cast<f32x4*>(obase + dq * S_D + row * S_PAR) = o;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+    __syncthreads();  // the next patch is in place; act1 may be overwritten
+    item = item1;
+    item1 = item2;
+    item2 = item3;
+    cur = nx;
+    nx = nx2;
+    nx2 = ItemPos::of(item3);
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t svk_c3d2_stage1_lds_bytes(void) { return sizeof(float) * (size_t)(WACT_FLOATS + WP_FLOATS + 2048); }
+
+int svk_c3d2_stage1h(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const void* d_w1blk,
+                     const float* d_bias1, const float* d_slope1, const void* d_w2blk, const float* d_bias2,
+                     const float* d_slope2, int32_t flags, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  const bool slope01 = (flags & 2) != 0;
+  SVK_REQUIRE(ctx, (flags & ~2) == 0, "flags: only bit 1 (slopes in [0, 1]) is defined");
+  SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 1, "shape");
+  if (n_cols != NCOEF || n_crops != NCROP || crop_frames != NFRAME)
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED,
+                    "svk_c3d2_stage1h is built for the 20 x 80 x 40 cube of utils.py:20-21 (got %d x %d x %d)", n_crops,
+                    crop_frames, n_cols);
+  if (n_utt == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_feat && d_crop_idx && d_w1blk && d_bias1 && d_slope1 && d_w2blk && d_bias2 && d_slope2 && d_out,
+              "NULL buffer");
+  SVK_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_feat) & 7) == 0 && ((reinterpret_cast<uintptr_t>(d_w1blk) | reinterpret_cast<uintptr_t>(d_w2blk) |
+                                                                    reinterpret_cast<uintptr_t>(d_out)) & 15) == 0,
+              "d_feat must be 8-byte, the weight blocks and d_out 16-byte aligned");
+  SVK_REQUIRE(ctx, (int64_t)n_utt * 36 + 4 * (int64_t)ctx->num_cu < ((int64_t)1 << 31), "too many cubes for one launch");
+  Stage1hParams p;
+  p.feat = d_feat;
+  p.crop = d_crop_idx;
+  p.n_utt = n_utt;
+  p.max_frames = max_frames;
+  p.w1blk = static_cast<const u32x4*>(d_w1blk);
+  p.bias1 = d_bias1;
+  p.slope1 = d_slope1;
+  p.w2blk = static_cast<const u32x4*>(d_w2blk);
+  p.bias2 = d_bias2;
+  p.slope2 = d_slope2;
+  p.out = d_out;
+  const size_t lds = sizeof(float) * (size_t)(HACT_WORDS + WP_FLOATS);
+  if (lds + 64 > (size_t)ctx->lds_per_cu)
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage1h needs %zu bytes of LDS per workgroup (device: %d)", lds, ctx->lds_per_cu);
+  void (*kern)(const Stage1hParams) = slope01 ? c3d2_stage1h_kernel<true> : c3d2_stage1h_kernel<false>;
+  SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t items = (int64_t)n_utt * 36;
+  const unsigned grid = (unsigned)std::min<int64_t>(items, ctx->num_cu);
+  p.queue = getenv("SVK_C3D2_STATIC_ITEMS") ? nullptr : reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 112);
+  if (p.queue) SVK_HIP(ctx, hipMemsetAsync(p.queue, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, p);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
 
 int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const float* d_w1frag,

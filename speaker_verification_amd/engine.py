@@ -469,6 +469,22 @@ class Engine:
                                        self._ptr(slope2), 2 if slope01 else 0, self._ptr(out)), self.ctx)
         return out
 
+    def c3d2_stage1h(self, feat, crop_idx, tables, crop_frames=80):
+        """svk_c3d2_stage1h: the same block, boundary and output as `c3d2_stage1` through two-piece f16 products on
+        v_mfma_f32_16x16x32_f16 (tables: `FusedEmbedder.stage1h_tables()`)."""
+        torch = _torch()
+        feat = self.to_device(feat, torch.float32)
+        idx = self.to_device(crop_idx, torch.int32)
+        n, T, Cc = feat.shape
+        w1blk, bias1, slope1, w2blk, bias2, slope2 = tables[:6]
+        slope01 = bool(tables[6]) if len(tables) > 6 else False
+        out = torch.empty((n, 16, 36, 18, 16), dtype=torch.float32, device=self.device)
+        self._stream()
+        check(self.lib.svk_c3d2_stage1h(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), idx.shape[1], crop_frames,
+                                        self._ptr(w1blk), self._ptr(bias1), self._ptr(slope1), self._ptr(w2blk), self._ptr(bias2),
+                                        self._ptr(slope2), 2 if slope01 else 0, self._ptr(out)), self.ctx)
+        return out
+
     def c3d2_stage2(self, act1, tables):
         """svk_c3d2_stage2: [n, 16, 36, 18, 16] (svk_c3d2_stage1's output) -> conv2_1 -> conv2_2 -> pool2 with their
         BN + PReLU -> [n, 12, 15, 7, 32] f32 (channels last), both convolutions depth-transformed."""

@@ -234,6 +234,45 @@ class FusedEmbedder:
                         s2.expand(16).contiguous() if s2.numel() == 1 else s2.contiguous(), slope01)
         return self._stage1
 
+    def stage1h_tables(self):
+        """Operand blocks of `svk_c3d2_stage1h` (two-piece f16 products; include/svk.h): the BN-folded weights of conv1_1 /
+        conv1_2 split into halves H = f16(w), L = f16(w - H) and laid out in the lane order of v_mfma_f32_16x16x32_f16's A
+        operand (lane l = (co = l & 15, kk = l >> 4), eight halves: K = 8 kk + e), or None when the block is not C3D2's.
+          w1blk [2][64][8]      : conv1_1, tap t = 8 (kk & 1) + e (t = 5 kd + kw; 15 -> 0): H for every kk | L for kk < 2, 0 above
+          w2blk [14][2][64][8]  : conv1_2, tap pairs (a | b): ci = 8 (kk & 1) + e at tap a (kk < 2) / b (kk >= 2); H | L"""
+        hit = getattr(self, "_stage1h", False)
+        if hit is not False:
+            return hit
+        self._stage1h = None
+        base = self.stage1_tables()
+        if base is None:
+            return None
+        (w1, b1, s1, _, _, _), (w2, b2, s2, _, _, _) = self.stages[0], self.stages[1]
+        dev = w1.device
+
+        def halves(w):
+            h = w.to(torch.float16)
+            return h, (w - h.to(torch.float32)).to(torch.float16)
+
+        lane = torch.arange(64, device=dev)
+        co, kk = lane & 15, lane >> 4
+        e = torch.arange(8, device=dev)
+        w1c = torch.cat([w1.contiguous().view(16, 15), torch.zeros((16, 1), device=dev)], 1)     # [co][t], t = 15: zero
+        t = 8 * (kk & 1)[:, None] + e[None, :]                                                    # [64][8]
+        h1, l1 = halves(w1c[co[:, None], t])
+        w1blk = torch.stack([h1, torch.where((kk < 2)[:, None], l1, torch.zeros_like(l1))])       # [2][64][8]
+        w2c = w2.contiguous()[:, :, :, :, 0]                                                      # [co][ci][kd][kh]
+        pairs = [((p // 4, 2 * (p % 4)), (p // 4, 2 * (p % 4) + 1)) for p in range(12)] + [((0, 8), (1, 8)), ((2, 8), None)]
+        ci = 8 * (kk & 1)[:, None] + e[None, :]
+        w2blk = torch.zeros((14, 2, 64, 8), dtype=torch.float16, device=dev)
+        for p, (ta, tb) in enumerate(pairs):
+            wa = w2c[co[:, None], ci, ta[0], ta[1]]
+            wb = w2c[co[:, None], ci, tb[0], tb[1]] if tb is not None else torch.zeros_like(wa)
+            h, l = halves(torch.where((kk < 2)[:, None], wa, wb))
+            w2blk[p, 0], w2blk[p, 1] = h, l
+        self._stage1h = (w1blk.contiguous(), base[1], base[2], w2blk.contiguous(), base[4], base[5], base[6])
+        return self._stage1h
+
     def stage2_tables(self):
         """Operand fragments of `svk_c3d2_stage2` (conv2_1 16 -> 32 k(3,1,4); conv2_2 32 -> 32 k(3,8,1) stride
         (1,2,1) + pool), BN folded, or None when the layers differ:
