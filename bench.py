@@ -19,22 +19,24 @@ and --gpus N > 1 this process only starts N fresh rank processes of itself (RANK
 WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), polls them, ends the others when one dies, relays rank 0's JSON line.
 
 The JSON line also carries
-  roofline      -- the dominant kernel, c3d2_stage1w_kernel (cube + conv1_1 + conv1_2 + pool1, ~44 % of the step), bound
-                   MFMA: frac = ISSUED matrix work (SQ_INSTS_MFMA per cube from the committed PMC pass x 2 048 FLOP x
-                   cubes per launch) / the HIP-event duration of each launch in the timed region / 157.3 TFLOP/s -- a
-                   share of the f32 matrix pipe's issue slots, never above 1; algorithmic_frac = SURVEY 8(d)'s direct-form
-                   multiply-adds instead (what Winograd F(2,3) along depth saves shows as algorithmic_frac > frac);
+  roofline      -- the dominant kernel, c3d2_stage1h_kernel (cube + conv1_1 + conv1_2 + pool1 through two-piece f16 products,
+                   ~30 % of the step), bound MFMA: frac = ISSUED matrix work (SQ_INSTS_MFMA per cube from the committed PMC
+                   pass x 16 384 FLOP x cubes per launch) / the HIP-event duration of each launch in the timed region / the
+                   dense f16 matrix peak (16 x 157.3 TFLOP/s) -- a share of the F16 matrix pipe's issue slots, never above 1;
+                   algorithmic_frac = SURVEY 8(d)'s direct-form f32 multiply-adds against the F32 matrix peak instead;
                    counters_from / stale: what the committed counters were collected from (sha256 of the kernel sources,
                    of libsvk.so, git HEAD) and whether that differs from the sources this run uses;
   roofline_network -- the same two fractions for EVERY network kernel (stage2 = conv2_1 + conv2_2, conv3_1, conv3_2,
                    conv4_1, conv4_2, fc5) with each one's share of the step; roofline_stage2 = its stage2 row;
+                   each row names its pipe and peak (the first block: f16, the others f32);
                    valu_per_mfma / fp32_lanes_busy: the other vector instructions per MFMA (committed SQ_INSTS_VALU)
-                   and frac x (1 + valu_per_mfma x 4 / 32) -- f32 MFMA and f32 VALU never co-execute on this chip, so
-                   this is the share of the SIMDs' FP32 issue slots that is occupied at all (the rest are stalls);
+                   and, for the f32 rows, frac x (1 + valu_per_mfma x 4 / 32) -- f32 MFMA and f32 VALU never co-execute on
+                   this chip, so this is the share of the SIMDs' FP32 issue slots that is occupied at all (the rest are stalls);
   roofline_frontend -- the fused front-end kernel (HBM roof): algorithmic HBM bytes of the launches it actually
                    ran (VAD-shortened clips) over their HIP-event durations;
-  roofline_e2e  -- the whole step against the f32 matrix peak: frac from the issued MFMA work per utterance,
-                   algorithmic_frac from SURVEY 8(d)'s 676.6 MFLOP (ceiling 232 k utt/s/GPU);
+  roofline_e2e  -- the whole step: frac = the time the matrix pipes need at their peaks for the MFMA work issued per
+                   utterance / wall time; algorithmic_frac from SURVEY 8(d)'s 676.6 MFLOP against the f32 matrix peak
+                   (ceiling 232 k utt/s/GPU on that pipe);
   ranks_seen / backend / allgather_us / per_rank_ms / slowest_rank / fastest_rank / scaling_efficiency_vs -- what
                    torch.distributed reports, the HIP-event time of the embedding all-gather, every rank's own step time,
                    N x the committed 1-GPU value for reference;
@@ -66,18 +68,22 @@ C3D2_GFLOP_PER_UTT = 0.6766      # 338.3 M multiply-adds per cu
 STAGE1_GFLOP_PER_UTT = 2 * (12.4416 + 143.327232) / 1e3   # conv1_1 12.44 M + conv1_2 143.33 M multiply-adds
 STAGE2_GFLOP_PER_UTT = 2 * (46.44864 + 66.3552) / 1e3     # conv2_1 46.45 M + conv2_2 66.36 M
 MFMA_FLOP = 2048                 # v_mfma_f32_16x16x4_f32: 16 x 16 x 4 multiply-adds
+F16_MATRIX_PEAK_TFLOPS = 16 * F32_MATRIX_PEAK_TFLOPS   # "~2.5 PF dense": v_mfma_f32_16x16x32_f16 issues every 16 cycles with 8 x the K
+F16_MFMA_FLOP = 16384            # v_mfma_f32_16x16x32_f16: 16 x 16 x 32 multiply-adds
 # The network kernels as the pipeline times them (HIP-event spans): span name, kernel symbols in the rocprofv3 / PMC
 # summaries, SURVEY 8(a)'s direct-form multiply-adds per cube (millions), and the MFMA wave-instructions the kernel issues
 # per cube BY CONSTRUCTION (items x tiles x taps x 4-deep steps) -- replaced at run time by the committed
 # SQ_INSTS_MFMA counter of profiles/rNN_frontend_pmc.json when that file has the kernel (they agree to 1e-4).
+# The first block runs on the F16 matrix pipe through two-piece products (three f16 products per f32 product): its row carries
+# that pipe's FLOP per MFMA and peak; the others the f32 pipe's.
 NETWORK_KERNELS = (
-    ("stage1", ("c3d2_stage1w_kernel",), 12.4416 + 143.327232, 36 * (400 + 18 * 144)),   # 36 items x (conv1_1 + 18 tiles of conv1_2)
-    ("stage2", ("c3d2_conv21w_kernel", "c3d2_conv22w_kernel"), 46.44864 + 66.3552, 32256 + 43008),
-    ("conv3_1", ("c3d2_conv31w_kernel",), 13.824, 9600),
-    ("conv3_2", ("c3d2_tail_kernel<Conv32T>",), 30.96576, 20160),          # 20 items x 8 chunks x 28 steps x 18 MFMAs x 4 waves / 16 cubes
-    ("conv4_1", ("c3d2_tail_kernel<Conv41>",), 11.943936, 7776),            # 9 items x 4 phases x 24 steps x 18 x 8 waves / 16 cubes
-    ("conv4_2", ("c3d2_tail_kernel<Conv42>",), 12.386304, 8064),
-    ("fc5", ("fc5_kernel",), 0.589824, 576),                                   # 4 K ranges x 72 steps x 16 x 8 waves / 64 cubes
+    ("stage1", ("c3d2_stage1h_kernel",), 12.4416 + 143.327232, 36 * (100 * 2 + 36 * 42), F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # 36 items x (100 conv1_1 tiles x 2 + 36 conv1_2 tiles x 14 tap pairs x 3)
+    ("stage2", ("c3d2_conv21w_kernel", "c3d2_conv22w_kernel"), 46.44864 + 66.3552, 32256 + 43008, MFMA_FLOP, F32_MATRIX_PEAK_TFLOPS),
+    ("conv3_1", ("c3d2_conv31w_kernel",), 13.824, 9600, MFMA_FLOP, F32_MATRIX_PEAK_TFLOPS),
+    ("conv3_2", ("c3d2_tail_kernel<Conv32T>",), 30.96576, 20160, MFMA_FLOP, F32_MATRIX_PEAK_TFLOPS),   # 20 items x 8 chunks x 28 steps x 18 MFMAs x 4 waves / 16 cubes
+    ("conv4_1", ("c3d2_tail_kernel<Conv41>",), 11.943936, 7776, MFMA_FLOP, F32_MATRIX_PEAK_TFLOPS),    # 9 items x 4 phases x 24 steps x 18 x 8 waves / 16 cubes
+    ("conv4_2", ("c3d2_tail_kernel<Conv42>",), 12.386304, 8064, MFMA_FLOP, F32_MATRIX_PEAK_TFLOPS),
+    ("fc5", ("fc5_kernel",), 0.589824, 576, MFMA_FLOP, F32_MATRIX_PEAK_TFLOPS),                        # 4 K ranges x 72 steps x 16 x 8 waves / 64 cubes
 )
 N_CORPUS = 148642                # VoxCeleb1 dev utterances (README.md:5-7) = BASELINE configs[4]
 N_TEST, N_TEST_SPK = 4874, 40    # VoxCeleb1 verification split (README.md:4-7)
@@ -1009,8 +1015,9 @@ def main():
             cubes_total = float(sum(sp["cubes"] for sp in kernel_events))
             network_rows = {}
             issued_gflop_per_utt = 0.0
+            pipe_seconds_per_utt = 0.0       # time the matrix pipes need for the issued work at their peaks (f32 and f16 rows each at its own)
             covered_ms = 0.0
-            for name, symbols, mmac, mfma_design in NETWORK_KERNELS:
+            for name, symbols, mmac, mfma_design, mfma_flop, peak in NETWORK_KERNELS:
                 evs = [sp[name] for sp in kernel_events if name in sp]
                 if not evs:
                     continue
@@ -1030,13 +1037,18 @@ def main():
                     got, _ = pmc_counter(sym, "SQ_INSTS_VALU")
                     valu = None if (got is None or valu is None) else valu + got
                 valu_per_mfma = None if (valu is None or not all(src) or mfma <= 0) else (valu - mfma) / mfma
-                tf_issued = cubes_total * mfma * MFMA_FLOP / ms / 1e9
+                tf_issued = cubes_total * mfma * mfma_flop / ms / 1e9
                 tf_alg = cubes_total * 2 * mmac * 1e6 / ms / 1e9
-                issued_gflop_per_utt += mfma * MFMA_FLOP / 1e9
+                issued_gflop_per_utt += mfma * mfma_flop / 1e9
+                pipe_seconds_per_utt += mfma * mfma_flop / (peak * 1e12)
                 covered_ms += ms
+                f16 = mfma_flop == F16_MFMA_FLOP
                 network_rows[name] = {
-                    "bound": "mfma", "achieved": tf_issued, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf_issued / F32_MATRIX_PEAK_TFLOPS, "algorithmic_tflops": tf_alg,
+                    "bound": "mfma", "achieved": tf_issued, "peak": peak, "unit": "TFLOP/s",
+                    "pipe": "f16 (v_mfma_f32_16x16x32_f16, two-piece products: 3 issued products per f32 product)" if f16
+                            else "f32 (v_mfma_f32_16x16x4_f32)",
+                    "frac": tf_issued / peak, "algorithmic_tflops": tf_alg,
+                    # SURVEY 8(d)'s direct-form f32 multiply-adds against the F32 matrix peak, whatever pipe the kernel uses
                     "algorithmic_frac": tf_alg / F32_MATRIX_PEAK_TFLOPS, "kernel": " + ".join(symbols),
                     "avg_launch_ms": ms / len(evs), "cubes_per_launch": cubes_total / len(evs),
                     "mfma_per_cube": mfma, "mfma_per_cube_by_construction": mfma_design, "mfma_source": src[0],
@@ -1044,8 +1056,10 @@ def main():
                     "stale": None if not all(src) or src[0].startswith("by ") else pmc_provenance(src[0])[2],
                     "direct_form_mmac_per_cube": mmac, "share_of_step": ms / args.steps / ms_per_step,
                     "valu_per_mfma": valu_per_mfma,
-                    "fp32_lanes_busy": None if valu_per_mfma is None
-                    else tf_issued / F32_MATRIX_PEAK_TFLOPS * (1.0 + valu_per_mfma * 4.0 / 32.0)}
+                    # (the f32 MFMA excludes every other vector instruction for its 32 cycles; the f16 one holds the vector issue
+                    # for 8 of its 16: no such sum for the first block)
+                    "fp32_lanes_busy": None if valu_per_mfma is None or f16
+                    else tf_issued / peak * (1.0 + valu_per_mfma * 4.0 / 32.0)}
             r1 = network_rows["stage1"]
             t1, t1_src = pmc_traffic(r1["kernel"])
             main_roofline = dict(r1)
@@ -1053,22 +1067,27 @@ def main():
                 "traffic": None if t1 is None else t1 * r1["cubes_per_launch"] / 1024.0, "traffic_source": t1_src,
                 "traffic_note": "PMC pass: 1 024 cubes per launch, scaled by cubes_per_launch / 1024; algorithmic bytes per cube: "
                                 "47 520 (features, re-read 36 x from L2) + 663 552 written",
-                "kernel": r1["kernel"] + " (cube + conv1_1 + conv1_2 via Winograd F(2,3) along depth + pool1, "
-                          "v_mfma_f32_16x16x4_f32)",
-                "note": "frac = issued MFMA work (SQ_INSTS_MFMA per cube x 2 048 FLOP x cubes per launch) / HIP-event launch "
-                        "time / 157.3 TFLOP/s (MI355X_MICROARCH.md): the share of the f32 matrix pipe's issue slots.  "
-                        "algorithmic_frac counts SURVEY 8(d)'s direct-form multiply-adds (conv1_1 12.44 M + conv1_2 143.33 M per "
-                        "cube) instead and exceeds it because conv1_2 issues 2/3 of its products while conv1_1 recomputes the "
-                        "depth halo per item (20 depths for 18) with K padded 15 -> 16.  `stale`: the committed counters were "
+                "kernel": r1["kernel"] + " (cube + conv1_1 + conv1_2 + pool1 through two-piece f16 products, "
+                          "v_mfma_f32_16x16x32_f16)",
+                "note": "frac = issued MFMA work (SQ_INSTS_MFMA per cube x 16 384 FLOP x cubes per launch) / HIP-event launch "
+                        "time / the dense f16 matrix peak (16 x the f32 one: MI355X_MICROARCH.md '~2.5 PF'): the share of the F16 "
+                        "matrix pipe's issue slots.  Every f32 product is issued as three f16 products (x = h + l: h_x h_w + "
+                        "l_x h_w + h_x l_w, f32 accumulation; conv1_1 as two K = 32 blocks of which 3/4 carry products).  "
+                        "algorithmic_frac counts SURVEY 8(d)'s direct-form f32 multiply-adds (conv1_1 12.44 M + conv1_2 143.33 M per "
+                        "cube) against the F32 matrix peak: what the same sums would need on the pipe the reference's dtype "
+                        "names -- above 1 is the point of the construction.  `stale`: the committed counters were "
                         "collected from other kernel sources than this run's (csrc_sha differs); SQ_INSTS_MFMA is then checked "
-                        "against mfma_per_cube_by_construction, valu_per_mfma / fp32_lanes_busy describe the profiled code",
+                        "against mfma_per_cube_by_construction, valu_per_mfma describes the profiled code",
                 "this_run": pmc_provenance("")[1]})
             stage2_roofline = network_rows.get("stage2")
             network_rows["_covered_share_of_step"] = covered_ms / args.steps / ms_per_step
         result = {
             "metric": "utterances/sec (MFCC->embed->cosine)", "value": value, "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            # f32 in, f32 out, f32 accumulation everywhere; the first block's PRODUCTS are three f16 piece products per f32 product
+            # (22-bit operands: 1e-6 of the activation scale from the f32 kernel it replaces, parity bars unchanged)
+            "dtype": "f32 (first block: two-piece f16 products, f32 accumulation)",
             "data": "synthetic (seeded formant 'voices', 3 s / 16 kHz int16, generated on device); C3D2 weights: %s"
                     % ("seeded random init" if args.random_init else
                        "the committed checkpoint trained on synthetic speakers disjoint from the corpus's (tools/train_synth_checkpoint.py)"),
@@ -1098,19 +1117,20 @@ def main():
             "roofline_stage2": stage2_roofline,
             "roofline_network": network_rows,
             "roofline_e2e": {"bound": "mfma",
-                             "achieved": None if issued_gflop_per_utt is None else value * issued_gflop_per_utt / 1e3,
-                             "peak": F32_MATRIX_PEAK_TFLOPS * world, "unit": "TFLOP/s",
-                             "frac": None if issued_gflop_per_utt is None
-                             else value * issued_gflop_per_utt / 1e3 / (F32_MATRIX_PEAK_TFLOPS * world),
+                             "achieved": None if issued_gflop_per_utt is None else value * pipe_seconds_per_utt / world,
+                             "peak": 1.0, "unit": "matrix-pipe issue time / wall time",
+                             "frac": None if issued_gflop_per_utt is None else value * pipe_seconds_per_utt / world,
                              "issued_gflop_per_utt": issued_gflop_per_utt,
                              "algorithmic_tflops": e2e_tflops,
                              "algorithmic_frac": e2e_tflops / (F32_MATRIX_PEAK_TFLOPS * world),
                              "gflop_per_utt": C3D2_GFLOP_PER_UTT,
-                             "note": "whole step vs the dense f32 matrix peak of the N GPUs.  frac = utterances/s x the MFMA work "
-                                     "the network kernels ISSUE per utterance (sum of the roofline_network rows: every layer "
-                                     "is a libsvk f32-MFMA kernel); algorithmic_frac = utterances/s x SURVEY 8(d)'s 676.6 MFLOP "
-                                     "of direct-form sums (ceiling 232 k utt/s per GPU) -- conv1_2 .. conv4_2 run through "
-                                     "Winograd F(2,3) along depth and issue 2/3 of theirs"},
+                             "note": "whole step.  frac = utterances/s x the time the matrix pipes need, at their dense peaks, for the "
+                                     "MFMA work the network kernels ISSUE per utterance (sum over the roofline_network rows: the "
+                                     "first block on the f16 pipe at 16 x the f32 rate, the others on the f32 pipe; with every "
+                                     "kernel on the f32 pipe this is rounds 2 - 4's definition); algorithmic_frac = utterances/s x "
+                                     "SURVEY 8(d)'s 676.6 MFLOP of direct-form f32 sums / the f32 matrix peak (ceiling 232 k utt/s "
+                                     "per GPU on that pipe) -- conv2_1 .. conv4_2 run through Winograd F(2,3) along depth and issue "
+                                     "2/3 of theirs, the first block issues 3 f16 products per f32 product at 16 x the rate"},
             "eer": {"eer": eer, "auc": auc, "eer_device": eer_dev, "auc_device": auc_dev, "pairs": int(labels.size),
                     "short_clips": bad,
                     "note": ("random-init C3D2 (--random-init): an EER near 0.5 is that of an untrained network; the statement is "

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 109 /* 0.1.8: svk_c3d2_stage1h (the first block through two-piece f16 products); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
+#define SVK_VERSION 109 /* 0.1.8: svk_c3d2_stage1 runs on the f16 matrix pipe through two-piece products (new weight tables d_w1blk / d_w2blk); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -247,41 +247,29 @@ int svk_roc_eer(svk_ctx* ctx, const float* d_scores, const uint8_t* d_labels, in
 /* ---- the first block of the embedding network ----------------------------------------------------
  * model.py:110-117 + :141-150 (C3D2): cube (utils.py:351-379) -> conv1_1 (1 -> 16, kernel (3,1,5)) -> BN -> PReLU
  * -> conv1_2 (16 -> 16, kernel (3,9,1), stride (1,2,1)) -> BN -> PReLU -> MaxPool3d((1,1,2)), eval mode, as ONE
- * kernel on v_mfma_f32_16x16x4_f32 (exact f32): conv1_1's output (3.3 MB per cube) lives only in LDS.  The host
- * folds the BatchNorm statistics into weights / biases and lays the operands out:
- *   d_w1frag [4][64]    float: lane l = (channel l & 15, kq = l >> 4), row k = 4 jj + kq of the 16 x 16 conv1_1
- *                       GEMM: k < 15 -> weight of tap (kd = k / 5, kw = k % 5), k = 15 -> 0;   d_bias1 [16]
- *   d_w2frag [27][64][4] float: lane (co = l & 15, kk = l >> 4), element e = W2[co][ci = 4 kk + e][kd][kh] of
- *                       tap t = 9 kd + kh;   d_bias2 [16];   d_slope1 / d_slope2 [16] PReLU slopes per channel
- * d_feat [n_utt][max_frames][40], d_crop_idx [n_utt][20] as for svk_cube_gather (crop -1 -> zero cube).
- * conv1_2 runs through Winograd's F(2, 3) along depth (every C3D2 kernel is 3 taps deep: 2 / 3 of the multiply-adds; the
- * transformed weights are derived in the kernel from d_w2frag; the same sums in another association, ~1e-6 relative from
- * the direct form); the remainder rows 32 .. 35 of two depth pairs share one M tile, cut by accumulator over the
- * workgroup's eight waves.
+ * kernel: conv1_1's output (3.3 MB per cube) lives only in LDS.  Since 0.1.8 on v_mfma_f32_16x16x32_f16 through TWO-PIECE
+ * products: a value x travels as the halves h = f16(x), l = f16(x - h) (22 significant bits in four bytes) and
+ * x w = h_x h_w + l_x h_w + h_x l_w, three f16 products, exact in the f32 they are accumulated in (measured on this network:
+ * 1 - 5e-7 of the activation scale from the f64 convolution; the f32 direct form: 2 - 8e-7).  Direct form (the depth
+ * transform's adds do not distribute over pieces), two taps per K = 32 block.  The host folds the BatchNorm statistics into
+ * weights / biases, splits the weights and lays them out in the lane order of the MFMA's A operand (lane l = (co = l & 15,
+ * kk = l >> 4), eight halves: K = 8 kk + e):
+ *   d_w1blk [2][64][8 halves]: conv1_1, element e = tap t = 8 (kk & 1) + e (t = 5 kd + kw; t = 15 -> 0):
+ *                        block 0 = H for every kk, block 1 = L for kk < 2 and 0 for kk >= 2;   d_bias1 [16]
+ *   d_w2blk [14][2][64][8 halves]: conv1_2's tap pairs (a | b): pr < 12 -> a = (kd = pr / 4, kh = 2 (pr % 4)), b = (kd, kh + 1);
+ *                        pr = 12 -> (0, 8) | (1, 8); pr = 13 -> (2, 8) | none (zeros).  Element e =
+ *                        W2[co][ci = 8 (kk & 1) + e][tap a if kk < 2 else b]; block 0 = H pieces, block 1 = L pieces;
+ *                        d_bias2 [16];   d_slope1 / d_slope2 [16] PReLU slopes per channel
+ * d_feat [n_utt][max_frames][40] f32, d_crop_idx [n_utt][20] as for svk_cube_gather (a start outside the clip -> zero rows).
  * d_out: the activation after the pool, float32, channels last: [n_utt][16 d][36 h][18 w][16 c]
  * flags bit 1 (value 2) = the caller asserts every PReLU slope lies in [0, 1] (then prelu(v) = max(v, slope v): two
  * instructions per value instead of four); every other bit must be 0.
  * Geometry other than the 20 x 80 x 40 cube -> SVK_ERR_UNSUPPORTED (the torch module is the path for other models). */
 size_t svk_c3d2_stage1_lds_bytes(void);
 int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
-                    const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const float* d_w1frag,
-                    const float* d_bias1, const float* d_slope1, const float* d_w2frag, const float* d_bias2,
+                    const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const void* d_w1blk,
+                    const float* d_bias1, const float* d_slope1, const void* d_w2blk, const float* d_bias2,
                     const float* d_slope2, int32_t flags, float* d_out);
-
-/* The same block (same model.py lines, same d_feat / d_crop_idx / d_out, same flags) on v_mfma_f32_16x16x32_f16 through
- * TWO-PIECE products: a value x travels as the halves h = f16(x), l = f16(x - h) (22 significant bits in four bytes) and
- * x w = h_x h_w + l_x h_w + h_x l_w, three f16 products accumulated in f32 (measured on this network: 1 - 5e-7 of the
- * activation scale from the f64 convolution; the f32 direct form: 2 - 8e-7).  Direct form (the depth transform's adds do not
- * distribute over pieces), two taps per K = 32 block.  The host splits the BN-folded weights:
- *   d_w1blk [2][64][8 halves]: conv1_1's A blocks, lane l = (co = l & 15, kk = l >> 4), element e = tap t = 8 (kk & 1) + e
- *                        of conv1_1 (t = 5 kd + kw; t = 15 -> 0): block 0 = H (all lanes), block 1 = L for kk < 2, 0 for kk >= 2
- *   d_w2blk [14][2][64][8 halves]: conv1_2's tap pairs (a | b): pr < 12 -> a = (kd = pr / 4, kh = 2 (pr % 4)), b = (kd, kh + 1);
- *                        pr = 12 -> (0, 8) | (1, 8); pr = 13 -> (2, 8) | none (zeros).  Lane (co, kk): element e =
- *                        W2[co][ci = 8 (kk & 1) + e][tap a if kk < 2 else b]; block 0 = H pieces, block 1 = L pieces */
-int svk_c3d2_stage1h(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
-                     const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const void* d_w1blk,
-                     const float* d_bias1, const float* d_slope1, const void* d_w2blk, const float* d_bias2,
-                     const float* d_slope2, int32_t flags, float* d_out);
 
 /* The second block, model.py:119-124 + :151-158: conv2_1 (16 -> 32, kernel (3,1,4)) -> BN -> PReLU -> conv2_2
  * (32 -> 32, kernel (3,8,1), stride (1,2,1)) -> BN -> PReLU -> MaxPool3d((1,1,2)), two f32-MFMA kernels with the

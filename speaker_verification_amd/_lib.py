@@ -78,7 +78,6 @@ SIGNATURES = {
     "svk_l2_dist": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "svk_c3d2_stage1_lds_bytes": (C.c_size_t, []),
     "svk_c3d2_stage1": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "svk_c3d2_stage1h": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_stage2": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "svk_c3d2_conv31": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "svk_c3d2_conv32t": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),

@@ -1,33 +1,29 @@
-// The C3D2 embedding network's first three blocks (model.py:110-131, :141-164) on v_mfma_f32_16x16x4_f32.
-//   c3d2_stage1w_kernel   cube + conv1_1 + conv1_2 + pool1; conv1_2 through Winograd's F(2, 3) along depth, the 4-row
-//                         remainders of two depth pairs sharing one M tile
-//   c3d2_conv21w_kernel   conv2_1, depth-transformed
+// The C3D2 embedding network's first three blocks (model.py:110-131, :141-164).
+//   c3d2_stage1h_kernel   cube + conv1_1 + conv1_2 + pool1 on v_mfma_f32_16x16x32_f16 through two-piece f16 products (round 4)
+//   c3d2_conv21w_kernel   conv2_1, v_mfma_f32_16x16x4_f32, depth-transformed (Winograd F(2, 3) along depth)
 //   c3d2_conv22w_kernel   conv2_2 + pool2, depth-transformed
 //   c3d2_conv31w_kernel   conv3_1, depth-transformed; writes the chunked, column-major layout c3d2_tail_kernel<Conv32T> stages
 // (conv3_2, conv4_1, conv4_2 and FC5 live in c3d2_tail.hip.)  BatchNorm (eval mode) is folded into weights and biases by
-// the host (model.FusedEmbedder).  The kernels that share a CU between workgroups (conv21w, conv22w, conv31w) draw their
-// work items from a device-wide counter.  What rounds 2 and 3 built and superseded -- the direct-form kernels, the first
-// block without merged remainder tiles, the t-plane first block, the K-split conv3_2 -- is
-// tools/experiments/c3d2_superseded_r3.patch with its measured numbers in tools/experiments/README.md.
+// the host (model.FusedEmbedder).  Work items come from device-wide counters.  What earlier rounds built and superseded is
+// under tools/experiments/ with its measured numbers: the direct-form f32 kernels, the t-plane first block, the K-split conv3_2
+// (c3d2_superseded_r3.patch) and the f32 first block through the depth transform, round 4's 7.12 ms kernel
+// (stage1_f32_winograd.patch).
 //
-// The first block of the C3D2 embedding network as ONE gfx950 kernel:
+// The first block as ONE gfx950 kernel:
 //   feature rows + crop starts -> cube (utils.py:351-379) -> conv1_1 (1 -> 16, k(3,1,5)) + BN + PReLU
 //   -> conv1_2 (16 -> 16, k(3,9,1), stride (1,2,1)) + BN + PReLU -> MaxPool3d((1,1,2))
 // (/root/reference/model.py:110-117 and :141-150).  These two layers are 46 % of the network's multiply-adds, and
-// conv1_1's output is the network's largest tensor (3.3 MB per cube); here it only ever exists as a 115 KB tile in LDS.
+// conv1_1's output is the network's largest tensor (3.3 MB per cube); here it only ever exists as a 100 KB tile in LDS.
 //
 // Work item = (cube u, pooled output column j, half q of the output depths): conv1_2 outputs
 //   d in [8q, 8q + 8), h in [0, 36), w in {2j, 2j + 1}  ->  pooled column j, 16 channels.
 // A persistent workgroup of 8 waves (two per SIMD; it owns the CU's LDS) loops over items:
-//   1. the 12 x 80 x 6 cube patch the item needs is moved into LDS by LDS-DMA inside the previous item's matrix work;
-//   2. conv1_1 as a GEMM: [16 channels] x [K = 15 taps + 1 pad] x [16 pixels] (A = the weights, B gathered from the patch),
-//      result + PReLU written to the act1 tile in LDS: 10 depths x 80 rows x 2 columns x 16 channels;
-//   3. conv1_2 as an implicit GEMM, depth-transformed (below): the transformed weight matrix lives in 144 VGPRs per wave
-//      (B operand); the A operand of a row tap is ONE ds_read_b128 per lane and depth plane at a compile-time offset;
-//   4. bias, PReLU, max over the column pair (the two columns of a pooling window are adjacent rows of the
-//      accumulator tile: no lane movement), store.
-// K is permuted identically on both operands (lane (i, kk) holds channels 4 kk .. 4 kk + 3 of a 16-channel
-// chunk, MFMA step e uses element e), so fragments are plain 16-byte accesses.
+//   1. the 12 x 80 x 6 cube patch the item needs is moved into LDS by LDS-DMA inside the previous item's matrix work and
+//      converted in place to (h, l) half pairs by the waves that fetched it;
+//   2. conv1_1 as a GEMM [16 channels] x [K = 32: 15 taps + pad, h | l] x [16 pixels], + PReLU, split into (h, l), written to
+//      the act1 tile in LDS: 10 depths x 80 rows x 2 columns x 16 channels;
+//   3. conv1_2 as an implicit GEMM in the direct form, two taps per K = 32 block, the weights of all 27 taps in 112 VGPRs;
+//   4. bias (in the accumulator), PReLU, max over the column pair (adjacent lanes: one DPP instruction), 16-byte stores.
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -60,19 +56,20 @@ struct ItemPos {
   }
 };
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 struct Stage1Params {
   const float* feat;
   const int32_t* crop;
   int32_t n_utt, max_frames;
-  const float* w1frag;   // [4][64]: B operand of the conv1_1 GEMM, k = 4 jj + (lane >> 4): tap (k / 5, k % 5), k = 15: zero
-  const float* bias1;    // [16]
-  const float* slope1;   // [16]
-  const f32x4* w2frag;   // [27][64]: lane (co = l & 15, kk = l >> 4), element e = W[co][4 kk + e][kd][kh], tap = 9 kd + kh
-  const float* bias2;    // [16]
-  const float* slope2;   // [16]
+  const u32x4* w1blk;    // [2][64]: conv1_1's A blocks (8 halves per lane): [H taps 0-15 | H taps 0-15], [L taps 0-15 | 0]
+  const float* bias1;
+  const float* slope1;
+  const u32x4* w2blk;    // [14 pairs][2][64]: [H_a | H_b], [L_a | L_b]; lane (co = l & 15, kk): ci = 8 (kk & 1) + e, tap a (kk < 2) / b
+  const float* bias2;
+  const float* slope2;
   float* out;
-  unsigned* queue;                     // work-item counter (zeroed by the host before the launch), or NULL = items at a fixed stride
-  unsigned long long* stamps;          // tuning builds only (-DSVK_TUNING): [grid][4 waves][6] summed phase cycles
+  unsigned* queue;
 };
 
 // In-kernel phase stamps (s_memtime) for `make TUNING=1` builds; compiled out of the shipped library.
@@ -101,27 +98,6 @@ __device__ __forceinline__ int fetch_starts(const Stage1Params& p, ItemPos it, i
   return cr[lane < PD ? lane : 0];
 }
 
-// -----------------------------------------------------------------------------------------------------
-// The same block with conv1_2 through Winograd's F(2, 3) ALONG DEPTH (every C3D2 kernel is 3 deep, stride 1):
-// for an output depth pair (2 P, 2 P + 1) and act1 depths x0 .. x3 = 2 P .. 2 P + 3,
-//     t0 = x0 - x2,  t1 = x1 + x2,  t2 = x2 - x1,  t3 = x1 - x3,
-//     G0 = g0,  G1 = (g0 + g1 + g2) / 2,  G2 = (g0 - g1 + g2) / 2,  G3 = g2      (g = the three depth taps of a row tap),
-//     a_k = sum over (row tap, channel) of t_k G_k,        y(2 P) = a0 + a1 + a2,   y(2 P + 1) = a1 - a2 - a3:
-// four MFMAs where the direct form issues six.  The transform of the A operand is VALU work per fragment (16 adds
-// per 16 MFMAs), and a wave does not overlap its own VALU with its own MFMAs on this chip (measured: every add between
-// two MFMAs of a single resident wave costs its full issue time and more) -- so this variant runs EIGHT waves per
-// workgroup, two per SIMD, each with its own M tiles: one wave's adds, LDS waits and epilogues run under the other's
-// MFMAs (the conv1_1 phase, VALU-bound in the four-wave kernel, gains the same way).
-//   * act1 pixel p at 16 p + 4 (p >> 2) + 16 (p >> 4): an M tile is 8 output rows x 2 columns of one depth, its 16
-//     pixels 4 apart; 4 hl + 16 ((hl + s) >> 2) + 16 wc (mod 64) are 16 different multiples of 4, one conflict-free
-//     ds_read_b128 per quarter wave.  The lane part depends on the row tap only through s = kh >> 1: five bases.
-//   * wave = (pair P = wave & 3, part = wave >> 2): part 0 owns the tiles at rows 0, 8, 16, part 1 those at 24 and 28
-//     (the last repeats rows 28 .. 31 and stores 32 .. 35): five tiles of 144 MFMAs per SIMD and item.
-//   * the weights G (36 fragments = 144 VGPRs) are derived in the prologue from the same 27 fragments the direct kernel
-//     takes: the C-ABI does not change.
-// -----------------------------------------------------------------------------------------------------
-constexpr int WPIXF = 18;                                  // average floats per act1 pixel in this layout
-constexpr int WACT_FLOATS = WPIXF * DIN * NFRAME * 2;
 constexpr int WPW = 8;                                     // floats per patch row in LDS: [ww 0 1 2 | - | ww 3 4 5 | -]
 constexpr int WP_FLOATS = PD * NFRAME * WPW;               // 7 680
 
@@ -204,11 +180,6 @@ __device__ __forceinline__ float max_raw(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
-__device__ __forceinline__ float max3_raw(float a, float b, float c) {
-  float d;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
 template <bool SLOPE01>
 __device__ __forceinline__ f32x4 prelu4(f32x4 v, f32x4 slope) {
   f32x4 o;
@@ -269,15 +240,6 @@ __device__ __forceinline__ void prelu_pairs(f32x2 (&y0)[2], f32x2 (&y1)[2], f32x
     }
   }
 }
-// max(prelu(a), prelu(b)) with one slope (the pool over a column pair): one packed product + v_max3 + v_max
-template <bool SLOPE01>
-__device__ __forceinline__ float prelu_max2(f32x2 v, f32x2 slope2) {
-  if (SLOPE01) {
-    const f32x2 m = pk_mul(v, slope2);
-    return max_raw(max3_raw(v[0], m[0], v[1]), m[1]);
-  }
-  return fmaxf(prelu(v[0], slope2[0]), prelu(v[1], slope2[1]));
-}
 __device__ __forceinline__ void wino_input_pair(const f32x4 (&x)[4], int hf, f32x2 (&t)[4][2]) {
   f32x2 xh[4];
 #pragma unroll
@@ -286,322 +248,6 @@ __device__ __forceinline__ void wino_input_pair(const f32x4 (&x)[4], int hf, f32
   t[1][hf] = pk_add(xh[1], xh[2]);
   t[2][hf] = pk_sub(xh[2], xh[1]);
   t[3][hf] = pk_sub(xh[1], xh[3]);
-}
-
-// One (merged tile, k) unit of the kernel below: accumulator a_k of the tile made of rows 32 .. 35 of the depth pairs
-// 2 m and 2 m + 1 (lanes 0 .. 7 / 8 .. 15), k a compile-time constant: t_k needs two of the four depth planes -- two
-// ds_read_b128, two packed adds and four MFMAs per row tap.
-template <int K>
-__device__ __forceinline__ f32x4 stage1w_merged_unit(const float* const (&pbm)[5], const f32x4 (&G)[36]) {
-  constexpr int DA = K == 0 ? 0 : K == 2 ? 2 : 1, DB = K == 0 ? 2 : K == 1 ? 2 : K == 2 ? 1 : 3;   // t_K = x[DA] -/+ x[DB]
-  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;   // two chains: a dependent MFMA would wait 40 cycles for its predecessor
-  f32x4 xa = *reinterpret_cast<const f32x4*>(pbm[0] + 160 * WPIXF * DA), xb = *reinterpret_cast<const f32x4*>(pbm[0] + 160 * WPIXF * DB);
-#pragma unroll
-  for (int kh = 0; kh < 9; ++kh) {
-    const f32x2 alo = __builtin_shufflevector(xa, xa, 0, 1), ahi = __builtin_shufflevector(xa, xa, 2, 3);
-    const f32x2 blo = __builtin_shufflevector(xb, xb, 0, 1), bhi = __builtin_shufflevector(xb, xb, 2, 3);
-    const f32x2 tlo = K == 1 ? pk_add(alo, blo) : pk_sub(alo, blo), thi = K == 1 ? pk_add(ahi, bhi) : pk_sub(ahi, bhi);
-    __builtin_amdgcn_sched_barrier(0);
-    if (kh + 1 < 9) {
-      const int off = 32 * (kh + 1) + 4 * ((kh + 1) >> 1);
-      xa = *reinterpret_cast<const f32x4*>(pbm[(kh + 1) >> 1] + 160 * WPIXF * DA + off);
-      xb = *reinterpret_cast<const f32x4*>(pbm[(kh + 1) >> 1] + 160 * WPIXF * DB + off);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(tlo[0], G[9 * K + kh][0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tlo[1], G[9 * K + kh][1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(thi[0], G[9 * K + kh][2], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(thi[1], G[9 * K + kh][3], acc1, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  return acc0 + acc1;
-}
-
-// Merged remainder tiles (round 3): 36 output rows are four 8-row tiles + 4 rows.  The round-2 kernel covered the remainder
-// with a fifth tile that repeated rows 28 .. 31 (40 rows issued for every 36: 720 MFMAs per SIMD and item); here the
-// remainders of two depth pairs make ONE tile (lanes 0 .. 7: pair 2 m, lanes 8 .. 15: pair 2 m + 1), and the two merged
-// tiles of an item are cut by accumulator into eight (tile m, k) units of 36 MFMAs, one per wave: every wave issues two
-// full tiles + one unit = 324 MFMAs (648 per SIMD, - 10 %), the units' accumulators meet in 8 KB of LDS and waves 0 and 4
-// finish the two tiles behind the item's last barrier.  The sums are those of the round-2 kernel, in the same order.
-template <bool SLOPE01>
-__global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p) {
-  extern __shared__ __attribute__((aligned(16))) float smem_c3d2[];
-  float* act = smem_c3d2;               // [WACT_FLOATS]
-  float* patch = act + WACT_FLOATS;     // [WP_FLOATS]: [12 dd][80 h][8]
-  float* const exch = patch + WP_FLOATS; // [2 m][4 k][64 lanes] f32x4: the merged tiles' accumulators
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: a scalar
-  const int i = lane & 15, kk = lane >> 4;
-  const int pair = wave & 3, part = wave >> 2;
-  const int n_items = p.n_utt * 36;
-#ifdef SVK_TUNING
-  const unsigned long long clk_entry = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one counter for the whole chip
-#endif
-
-  f32x4 G[36];   // [k][kh]
-#pragma unroll
-  for (int kh = 0; kh < 9; ++kh) {
-    const f32x4 g0 = p.w2frag[kh * 64 + lane], g1 = p.w2frag[(9 + kh) * 64 + lane], g2 = p.w2frag[(18 + kh) * 64 + lane];
-    G[kh] = g0;
-    G[9 + kh] = 0.5f * ((g0 + g2) + g1);
-    G[18 + kh] = 0.5f * ((g0 + g2) - g1);
-    G[27 + kh] = g2;
-  }
-  float w1[4];
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) w1[jj] = p.w1frag[jj * 64 + lane];
-  f32x4 b1v, sl1v;   // conv1_1 with the operands swapped: a lane holds channels 4 kk .. 4 kk + 3 of ONE pixel
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    b1v[r] = p.bias1[4 * kk + r];
-    sl1v[r] = p.slope1[4 * kk + r];
-  }
-  const float b2 = p.bias2[i], sl2 = p.slope2[i];
-
-  int starts = 0;
-  // Items: the first three of a workgroup at a fixed stride, every later one drawn from a device-wide counter TWO items ahead (the
-  // crop starts of item k + 2 and the patch of item k + 1 are fetched during item k).  The CUs of this chip do not run at one
-  // clock (2 344 .. 2 390 MHz across the 256 workgroups of one launch, in-kernel stamps): with equal shares the slowest XCD's
-  // workgroups left the loop 166 us after the fastest one's, 2.3 % of the kernel.
-  __shared__ int q_item3;
-  int item = blockIdx.x, item1 = item + (int)gridDim.x, item2 = item1 + (int)gridDim.x;
-  ItemPos cur = ItemPos::of(item), nx = ItemPos::of(item1), nx2 = ItemPos::of(item2);
-  if (item < n_items) {
-    starts = fetch_starts(p, cur, lane);
-    if (part == 0) dma_patch_w(p, cur, starts, pair, lane, patch);
-    if (item1 < n_items) starts = fetch_starts(p, nx, lane);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed (the compiler emits this wait too; spelt out: the barrier relies on it)
-  __syncthreads();
-#ifdef SVK_TUNING
-  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
-  // the clock the chip holds under this kernel's load: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime) over the loop
-  const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  while (item < n_items) {
-    SVK_STAMP(ts0);
-    const int next = item1;
-    unsigned q_ticket = 0;   // (requested here, published with barrier 1: the round trip runs under the conv1_1 phase)
-    if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
-    SVK_STAMP(ts1);
-
-    // ---- conv1_1 + PReLU: 100 tiles of 16 pixels, tile tt = wave + 8 m: 13 for waves 0 .. 3, 12 for the others, four at
-    // a time (patch offset 64 tt and act1 offset 288 tt are linear in tt: per-lane bases + immediates) ----
-    {
-      const float* pl[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {   // (recomputed per item: this kernel has no registers to spare)
-        // tap k = 4 jj + kk = (kd, kw) = (k / 5, k % 5) without the division: kk + (4 jj mod 5) wraps at most once
-        const int t5 = kk + (4 * jj) % 5, wrap = t5 >= 5 ? 1 : 0;
-        const int kw = t5 - 5 * wrap, kd = (4 * jj) / 5 + wrap;
-        const bool pad = jj == 3 && kk == 3;                // k = 15: the zero row of the weights, any finite operand
-        const int col = (i & 1) + (pad ? 0 : kw);           // patch column 0 .. 5 at float col + (col >= 3) of the 8-float row
-        pl[jj] = patch + 8 * WPW * wave + (i >> 1) * WPW + col + (col >= 3 ? 1 : 0) + (pad ? 0 : kd * (NFRAME * WPW));
-      }
-      // M = channel (A = the weights), N = pixel (B = the patch values): a lane ends up with channels 4 kk .. 4 kk + 3 of pixel i --
-      // 16 contiguous bytes of the act1 tile: ONE ds_write_b128 per tile (round 4; with M = pixel a lane held one channel of four
-      // pixels: four ds_write_b32 per tile; the same products in the same order, bit-identical output, phase 5.8 k -> 5.5 k cycles)
-      float* const al = act + 16 * WPIXF * wave + 68 * (i >> 2) + 16 * (i & 3) + 4 * kk;
-      // Fragments a step ahead: step = (tap quarter jj, tile pair): one ds_read2st64_b32 = the pair's two values, read while the
-      // previous step's two MFMAs run (left to the scheduler, every read sat directly in front of its MFMAs with a full
-      // lgkmcnt(0) wait: the LDS round trip per 64 cycles of matrix work, covered only by the SIMD's other wave)
-      float av[2][2];
-      av[0][0] = pl[0][0];
-      av[0][1] = pl[0][64 * WPW];
-#pragma unroll
-      for (int g4 = 0; g4 < 3; ++g4) {
-        f32x4 acc1[4];
-#pragma unroll
-        for (int step = 0; step < 8; ++step) {
-          const int jj = step >> 1, qp = 2 * (step & 1), cur = step & 1, nxt = cur ^ 1;
-          const int ns = step + 1, njj = (ns & 7) >> 1, nt = 4 * (g4 + (ns >> 3)) + 2 * (ns & 1);   // the next step's tap quarter / first tile
-          if (nt < 12) {
-            av[nxt][0] = pl[njj][64 * WPW * nt];
-            av[nxt][1] = pl[njj][64 * WPW * (nt + 1)];
-          } else if (part == 0) {   // behind the last group: the single tile 96 + wave of the older waves
-            av[nxt][0] = pl[0][64 * WPW * 12];
-            av[nxt][1] = pl[1][64 * WPW * 12];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          acc1[qp] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[jj], av[cur][0], jj ? acc1[qp] : b1v, 0, 0, 0);
-          acc1[qp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[jj], av[cur][1], jj ? acc1[qp + 1] : b1v, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        // (all sixteen MFMAs first: the epilogue then starts on the tile whose last MFMA is three MFMAs old)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-          *reinterpret_cast<f32x4*>(al + 128 * WPIXF * (4 * g4 + q4)) = prelu4<SLOPE01>(acc1[q4], sl1v);
-      }
-      if (part == 0) {   // tile 96 + wave (its first two fragments came with the last group's final step)
-        const float a2 = pl[2][64 * WPW * 12], a3 = pl[3][64 * WPW * 12];
-        f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[0], av[0][0], b1v, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[1], av[0][1], acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[2], a2, acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[3], a3, acc1, 0, 0, 0);
-        *reinterpret_cast<f32x4*>(al + 128 * WPIXF * 12) = prelu4<SLOPE01>(acc1, sl1v);
-      }
-    }
-    SVK_STAMP(ts2);
-    if (threadIdx.x == 0) q_item3 = p.queue ? (int)q_ticket + 3 * (int)gridDim.x : item2 + (int)gridDim.x;
-    __syncthreads();  // act1 is complete; the patch buffer is free
-    const int item3 = q_item3;
-    SVK_STAMP(ts3);
-
-    // ---- conv1_2, depth-transformed ----
-    {
-      const int u = cur.u, q = cur.q(), j = cur.j();
-      const int hl = i >> 1, wc = i & 1;
-      const float* const wbase = act + 2 * (160 * WPIXF) * pair + 68 * hl + 16 * wc + 4 * kk;
-      // (wave-uniform 64-bit bases + one 32-bit lane offset: the stores need no per-store address VALU)
-      float* const obase = p.out + (int64_t)u * S_N + (TD * q + 2 * pair) * S_D + j * S_W;
-      const int olane = kk * S_HP + i;
-      // (the SIMD's two waves do not share its issue slots evenly -- the older one, part 0, gets about two in three, and
-      // s_setprio changes nothing, measured -- but the younger one fills what the older leaves: the phase lasts the SUM
-      // of both waves' MFMA + VALU time whichever way the five tiles are split, so 3 + 2 it is)
-      // full tiles at rows 16 part, 16 part + 8 (tl = 2 part, 2 part + 1)
-      const int tl0 = 2 * part, tl1 = 2 * part + 2;
-#pragma unroll 1
-      for (int tl = tl0; tl < tl1; ++tl) {
-        // the next item's patch (LDS-DMA), by the older waves in front of their first tile (behind barrier 1: conv1_1 has
-        // read the patch buffer); one piece every other row tap instead of one burst: measured 2.7 % SLOWER
-        if (part == 0 && tl == tl0 && next < n_items) {
-          dma_patch_w(p, nx, starts, pair, lane, patch);
-          if (item2 < n_items) starts = fetch_starts(p, nx2, lane);
-        }
-        const int h0 = 8 * tl;
-        const float* pb[5];
-#pragma unroll
-        for (int sft = 0; sft < 5; ++sft) pb[sft] = wbase + 72 * h0 + 16 * ((hl + sft) >> 2);
-        f32x4 acc[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // (the tile's first tap is read HERE, its round trip in the open: reading it under the previous tile's last tap -- as the
-        // second block's kernels do -- measured 1.4 % SLOWER in this kernel, 7.34 -> 7.55 ms: 252 VGPRs and a branch in the tap loop)
-        f32x4 x[4];
-        f32x2 t[4][2];   // [k][element pair]
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(pb[0] + 160 * WPIXF * dd);
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) wino_input_pair(x, hf, t);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(pb[0] + 160 * WPIXF * dd + 32);
-        // Row tap kh: 16 MFMAs on t, then the NEXT tap's t in place (x = the next tap's fragments, read a tap earlier):
-        // eight packed adds in ONE burst per tap.  (f32 MFMA and f32 VALU share the SIMD's multipliers on this chip --
-        // neither the same wave nor the SIMD's other wave overlaps the two, measured -- so every add is paid for, and
-        // every switch from MFMAs to adds and back costs ~10 cycles on top: packed adds, few bursts.)
-#pragma unroll
-        for (int kh = 0; kh < 9; ++kh) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e >> 1][e & 1], G[9 * k + kh][e], acc[k], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (kh + 1 < 9) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) wino_input_pair(x, hf, t);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (kh + 2 < 9) {
-            const int off = 32 * (kh + 2) + 4 * ((kh + 2) >> 1);
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(pb[(kh + 2) >> 1] + 160 * WPIXF * dd + off);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        // rows 4 kk + r of the tile: output row h0 + 2 kk + (r >> 1), column r & 1: pool = max over r pairs
-        {
-          // (packed, written out: the compiler emits scalar subtractions for the differences)
-          f32x2 y0[2], y1[2];
-          const f32x2 b22 = (f32x2){b2, b2}, sl22 = (f32x2){sl2, sl2};
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            const f32x2 c0 = hf ? __builtin_shufflevector(acc[0], acc[0], 2, 3) : __builtin_shufflevector(acc[0], acc[0], 0, 1);
-            const f32x2 c1 = hf ? __builtin_shufflevector(acc[1], acc[1], 2, 3) : __builtin_shufflevector(acc[1], acc[1], 0, 1);
-            const f32x2 c2 = hf ? __builtin_shufflevector(acc[2], acc[2], 2, 3) : __builtin_shufflevector(acc[2], acc[2], 0, 1);
-            const f32x2 c3 = hf ? __builtin_shufflevector(acc[3], acc[3], 2, 3) : __builtin_shufflevector(acc[3], acc[3], 0, 1);
-            const f32x2 s0 = pk_add(pk_add(pk_add(c0, c1), c2), b22), s1 = pk_add(pk_sub(pk_sub(c1, c2), c3), b22);
-            y0[hf] = s0;
-            y1[hf] = s1;
-          }
-          float* const o00 = obase + (h0 / 2) * S_HP;
-          float* const o01 = o00 + S_PAR;
-          float* const o10 = o00 + S_D;
-          float* const o11 = o10 + S_PAR;
-          o00[olane] = prelu_max2<SLOPE01>(y0[0], sl22);
-          o01[olane] = prelu_max2<SLOPE01>(y0[1], sl22);
-          o10[olane] = prelu_max2<SLOPE01>(y1[0], sl22);
-          o11[olane] = prelu_max2<SLOPE01>(y1[1], sl22);
-        }
-      }
-    }
-    {
-      // this wave's (merged tile m = part, k = pair) unit
-      int lane_m = lane;
-      asm volatile("" : "+v"(lane_m));   // (as in the finish block below)
-      const int i_m = lane_m & 15;
-      const int hlm = (i_m >> 1) & 3, wcm = i_m & 1;
-      const float* const mbase = act + 2 * (160 * WPIXF) * (2 * part + (i_m >> 3)) + 68 * hlm + 16 * wcm + 4 * (lane_m >> 4) + 72 * 32;
-      const float* pbm[5];
-#pragma unroll
-      for (int sft = 0; sft < 5; ++sft) pbm[sft] = mbase + 16 * ((hlm + sft) >> 2);
-      f32x4 au;
-      if (pair == 0) au = stage1w_merged_unit<0>(pbm, G);
-      else if (pair == 1) au = stage1w_merged_unit<1>(pbm, G);
-      else if (pair == 2) au = stage1w_merged_unit<2>(pbm, G);
-      else au = stage1w_merged_unit<3>(pbm, G);
-      *reinterpret_cast<f32x4*>(exch + ((part * 4 + pair) * 64 + lane) * 4) = au;
-    }
-    SVK_STAMP(ts4);
-    SVK_STAMP(ts5);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed (as above)
-    __syncthreads();  // the next patch is in place; act1 may be overwritten
-    SVK_STAMP(ts6);
-    if (pair == 0) {
-      // waves 0 and 4 finish merged tile m = part: rows 4 kk + r = (pair 2 m + (kk >> 1), output row 32 + 2 (kk & 1) + (r >> 1),
-      // column r & 1); the exchange buffer is written again behind the next item's first barrier
-      const int u = cur.u, q = cur.q(), j = cur.j();
-      int lane_f = lane;
-      asm volatile("" : "+v"(lane_f));   // (keeps the address arithmetic below INSIDE the loop: hoisted, it costs registers this kernel spills)
-      const int i_f = lane_f & 15, kk_f = lane_f >> 4;
-      const float* xe = exch + (part * 4 * 64 + lane_f) * 4;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(xe), a1 = *reinterpret_cast<const f32x4*>(xe + 256),
-                  a2 = *reinterpret_cast<const f32x4*>(xe + 512), a3 = *reinterpret_cast<const f32x4*>(xe + 768);
-      const f32x4 y0 = a0 + a1 + a2 + b2, y1 = a1 - a2 - a3 + b2;
-      float* const o0 = p.out + (int64_t)u * S_N + (TD * q + 2 * (2 * part + (kk_f >> 1))) * S_D + j * S_W + (16 + (kk_f & 1)) * S_HP + i_f;
-      o0[0] = fmaxf(prelu_t<SLOPE01>(y0[0], sl2), prelu_t<SLOPE01>(y0[1], sl2));
-      o0[S_PAR] = fmaxf(prelu_t<SLOPE01>(y0[2], sl2), prelu_t<SLOPE01>(y0[3], sl2));
-      o0[S_D] = fmaxf(prelu_t<SLOPE01>(y1[0], sl2), prelu_t<SLOPE01>(y1[1], sl2));
-      o0[S_D + S_PAR] = fmaxf(prelu_t<SLOPE01>(y1[2], sl2), prelu_t<SLOPE01>(y1[3], sl2));
-    }
-    SVK_STAMP_ADD(0, ts0, ts1);
-    SVK_STAMP_ADD(1, ts1, ts2);
-    SVK_STAMP_ADD(2, ts2, ts3);
-    SVK_STAMP_ADD(3, ts3, ts4);
-    SVK_STAMP_ADD(4, ts4, ts5);
-    SVK_STAMP_ADD(5, ts5, ts6);
-    item = item1;
-    item1 = item2;
-    item2 = item3;
-    cur = nx;
-    nx = nx2;
-    nx2 = ItemPos::of(item3);
-  }
-#ifdef SVK_TUNING
-  if (p.stamps && lane == 0) {
-    for (int k = 0; k < 6; ++k) p.stamps[((size_t)blockIdx.x * 8 + wave) * 6 + k] = stamp_acc[k];
-    if (wave == 0) {
-      unsigned long long* clk = p.stamps + (size_t)gridDim.x * 8 * 6 + (size_t)blockIdx.x * 5;
-      const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-      clk[0] = __builtin_amdgcn_s_memtime() - clk_c0;
-      clk[1] = r1 - clk_r0;
-      clk[2] = clk_entry;   // absolute: when this workgroup entered the kernel, reached its loop, left it
-      clk[3] = clk_r0;
-      clk[4] = r1;
-    }
-  }
-#endif
 }
 
 
@@ -629,26 +275,10 @@ __global__ __launch_bounds__(512) void c3d2_stage1w_kernel(const Stage1Params p)
 // =====================================================================================================
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HACT_WORDS = 16 * DIN * NFRAME * 2;            // 25 600 32-bit words = 6 400 slots of 16 bytes
 constexpr int HPLANE = DIN * NFRAME;                         // slots per (quarter, row parity) plane: [10 dd][40 r / 2][2 col]
 constexpr int HPAIRS = 14;                                   // tap pairs of conv1_2 (27 taps + one empty)
-
-struct Stage1hParams {
-  const float* feat;
-  const int32_t* crop;
-  int32_t n_utt, max_frames;
-  const u32x4* w1blk;    // [2][64]: conv1_1's A blocks (8 halves per lane): [H taps 0-15 | H taps 0-15], [L taps 0-15 | 0]
-  const float* bias1;
-  const float* slope1;
-  const u32x4* w2blk;    // [14 pairs][2][64]: [H_a | H_b], [L_a | L_b]; lane (co = l & 15, kk): ci = 8 (kk & 1) + e, tap a (kk < 2) / b
-  const float* bias2;
-  const float* slope2;
-  float* out;
-  unsigned* queue;
-};
 
 // (h, l) of two f32 values as two packed-half words: {h0, h1}, {l0, l1}
 __device__ __forceinline__ void split2(f32x2 v, unsigned& h, unsigned& l) {
@@ -670,7 +300,7 @@ __device__ __forceinline__ float max_with_lane_xor1(float x) {
 }
 
 template <bool SLOPE01>
-__global__ __launch_bounds__(512) void c3d2_stage1h_kernel(const Stage1hParams p) {
+__global__ __launch_bounds__(512) void c3d2_stage1h_kernel(const Stage1Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem_c3d2[];
   unsigned* const act = reinterpret_cast<unsigned*>(smem_c3d2);   // [HACT_WORDS]
   float* const patch = smem_c3d2 + HACT_WORDS;                    // [WP_FLOATS]: [12 dd][80 h][8], f32 from the DMA, then (l << 16 | h) words
@@ -699,37 +329,42 @@ __global__ __launch_bounds__(512) void c3d2_stage1h_kernel(const Stage1hParams p
   __shared__ int q_item3;
   int item = blockIdx.x, item1 = item + (int)gridDim.x, item2 = item1 + (int)gridDim.x;
   ItemPos cur = ItemPos::of(item), nx = ItemPos::of(item1), nx2 = ItemPos::of(item2);
-  Stage1Params pf;   // (what the patch fetch reads of the parameters)
-  pf.feat = p.feat;
-  pf.crop = p.crop;
-  pf.n_utt = p.n_utt;
-  pf.max_frames = p.max_frames;
-  if (item < n_items) {
-    starts = fetch_starts(pf, cur, lane);
-    if (part == 0) dma_patch_w(pf, cur, starts, pair, lane, patch);
-    if (item1 < n_items) starts = fetch_starts(pf, nx, lane);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  while (item < n_items) {
-    const int next = item1;
-    unsigned q_ticket = 0;
-    if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
-
-    // ---- (0) the patch in place: f32 -> (l << 16 | h) words, 7 680 of them, 16 bytes per thread and trip ----
-    for (int w = 4 * (int)threadIdx.x; w < WP_FLOATS; w += 4 * 512) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(patch + w);
+  // The patch in place, f32 -> (l << 16 | h) words: by the wave that FETCHED the words (its own vmcnt(0) is all it needs: no
+  // barrier of its own), depths pair, pair + 4, pair + 8 = 3 x 640 words = nine 16-byte trips per lane, all nine reads in flight
+  // before the first conversion.  (As a pass of all eight waves in front of conv1_1, behind a barrier: 0.45 of 4.11 ms.)
+  auto convert_own = [&]() {
+    f32x4 v[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int w = (pair + 4 * (k / 3)) * (NFRAME * WPW) + 256 * (k % 3) + 4 * lane;
+      if (k % 3 < 2 || lane < 32) v[k] = *reinterpret_cast<const f32x4*>(patch + w);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int w = (pair + 4 * (k / 3)) * (NFRAME * WPW) + 256 * (k % 3) + 4 * lane;
       unsigned h0, l0, h1, l1;
-      split2(__builtin_shufflevector(v, v, 0, 1), h0, l0);
-      split2(__builtin_shufflevector(v, v, 2, 3), h1, l1);
+      split2(__builtin_shufflevector(v[k], v[k], 0, 1), h0, l0);
+      split2(__builtin_shufflevector(v[k], v[k], 2, 3), h1, l1);
       u32x4 o;   // word = the value's own pair: low half h, high half l
       o[0] = __builtin_amdgcn_perm(l0, h0, 0x05040100u);
       o[1] = __builtin_amdgcn_perm(l0, h0, 0x07060302u);
       o[2] = __builtin_amdgcn_perm(l1, h1, 0x05040100u);
       o[3] = __builtin_amdgcn_perm(l1, h1, 0x07060302u);
-      *reinterpret_cast<u32x4*>(patch + w) = o;
+      if (k % 3 < 2 || lane < 32) *reinterpret_cast<u32x4*>(patch + w) = o;
     }
-    __syncthreads();
+  };
+  if (item < n_items) {
+    starts = fetch_starts(p, cur, lane);
+    if (part == 0) dma_patch_w(p, cur, starts, pair, lane, patch);
+    if (item1 < n_items) starts = fetch_starts(p, nx, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (part == 0 && item < n_items) convert_own();
+  __syncthreads();
+  while (item < n_items) {
+    const int next = item1;
+    unsigned q_ticket = 0;
+    if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
 
     // ---- (1) conv1_1 + PReLU -> act1 as (h, l): 100 tiles of 16 pixels, tile tt = wave + 8 m ----
     {
@@ -788,13 +423,15 @@ __global__ __launch_bounds__(512) void c3d2_stage1h_kernel(const Stage1hParams p
     // ---- (2) conv1_2 + PReLU + pool: 36 tiles of 16 positions, position P = 16 t + i -> (depth P / 72, row, column) ----
     {
       if (part == 0 && next < n_items) {
-        dma_patch_w(pf, nx, starts, pair, lane, patch);
-        if (item2 < n_items) starts = fetch_starts(pf, nx2, lane);
+        dma_patch_w(p, nx, starts, pair, lane, patch);
+        if (item2 < n_items) starts = fetch_starts(p, nx2, lane);
       }
       const int u = cur.u, q = cur.q(), j = cur.j();
       float* const obase = p.out + (int64_t)u * S_N + (TD * q) * S_D + j * S_W + 4 * kk;
+      // tiles t = wave + 8 m (m < 4); the last four go to the YOUNGER waves (the older ones fetch and convert the next patch)
 #pragma unroll 1
-      for (int t = wave; t < 36; t += 8) {
+      for (int m = 0; m < 4 + part; ++m) {
+        const int t = m < 4 ? wave + 8 * m : 28 + wave;
         const int P = 16 * t + i;
         const int dq = (P * 911) >> 16, rem = P - 72 * dq, row = rem >> 1;          // P / 72 for P < 576
         // pixel (dd = dq + kd, r = 2 row + kh, col), channels 8 (kk & 1) .. + 7: slot (((kk & 1) * 2 + (kh & 1)) * 10 + dd) * 80 +
@@ -809,21 +446,23 @@ __global__ __launch_bounds__(512) void c3d2_stage1h_kernel(const Stage1hParams p
           const char* ad = pr < 12 ? a2 + 1280 * (pr / 4) + 32 * (pr % 4) : pr == 12 ? a3 + 32 * 4 : a3 + 2 * 1280 + 32 * 4 - (kk >= 2 ? 16 * 80 : 0);
           return *reinterpret_cast<const u32x4*>(ad + 16 * 4 * HPLANE * piece);
         };
-        u32x4 bh = rd(0, 0), bl = rd(0, 1);
+        // fragments TWO pairs ahead (three rotating sets): a pair is 48 cycles of MFMA, less than an LDS round trip
+        u32x4 bh[3], bl[3];
+        bh[0] = rd(0, 0);
+        bl[0] = rd(0, 1);
+        bh[1] = rd(1, 0);
+        bl[1] = rd(1, 1);
 #pragma unroll
         for (int pr = 0; pr < HPAIRS; ++pr) {
-          u32x4 nh = bh, nl = bl;
-          if (pr + 1 < HPAIRS) {
-            nh = rd(pr + 1, 0);
-            nl = rd(pr + 1, 1);
+          if (pr + 2 < HPAIRS) {
+            bh[(pr + 2) % 3] = rd(pr + 2, 0);
+            bl[(pr + 2) % 3] = rd(pr + 2, 1);
           }
           __builtin_amdgcn_sched_barrier(0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][0]), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][0]), __builtin_bit_cast(f16x8, bl), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][1]), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][0]), __builtin_bit_cast(f16x8, bh[pr % 3]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][0]), __builtin_bit_cast(f16x8, bl[pr % 3]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][1]), __builtin_bit_cast(f16x8, bh[pr % 3]), acc, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          bh = nh;
-          bl = nl;
         }
         // PReLU, max over the column pair (lanes i, i ^ 1: the same depth and row), the even lane stores its four channels
         const f32x4 y = prelu4<SLOPE01>(acc, sl2v);
@@ -834,7 +473,8 @@ __global__ __launch_bounds__(512) void c3d2_stage1h_kernel(const Stage1hParams p
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
-    __syncthreads();  // the next patch is in place; act1 may be overwritten
+    if (part == 0 && next < n_items) convert_own();
+    __syncthreads();  // the next patch is in place and converted; act1 may be overwritten
     item = item1;
     item1 = item2;
     item2 = item3;
@@ -848,9 +488,9 @@ __global__ __launch_bounds__(512) void c3d2_stage1h_kernel(const Stage1hParams p
 
 extern "C" {
 
-size_t svk_c3d2_stage1_lds_bytes(void) { return sizeof(float) * (size_t)(WACT_FLOATS + WP_FLOATS + 2048); }
+size_t svk_c3d2_stage1_lds_bytes(void) { return sizeof(float) * (size_t)(HACT_WORDS + WP_FLOATS); }
 
-int svk_c3d2_stage1h(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
+int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
                      const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const void* d_w1blk,
                      const float* d_bias1, const float* d_slope1, const void* d_w2blk, const float* d_bias2,
                      const float* d_slope2, int32_t flags, float* d_out) {
@@ -860,7 +500,7 @@ int svk_c3d2_stage1h(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t m
   SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 1, "shape");
   if (n_cols != NCOEF || n_crops != NCROP || crop_frames != NFRAME)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED,
-                    "svk_c3d2_stage1h is built for the 20 x 80 x 40 cube of utils.py:20-21 (got %d x %d x %d)", n_crops,
+                    "svk_c3d2_stage1 is built for the 20 x 80 x 40 cube of utils.py:20-21 (got %d x %d x %d)", n_crops,
                     crop_frames, n_cols);
   if (n_utt == 0) return SVK_OK;
   SVK_REQUIRE(ctx, d_feat && d_crop_idx && d_w1blk && d_bias1 && d_slope1 && d_w2blk && d_bias2 && d_slope2 && d_out,
@@ -869,7 +509,7 @@ int svk_c3d2_stage1h(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t m
                                                                     reinterpret_cast<uintptr_t>(d_out)) & 15) == 0,
               "d_feat must be 8-byte, the weight blocks and d_out 16-byte aligned");
   SVK_REQUIRE(ctx, (int64_t)n_utt * 36 + 4 * (int64_t)ctx->num_cu < ((int64_t)1 << 31), "too many cubes for one launch");
-  Stage1hParams p;
+  Stage1Params p;
   p.feat = d_feat;
   p.crop = d_crop_idx;
   p.n_utt = n_utt;
@@ -881,10 +521,10 @@ int svk_c3d2_stage1h(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t m
   p.bias2 = d_bias2;
   p.slope2 = d_slope2;
   p.out = d_out;
-  const size_t lds = sizeof(float) * (size_t)(HACT_WORDS + WP_FLOATS);
+  const size_t lds = svk_c3d2_stage1_lds_bytes();
   if (lds + 64 > (size_t)ctx->lds_per_cu)
-    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage1h needs %zu bytes of LDS per workgroup (device: %d)", lds, ctx->lds_per_cu);
-  void (*kern)(const Stage1hParams) = slope01 ? c3d2_stage1h_kernel<true> : c3d2_stage1h_kernel<false>;
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage1 needs %zu bytes of LDS per workgroup (device: %d)", lds, ctx->lds_per_cu);
+  void (*kern)(const Stage1Params) = slope01 ? c3d2_stage1h_kernel<true> : c3d2_stage1h_kernel<false>;
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t items = (int64_t)n_utt * 36;
   const unsigned grid = (unsigned)std::min<int64_t>(items, ctx->num_cu);
@@ -892,125 +532,6 @@ int svk_c3d2_stage1h(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t m
   if (p.queue) SVK_HIP(ctx, hipMemsetAsync(p.queue, 0, 4, ctx->stream));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
-  return SVK_OK;
-}
-
-int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t max_frames, int32_t n_cols,
-                    const int32_t* d_crop_idx, int32_t n_crops, int32_t crop_frames, const float* d_w1frag,
-                    const float* d_bias1, const float* d_slope1, const float* d_w2frag, const float* d_bias2,
-                    const float* d_slope2, int32_t flags, float* d_out) {
-  if (!ctx) return SVK_ERR_BAD_ARG;
-  // (the slopes live on the device: whether all 32 lie in [0, 1] -- the two-instruction PReLU -- is the caller's
-  // knowledge, passed in bit 1 of `flags`)
-  const bool slope01 = (flags & 2) != 0;
-  SVK_REQUIRE(ctx, (flags & ~2) == 0, "flags: only bit 1 (slopes in [0, 1]) is defined");
-  SVK_REQUIRE(ctx, n_utt >= 0 && max_frames >= 1, "shape");
-  if (n_cols != NCOEF || n_crops != NCROP || crop_frames != NFRAME)
-    return svk_fail(ctx, SVK_ERR_UNSUPPORTED,
-                    "svk_c3d2_stage1 is built for the 20 x 80 x 40 cube of utils.py:20-21 (got %d x %d x %d)", n_crops,
-                    crop_frames, n_cols);
-  if (n_utt == 0) return SVK_OK;
-  SVK_REQUIRE(ctx, d_feat && d_crop_idx && d_w1frag && d_bias1 && d_slope1 && d_w2frag && d_bias2 && d_slope2 && d_out,
-              "NULL buffer");
-  SVK_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_feat) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_w2frag) & 15) == 0,
-              "d_feat must be 8-byte and d_w2frag 16-byte aligned");
-  SVK_REQUIRE(ctx, (int64_t)n_utt * 36 < ((int64_t)1 << 31), "too many cubes for one launch");
-  Stage1Params p;
-  p.feat = d_feat;
-  p.crop = d_crop_idx;
-  p.n_utt = n_utt;
-  p.max_frames = max_frames;
-  p.w1frag = d_w1frag;
-  p.bias1 = d_bias1;
-  p.slope1 = d_slope1;
-  p.w2frag = reinterpret_cast<const f32x4*>(d_w2frag);
-  p.bias2 = d_bias2;
-  p.slope2 = d_slope2;
-  p.out = d_out;
-  const size_t lds = svk_c3d2_stage1_lds_bytes();
-  if (lds > (size_t)ctx->lds_per_cu)
-    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage1 needs %zu bytes of LDS per workgroup (device: %d)", lds,
-                    ctx->lds_per_cu);
-  void (*kern)(const Stage1Params) = slope01 ? c3d2_stage1w_kernel<true> : c3d2_stage1w_kernel<false>;
-  const int n_waves = 8;
-  SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int64_t items = (int64_t)n_utt * 36;
-  const unsigned grid = (unsigned)std::min<int64_t>(items, ctx->num_cu);  // one persistent workgroup per CU
-  // (the work-item counter: a slot of the handle's 256-byte scratch, zeroed in stream order; SVK_C3D2_STATIC_ITEMS: a fixed stride)
-  p.queue = getenv("SVK_C3D2_STATIC_ITEMS") ? nullptr : reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 112);
-  if (p.queue) SVK_HIP(ctx, hipMemsetAsync(p.queue, 0, 4, ctx->stream));
-  p.stamps = nullptr;
-#ifdef SVK_TUNING
-  const bool want_stamps = getenv("SVK_C3D2_STAMPS") != nullptr;
-  const size_t stamp_bytes = ((size_t)grid * n_waves * 6 + (size_t)grid * 5) * sizeof(unsigned long long);
-  if (want_stamps) {
-    const int rc = svk_ensure_work(ctx, stamp_bytes);
-    if (rc != SVK_OK) return rc;
-    p.stamps = reinterpret_cast<unsigned long long*>(ctx->work);
-    SVK_HIP(ctx, hipMemsetAsync(p.stamps, 0, stamp_bytes, ctx->stream));
-  }
-#endif
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * n_waves), lds, ctx->stream, p);
-  SVK_LAUNCH_CHECK(ctx);
-#ifdef SVK_TUNING
-  if (want_stamps) {  // phase cycles (s_memtime, 100 MHz-independent shader clock), averaged over workgroups, per wave
-    std::vector<unsigned long long> h((size_t)grid * n_waves * 6 + (size_t)grid * 5);
-    SVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    SVK_HIP(ctx, hipMemcpy(h.data(), p.stamps, stamp_bytes, hipMemcpyDeviceToHost));
-    const char* names[6] = {"issue next patch loads", "conv1_1 phase", "barrier 1", "conv1_2 phase + epilogue", "park", "barrier 2"};
-    const double per = (double)items / grid;
-    for (int w = 0; w < n_waves; ++w) {
-      fprintf(stderr, "stage1 stamps wave %d (cycles per item):", w);
-      for (int k = 0; k < 6; ++k) {
-        double sum = 0;
-        for (unsigned b = 0; b < grid; ++b) sum += (double)h[((size_t)b * n_waves + w) * 6 + k];
-        fprintf(stderr, "  %s %.0f", names[k], sum / grid / per);
-      }
-      fprintf(stderr, "\n");
-    }
-    {   // spread over workgroups of the loop's total cycles (wave 0)
-      std::vector<double> tot;
-      for (unsigned b = 0; b < grid; ++b) {
-        double t = 0;
-        for (int k = 0; k < 6; ++k) t += (double)h[((size_t)b * n_waves) * 6 + k];
-        tot.push_back(t);
-      }
-      std::sort(tot.begin(), tot.end());
-      fprintf(stderr, "stage1 loop cycles per workgroup: min %.0f  median %.0f  p90 %.0f  max %.0f\n", tot.front(), tot[tot.size() / 2],
-              tot[tot.size() * 9 / 10], tot.back());
-    }
-    {   // in-kernel clock: median over workgroups of shader cycles per 100 MHz reference tick
-      std::vector<double> mhz;
-      for (unsigned b = 0; b < grid; ++b) {
-        const unsigned long long c = h[(size_t)grid * n_waves * 6 + 5 * b], r = h[(size_t)grid * n_waves * 6 + 5 * b + 1];
-        if (r) mhz.push_back(100.0 * (double)c / (double)r);
-      }
-      {   // the launch on the chip-wide 100 MHz counter: when workgroups enter, reach their loop, leave it (microseconds from the first entry)
-        std::vector<double> ent, beg, end;
-        for (unsigned b = 0; b < grid; ++b) {
-          const unsigned long long* c = &h[(size_t)grid * n_waves * 6 + 5 * b];
-          ent.push_back((double)c[2]);
-          beg.push_back((double)c[3]);
-          end.push_back((double)c[4]);
-        }
-        const double t0 = *std::min_element(ent.begin(), ent.end());
-        auto us = [&](std::vector<double>& v, const char* what) {
-          std::sort(v.begin(), v.end());
-          fprintf(stderr, "stage1 %s: first %.1f  median %.1f  last %.1f us after the first workgroup's entry\n", what, (v.front() - t0) / 100.0,
-                  (v[v.size() / 2] - t0) / 100.0, (v.back() - t0) / 100.0);
-        };
-        us(ent, "kernel entry");
-        us(beg, "loop start");
-        us(end, "loop end");
-      }
-      if (!mhz.empty()) {
-        std::sort(mhz.begin(), mhz.end());
-        fprintf(stderr, "stage1 in-kernel clock: median %.0f MHz (min %.0f, max %.0f) over %zu workgroups; the 157.3 TFLOP/s peak assumes 2400\n",
-                mhz[mhz.size() / 2], mhz.front(), mhz.back(), mhz.size());
-      }
-    }
-  }
-#endif
   return SVK_OK;
 }
 

@@ -454,35 +454,22 @@ class Engine:
 
     def c3d2_stage1(self, feat, crop_idx, tables, crop_frames=80):
         """svk_c3d2_stage1: feature rows + crop starts -> the activation after C3D2's first block (conv1_1, conv1_2,
-        pool1 with their BN + PReLU): [n, 16, 36, 18, 16] f32, channels last.  conv1_2 runs through Winograd's F(2, 3)
-        along depth (2 / 3 of the multiply-adds; the same sums in another association, ~1e-6 relative from the direct form)."""
+        pool1 with their BN + PReLU): [n, 16, 36, 18, 16] f32, channels last.  Two-piece f16 products on
+        v_mfma_f32_16x16x32_f16 (x = h + l, three piece products per f32 product, f32 accumulation: ~1e-6 of the scale from the
+        f32 form); tables: `FusedEmbedder.stage1_tables()`."""
         torch = _torch()
         feat = self.to_device(feat, torch.float32)
         idx = self.to_device(crop_idx, torch.int32)
         n, T, Cc = feat.shape
         w1frag, bias1, slope1, w2frag, bias2, slope2 = tables[:6]
+        if w1frag.dtype != torch.float16 or w2frag.dtype != torch.float16 or tuple(w1frag.shape) != (2, 64, 8) or tuple(w2frag.shape) != (14, 2, 64, 8):
+            raise ValueError("c3d2_stage1 wants the half-pair weight blocks of FusedEmbedder.stage1_tables()")
         slope01 = bool(tables[6]) if len(tables) > 6 else False          # every slope in [0, 1]: the two-instruction PReLU
         out = torch.empty((n, 16, 36, 18, 16), dtype=torch.float32, device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_stage1(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), idx.shape[1], crop_frames,
                                        self._ptr(w1frag), self._ptr(bias1), self._ptr(slope1), self._ptr(w2frag), self._ptr(bias2),
                                        self._ptr(slope2), 2 if slope01 else 0, self._ptr(out)), self.ctx)
-        return out
-
-    def c3d2_stage1h(self, feat, crop_idx, tables, crop_frames=80):
-        """svk_c3d2_stage1h: the same block, boundary and output as `c3d2_stage1` through two-piece f16 products on
-        v_mfma_f32_16x16x32_f16 (tables: `FusedEmbedder.stage1h_tables()`)."""
-        torch = _torch()
-        feat = self.to_device(feat, torch.float32)
-        idx = self.to_device(crop_idx, torch.int32)
-        n, T, Cc = feat.shape
-        w1blk, bias1, slope1, w2blk, bias2, slope2 = tables[:6]
-        slope01 = bool(tables[6]) if len(tables) > 6 else False
-        out = torch.empty((n, 16, 36, 18, 16), dtype=torch.float32, device=self.device)
-        self._stream()
-        check(self.lib.svk_c3d2_stage1h(self.ctx, self._ptr(feat), n, T, Cc, self._ptr(idx), idx.shape[1], crop_frames,
-                                        self._ptr(w1blk), self._ptr(bias1), self._ptr(slope1), self._ptr(w2blk), self._ptr(bias2),
-                                        self._ptr(slope2), 2 if slope01 else 0, self._ptr(out)), self.ctx)
         return out
 
     def c3d2_stage2(self, act1, tables):

@@ -200,11 +200,12 @@ class FusedEmbedder:
 
     # ---- the first block (conv1_1 .. pool1) as one libsvk kernel ------------------------------------
     def stage1_tables(self):
-        """Operand fragments of `svk_c3d2_stage1` (csrc/c3d2.hip) from the BN-folded weights of conv1_1 / conv1_2,
-        or None when the first block is not C3D2's (1 -> 16 k(3,1,5); 16 -> 16 k(3,9,1) stride (1,2,1); pool).
-          w1frag [4][64]   : lane (channel = l & 15, kq = l >> 4), GEMM row k = 4 jj + kq: tap (k // 5, k % 5) of
-                             conv1_1, row 15 = 0 (padding); its bias goes separately
-          w2frag [27][64][4]: lane (co = l & 15, kk = l >> 4), element e = W2[co][4 kk + e][kd][kh], tap = 9 kd + kh"""
+        """Operand blocks of `svk_c3d2_stage1` (two-piece f16 products; include/svk.h): the BN-folded weights of conv1_1 /
+        conv1_2 split into halves H = f16(w), L = f16(w - H) and laid out in the lane order of v_mfma_f32_16x16x32_f16's A
+        operand (lane l = (co = l & 15, kk = l >> 4), eight halves: K = 8 kk + e), or None when the first block is not C3D2's
+        (1 -> 16 k(3,1,5); 16 -> 16 k(3,9,1) stride (1,2,1); pool).
+          w1blk [2][64][8]      : conv1_1, tap t = 8 (kk & 1) + e (t = 5 kd + kw; 15 -> 0): H for every kk | L for kk < 2, 0 above
+          w2blk [14][2][64][8]  : conv1_2, tap pairs (a | b): ci = 8 (kk & 1) + e at tap a (kk < 2) / b (kk >= 2); H | L"""
         hit = getattr(self, "_stage1", False)
         if hit is not False:
             return hit
@@ -213,41 +214,6 @@ class FusedEmbedder:
         if (tuple(w1.shape) != (16, 1, 3, 1, 5) or tuple(w2.shape) != (16, 16, 3, 9, 1) or tuple(st1) != (1, 1, 1)
                 or tuple(st2) != (1, 2, 1) or p1 or not p2):
             return None
-        dev = w1.device
-        lane = torch.arange(64, device=dev)
-        ch, kq = lane & 15, lane >> 4
-        w1frag = torch.empty((4, 64), dtype=torch.float32, device=dev)
-        w1c = w1.contiguous().view(16, 15)                                  # [co][kd * 5 + kw]
-        for jj in range(4):
-            k = 4 * jj + kq
-            w1frag[jj] = torch.where(k < 15, w1c[ch, k.clamp(max=14)], torch.zeros_like(b1[ch]))
-        w2c = w2.contiguous()[:, :, :, :, 0]                                # [co][ci][kd][kh]
-        w2frag = torch.empty((27, 64, 4), dtype=torch.float32, device=dev)
-        for kd in range(3):
-            for kh in range(9):
-                for e in range(4):
-                    w2frag[9 * kd + kh, :, e] = w2c[ch, 4 * kq + e, kd, kh]
-        slope01 = bool(((s1 >= 0) & (s1 <= 1)).all() and ((s2 >= 0) & (s2 <= 1)).all())   # one host read per checkpoint
-        self._stage1 = (w1frag.contiguous(), b1.contiguous(),
-                        s1.expand(16).contiguous() if s1.numel() == 1 else s1.contiguous(),
-                        w2frag.contiguous(), b2.contiguous(),
-                        s2.expand(16).contiguous() if s2.numel() == 1 else s2.contiguous(), slope01)
-        return self._stage1
-
-    def stage1h_tables(self):
-        """Operand blocks of `svk_c3d2_stage1h` (two-piece f16 products; include/svk.h): the BN-folded weights of conv1_1 /
-        conv1_2 split into halves H = f16(w), L = f16(w - H) and laid out in the lane order of v_mfma_f32_16x16x32_f16's A
-        operand (lane l = (co = l & 15, kk = l >> 4), eight halves: K = 8 kk + e), or None when the block is not C3D2's.
-          w1blk [2][64][8]      : conv1_1, tap t = 8 (kk & 1) + e (t = 5 kd + kw; 15 -> 0): H for every kk | L for kk < 2, 0 above
-          w2blk [14][2][64][8]  : conv1_2, tap pairs (a | b): ci = 8 (kk & 1) + e at tap a (kk < 2) / b (kk >= 2); H | L"""
-        hit = getattr(self, "_stage1h", False)
-        if hit is not False:
-            return hit
-        self._stage1h = None
-        base = self.stage1_tables()
-        if base is None:
-            return None
-        (w1, b1, s1, _, _, _), (w2, b2, s2, _, _, _) = self.stages[0], self.stages[1]
         dev = w1.device
 
         def halves(w):
@@ -270,8 +236,12 @@ class FusedEmbedder:
             wb = w2c[co[:, None], ci, tb[0], tb[1]] if tb is not None else torch.zeros_like(wa)
             h, l = halves(torch.where((kk < 2)[:, None], wa, wb))
             w2blk[p, 0], w2blk[p, 1] = h, l
-        self._stage1h = (w1blk.contiguous(), base[1], base[2], w2blk.contiguous(), base[4], base[5], base[6])
-        return self._stage1h
+        slope01 = bool(((s1 >= 0) & (s1 <= 1)).all() and ((s2 >= 0) & (s2 <= 1)).all())   # one host read per checkpoint
+        self._stage1 = (w1blk.contiguous(), b1.contiguous(),
+                        s1.expand(16).contiguous() if s1.numel() == 1 else s1.contiguous(),
+                        w2blk.contiguous(), b2.contiguous(),
+                        s2.expand(16).contiguous() if s2.numel() == 1 else s2.contiguous(), slope01)
+        return self._stage1
 
     def stage2_tables(self):
         """Operand fragments of `svk_c3d2_stage2` (conv2_1 16 -> 32 k(3,1,4); conv2_2 32 -> 32 k(3,8,1) stride

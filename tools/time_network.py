@@ -35,10 +35,9 @@ feat = rnd(n, T, 40) * 2 - 6
 crops = torch.randint(0, T - 80, (n, 20), device=eng.device, dtype=torch.int32, generator=g)
 # name: (call, MFMA wave-instructions per cube by construction, direct-form multiply-adds per cube)
 kernels = {
-    "stage1": (lambda: eng.c3d2_stage1(feat, crops, emb.stage1_tables()), 36 * (400 + 18 * 144), 155.768832e6),
-    # the first block through two-piece f16 products (42 MFMAs of v_mfma_f32_16x16x32_f16 per 16 positions + 2 per conv1_1 tile,
-    # counted here in f32-MFMA units of 2 048 FLOP: 36 tiles x 42 x 4 + 100 x 2 x 4 per item)
-    "stage1h": (lambda: eng.c3d2_stage1h(feat, crops, emb.stage1h_tables()), 36 * (36 * 42 * 4 + 100 * 2 * 4), 155.768832e6),
+    # the first block runs two-piece f16 products: its MFMAs (v_mfma_f32_16x16x32_f16, 16 cycles) counted in units of the f32 MFMA's
+    # 32 cycles -- 36 items x (100 conv1_1 tiles x 2 + 36 conv1_2 tiles x 42) / 2 -- so that "issued" stays a share of issue TIME
+    "stage1": (lambda: eng.c3d2_stage1(feat, crops, emb.stage1_tables()), 36 * (100 * 2 + 36 * 42) / 2, 155.768832e6),
     "stage2": (lambda x=rnd(n, 16, 36, 18, 16): eng.c3d2_stage2(x, emb.stage2_tables()), 32256 + 43008, 112.80384e6),
     "conv3_1": (lambda x=rnd(n, 12, 15, 7, 32): eng.c3d2_conv31(x, emb.conv31_tables()), 9600, 13.824e6),
     "conv3_2": (lambda x=rnd(n, 10, 8, 5, 15, 8): eng.c3d2_conv32t(x, emb.conv32t_tables()), 20160, 30.96576e6),
@@ -65,17 +64,12 @@ def med(fn, reps=20, warm=5):
 
 total = 0.0
 for name, (fn, mfma, mmac) in kernels.items():
-    if args and name not in args or (not args and name == "stage1h"):
+    if args and name not in args:
         continue
     out = fn()
-    if name == "stage1h":       # against the f32 kernel on the same inputs
-        ref = kernels["stage1"][0]()
-        print("stage1h vs stage1: max |d| %.3e of scale %.3e (%.2e relative), rms %.2e" % (
-            float((out - ref).abs().max()), float(ref.abs().max()), float((out - ref).abs().max() / ref.abs().max()),
-            float((out - ref).double().pow(2).mean().sqrt() / ref.abs().max())))
     check = float(out.double().abs().sum())
     ms = med(fn)
     total += ms
-    print("%-8s %8.3f ms per %d cubes   issued %.3f of the f32 pipe (157.3 TFLOP/s)   direct-form %.3f   checksum %.9e"
+    print("%-8s %8.3f ms per %d cubes   issued %.3f of its matrix pipe's time   direct-form %.3f   checksum %.9e"
           % (name, ms, n, n * mfma * 2048 / ms / 1e9 / 157.3, 2 * mmac * n / ms / 1e9 / 157.3, check))
 print("total %.3f ms per %d cubes = %.0f cubes/s" % (total, n, n / total * 1e3))
