@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 109 /* 0.1.8: svk_c3d2_stage1 runs on the f16 matrix pipe through two-piece products (new weight tables d_w1blk / d_w2blk); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
+#define SVK_VERSION 109 /* 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -272,17 +272,18 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
                     const float* d_slope2, int32_t flags, float* d_out);
 
 /* The second block, model.py:119-124 + :151-158: conv2_1 (16 -> 32, kernel (3,1,4)) -> BN -> PReLU -> conv2_2
- * (32 -> 32, kernel (3,8,1), stride (1,2,1)) -> BN -> PReLU -> MaxPool3d((1,1,2)), two f32-MFMA kernels with the
- * input region of a work item in LDS and the weights in registers, both through Winograd's F(2, 3) along depth (the
- * transformed weights derived in the kernels from the direct-form fragments below); epilogues carry bias, PReLU and the pool.
+ * (32 -> 32, kernel (3,8,1), stride (1,2,1)) -> BN -> PReLU -> MaxPool3d((1,1,2)), two kernels on v_mfma_f32_16x16x32_f16
+ * through two-piece products like svk_c3d2_stage1 (direct form; the input region of a work item is split into (h, l) halves
+ * while it is staged into LDS, the weights of all taps sit in registers); epilogues carry bias, PReLU and the pool.
  *   d_in     [n_utt][16][36][18][16]  = svk_c3d2_stage1's output
- *   d_w21frag [2 nt][12 taps][64][4]  : lane (co = 16 nt + (l & 15), kk = l >> 4), e: W21[co][4 kk + e][kd][kw], tap 4 kd + kw
- *   d_w22frag [2 nt][24 taps][2][64][4]: W22[co][16 chunk + 4 kk + e][kd][kh], tap 8 kd + kh;  biases / slopes [32]
- *   flags    bit 1: the caller asserts every PReLU slope lies in [0, 1]; every other bit must be 0
- *   d_act2   [n_utt][14][36][15][32]  scratch the caller provides (conv2_1's output)
- *   d_out    [n_utt][12][15][7][32]   the activation after pool2, channels last                                  */
-int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_w21frag, const float* d_bias21,
-                    const float* d_slope21, const float* d_w22frag, const float* d_bias22, const float* d_slope22,
+ *   d_w21blk [2 nt][6 pairs][2][64][8 halves]: conv2_1, lane l = (co = 16 nt + (l & 15), kk = l >> 4), element e =
+ *            W[co][ci = 8 (kk & 1) + e][kd][kw + (kk >= 2)] of the tap pair 2 kd + kw / 2 (kw = 0, 2); block 0 = H, 1 = L
+ *   d_w22blk [2 nt][24 taps][2][64][8 halves]: conv2_2, element e = W[co][ci = 8 kk + e][kd][kh], tap = 8 kd + kh; H | L
+ *   d_bias / d_slope [32] per layer (BN folded; PReLU slope per channel)
+ *   d_act2   [n_utt][14][36][15][32]  conv2_1's activation (scratch, f32);  d_out [n_utt][12][15][7][32] (channels last)
+ * flags as for svk_c3d2_stage1. */
+int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_w21blk, const float* d_bias21,
+                    const float* d_slope21, const void* d_w22blk, const float* d_bias22, const float* d_slope22,
                     int32_t flags, float* d_act2, float* d_out);
 
 /* conv3_1 (32 -> 64, kernel (3,1,3)) -> BN -> PReLU, model.py:126-128 + :159-161, one f32-MFMA kernel through Winograd's

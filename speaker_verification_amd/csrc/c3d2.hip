@@ -1,13 +1,13 @@
 // The C3D2 embedding network's first three blocks (model.py:110-131, :141-164).
 //   c3d2_stage1h_kernel   cube + conv1_1 + conv1_2 + pool1 on v_mfma_f32_16x16x32_f16 through two-piece f16 products (round 4)
-//   c3d2_conv21w_kernel   conv2_1, v_mfma_f32_16x16x4_f32, depth-transformed (Winograd F(2, 3) along depth)
-//   c3d2_conv22w_kernel   conv2_2 + pool2, depth-transformed
-//   c3d2_conv31w_kernel   conv3_1, depth-transformed; writes the chunked, column-major layout c3d2_tail_kernel<Conv32T> stages
+//   c3d2_conv21h_kernel   conv2_1, two-piece f16 products
+//   c3d2_conv22h_kernel   conv2_2 + pool2, two-piece f16 products
+//   c3d2_conv31w_kernel   conv3_1 on v_mfma_f32_16x16x4_f32, depth-transformed (Winograd F(2, 3) along depth); writes the chunked, column-major layout c3d2_tail_kernel<Conv32T> stages
 // (conv3_2, conv4_1, conv4_2 and FC5 live in c3d2_tail.hip.)  BatchNorm (eval mode) is folded into weights and biases by
 // the host (model.FusedEmbedder).  Work items come from device-wide counters.  What earlier rounds built and superseded is
 // under tools/experiments/ with its measured numbers: the direct-form f32 kernels, the t-plane first block, the K-split conv3_2
-// (c3d2_superseded_r3.patch) and the f32 first block through the depth transform, round 4's 7.12 ms kernel
-// (stage1_f32_winograd.patch).
+// (c3d2_superseded_r3.patch) and the f32 first and second blocks through the depth transform, round 4's 7.12 + 5.09 ms kernels
+// (stage1_f32_winograd.patch, stage2_f32_winograd.patch).
 //
 // The first block as ONE gfx950 kernel:
 //   feature rows + crop starts -> cube (utils.py:351-379) -> conv1_1 (1 -> 16, k(3,1,5)) + BN + PReLU
@@ -71,15 +71,6 @@ struct Stage1Params {
   float* out;
   unsigned* queue;
 };
-
-// In-kernel phase stamps (s_memtime) for `make TUNING=1` builds; compiled out of the shipped library.
-#ifdef SVK_TUNING
-#define SVK_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define SVK_STAMP_ADD(slot, a, b) do { stamp_acc[slot] += (b) - (a); } while (0)   /* wave-uniform: scalar registers */
-#else
-#define SVK_STAMP(var) do { } while (0)
-#define SVK_STAMP_ADD(slot, a, b) do { } while (0)
-#endif
 
 __device__ __forceinline__ float prelu(float v, float slope) { return v > 0.f ? v : slope * v; }
 // 0 <= slope <= 1 (nn.PReLU starts at 0.25 and trained slopes stay there): prelu(v) = max(v, slope v), two
@@ -551,48 +542,41 @@ constexpr int S2_D = 16, S2_H = 36, S2_W = 18;       // input of conv2_1 (after 
 constexpr int A2_D = 14, A2_W = 15;                  // conv2_1 output (32 channels), rows = S2_H
 constexpr int O2_D = 12, O2_H = 15, O2_W = 7;        // after conv2_2 + pool2 (32 channels)
 
-struct Conv21Params {
+// ---- conv2_1 through two-piece f16 products (see c3d2_stage1h_kernel): direct form, 12 taps = 6 pairs (kd, kw | kw + 1) of
+// K = 32 blocks, three MFMAs per pair and N tile (both N tiles of a wave share the B fragments).  Item = (cube, block of 4
+// rows) as before; its input [16 d][4 rows][18 w][16 c] is split into (h, l) while it is staged and lies in LDS as four planes
+// of 16-byte slots (h c0-7, h c8-15, l c0-7, l c8-15), slot = pixel (d * 4 + row) * 18 + col: the 16 positions of a tile --
+// ANY 16 consecutive outputs of the item's 14 d x 4 rows x 15 columns = 840 (52.5 tiles) -- read consecutive slots (+ 3 across a
+// row end).  36 MFMAs of 16 cycles per tile where the depth-transformed f32 kernel issued 128 of 32 per 16 positions of a pair. ----
+constexpr int C21H_PIX = S2_D * 4 * S2_W;            // 1 152 pixels = slots per plane
+constexpr int C21H_LDS_WORDS = 4 * 4 * C21H_PIX;     // four planes of 16-byte slots: 73 728 bytes
+constexpr int C21H_POS = A2_D * 4 * A2_W;            // 840 output positions per item
+
+struct Conv21hParams {
   const float* in;      // [n][16][36][18][16]
-  const f32x4* wfrag;   // [2 nt][12 taps][64]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: W[co][4 kk + e][kd][kw], tap = 4 kd + kw
+  const u32x4* wblk;    // [2 nt][6 pairs][2][64]: lane (co = 16 nt + (l & 15), kk): e: W[co][8 (kk & 1) + e][kd][kw + (kk >= 2)], pair = 2 kd + kw / 2; H | L
   const float* bias;    // [32]
   const float* slope;   // [32]
   float* out;           // [n][14][36][15][32]
   int32_t n_utt;
-  unsigned* queue;      // work-item counter (zeroed by the host before the launch), or NULL = static round-robin
+  unsigned* queue;
 };
 
-// ---- conv2_1 through Winograd's F(2, 3) along depth (see c3d2_stage1w_kernel): per output depth pair P and row, the
-// planes x0 .. x3 = depths 2 P .. 2 P + 3 give t0 .. t3, four accumulators per N tile, 128 MFMAs where the direct form
-// issues 192; a transformed fragment feeds 8 MFMAs (two N tiles), so the packed adds are 1 per 4 MFMAs.  Item = (cube,
-// block of 4 rows): 7 pairs x 4 rows = 28 M tiles, 7 per wave; 78 KB of LDS, two workgroups per CU; the transformed
-// weights (128 VGPRs) are derived from the direct fragments in the prologue. ----
-constexpr int C21W_TH = 4;
-constexpr int C21W_PIX = S2_D * C21W_TH * S2_W;      // 1152 pixels of 16 channels, stored at 16 p + 4 (p >> 2)
-constexpr int C21W_LDS_FLOATS = 17 * (C21W_PIX + 4);
-constexpr int C21W_DSTEP = 17 * C21W_TH * S2_W;      // floats per depth plane (72 pixels = 18 groups of 4)
-
 template <bool SLOPE01>
-__global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params p) {
+__global__ __launch_bounds__(256, 2) void c3d2_conv21h_kernel(const Conv21hParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem_c21w[];
-  float* reg = smem_c21w;
+  unsigned* const reg = reinterpret_cast<unsigned*>(smem_c21w);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
-  f32x4 G[2][4][4];   // [nt][k][kw]
+  u32x4 W[2][6][2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int kw = 0; kw < 4; ++kw) {
-      const f32x4 g0 = p.wfrag[(nt * 12 + kw) * 64 + lane], g1 = p.wfrag[(nt * 12 + 4 + kw) * 64 + lane],
-                  g2 = p.wfrag[(nt * 12 + 8 + kw) * 64 + lane];
-      G[nt][0][kw] = g0;
-      G[nt][1][kw] = 0.5f * ((g0 + g2) + g1);
-      G[nt][2][kw] = 0.5f * ((g0 + g2) - g1);
-      G[nt][3][kw] = g2;
+    for (int pr = 0; pr < 6; ++pr) {
+      W[nt][pr][0] = p.wblk[((nt * 6 + pr) * 2) * 64 + lane];
+      W[nt][pr][1] = p.wblk[((nt * 6 + pr) * 2 + 1) * 64 + lane];
     }
-  // M = channel (A = the weights G), N = output column w' (B = the transformed fragments): a lane ends up with channels
-  // 16 nt + 4 kk .. + 3 of column i -- 16 contiguous bytes of the channels-last output: one 16-byte store per (N tile, depth)
-  // where M = position issued four 4-byte stores (round 4; the same products in the same order: bit-identical)
-  f32x4 b4[2], sl4[2];
+  f32x4 b4[2], sl4[2];   // a lane holds channels 16 nt + 4 kk .. + 3 of ONE position
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -600,34 +584,26 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
       b4[nt][r] = p.bias[16 * nt + 4 * kk + r];
       sl4[nt][r] = p.slope[16 * nt + 4 * kk + r];
     }
-  constexpr int BLOCKS = S2_H / C21W_TH;   // 9 row blocks per cube
+  constexpr int BLOCKS = S2_H / 4;   // 9 row blocks per cube
   const int n_items = p.n_utt * BLOCKS;
-  // Work items come from a device-wide counter, not from a fixed stride: of the two workgroups that share a CU the older
-  // one gets about two MFMA issue slots in three, so with equal shares it finished 20 % early and its partner ran the
-  // tail alone, latency-exposed (in-kernel stamps: 1.43 M vs 1.76 M loop cycles).  The next index is requested at the
-  // top of an item (it returns during the staging) and published through LDS with the staging barrier.
-  __shared__ int q_next;
+  __shared__ int q_next;   // dynamic work items (two workgroups share a CU)
   int item = blockIdx.x;
   while (item < n_items) {
     unsigned q_ticket = 0;
     if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
-    const int u = item / BLOCKS, hb = (item - u * BLOCKS) * C21W_TH;
-    // stage [16 d][4 rows][18 w][16 c]: 18 16-byte pieces per thread, six in flight at a time
+    const int u = item / BLOCKS, hb = (item - u * BLOCKS) * 4;
+    // stage + split: piece e = t + 256 k of thread t = channels 4 (e & 3) .. + 3 of pixel (t >> 2) + 64 k (18 pieces per thread);
+    // its four h halves are bytes 8 (piece & 1) .. + 7 of slot `pixel` in plane (piece >> 1), its l halves the same two planes on
     const float* src = p.in + (int64_t)u * (S2_D * S2_H * S2_W * 16);
-    constexpr int NV = 6;
-    static_assert(C21W_PIX * 4 % (256 * NV) == 0, "whole rounds");
-    // piece e = t + 256 k of thread t: 16-byte piece e & 3 of pixel (t >> 2) + 64 k.  The LDS address is linear in k (64 k is a
-    // multiple of 4: 16 pix + 4 (pix >> 2) moves by 1 088 k floats); the source is (576 d + 18 hb + pix) * 16 with d = pix / 72,
-    // and for a compile-time k that is a constant plus ONE comparison of t >> 2 with the window's depth boundary: two vector
-    // instructions per piece where the division took a dozen (none of them overlaps an MFMA on this chip).
     {
       int tl = threadIdx.x;
-      asm volatile("" : "+v"(tl));   // (keeps this arithmetic inside the item loop: hoisted, it costs registers)
+      asm volatile("" : "+v"(tl));   // (keeps this arithmetic inside the item loop)
       const int piece = tl & 3, pix0 = tl >> 2;
-      float* const a0s = reg + 16 * pix0 + 4 * (pix0 >> 2) + 4 * piece;
+      unsigned* const a0s = reg + 4 * ((piece >> 1) * C21H_PIX + pix0) + 2 * (piece & 1);
       const float* const g0 = src + (int64_t)(hb * S2_W + pix0) * 16 + 4 * piece;
-      constexpr int PER_D = C21W_TH * S2_W;            // 72 staged pixels per depth, 648 in the tensor
+      constexpr int PER_D = 4 * S2_W;                    // 72 staged pixels per depth, 648 in the tensor
       constexpr int DSTEP = (S2_H * S2_W - PER_D) * 16;  // floats the source gains per depth on top of 16 pix
+      constexpr int NV = 9;
 #pragma unroll
       for (int r0 = 0; r0 < 18; r0 += NV) {
         f32x4 sv[NV];
@@ -639,80 +615,54 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
           sv[k - r0] = *reinterpret_cast<const f32x4*>(g);
         }
 #pragma unroll
-        for (int k = r0; k < r0 + NV; ++k) *reinterpret_cast<f32x4*>(a0s + 1088 * k) = sv[k - r0];
+        for (int k = r0; k < r0 + NV; ++k) {
+          unsigned h0, l0, h1, l1;
+          split2(__builtin_shufflevector(sv[k - r0], sv[k - r0], 0, 1), h0, l0);
+          split2(__builtin_shufflevector(sv[k - r0], sv[k - r0], 2, 3), h1, l1);
+          *reinterpret_cast<u32x2*>(a0s + 4 * 64 * k) = (u32x2){h0, h1};
+          *reinterpret_cast<u32x2*>(a0s + 4 * 64 * k + 4 * 2 * C21H_PIX) = (u32x2){l0, l1};
+        }
       }
     }
     if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + (int)gridDim.x : item + (int)gridDim.x;
     __syncthreads();
     const int item_next = q_next;
-    // M tiles = (pair P, row hl): 16 pixels w' = 0 .. 15 (15 is a dummy), tile = 4 P + hl = 4 P + wave: this wave's seven tiles
-    // differ in P alone, and pixel 144 P + r sits at 2 448 P + 16 r + 4 (r >> 2) -- the four tap addresses of a lane are those
-    // of its first tile plus 2 448 floats per tile (four adds per tile; recomputed from the tile index they were 22 vector
-    // instructions per 128 MFMAs, none of which an MFMA hides)
-    int ao[4];   // (offsets into `reg`, not pointers: a pointer carried round the loop loses its LDS address space -- flat loads)
-    {
-      int il = i;
-      asm volatile("" : "+v"(il));   // (inside the item loop: hoisted out of it, the four addresses cost registers all kernel long)
-#pragma unroll
-      for (int kw = 0; kw < 4; ++kw) {
-        const int r = S2_W * wave + il + kw;
-        ao[kw] = 16 * r + 4 * (r >> 2) + 4 * kk;
-      }
-    }
-    // the first tile's first tap; every later tile's is read under the previous tile's last 32 MFMAs
-    f32x4 x[4];
-#pragma unroll
-    for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(reg + ao[0] + C21W_DSTEP * dd);
+    // tiles t = wave + 4 m of 16 positions P = 16 t + i -> (depth P / 60, row (P % 60) / 15, column P % 15); 53 tiles, the last half full
 #pragma unroll 1
-    for (int P = 0; P < 7; ++P) {
-      // (a1 enters both outputs with a plus sign: the bias rides in its accumulator)
-      f32x4 acc[2][4];
+    for (int t = wave; t < (C21H_POS + 15) / 16; t += 4) {
+      const int P = min(16 * t + i, C21H_POS - 1);
+      const int dq = (P * 1093) >> 16, rem = P - 60 * dq;                       // P / 60 for P < 840
+      const int row = (rem * 4370) >> 16, col = rem - 15 * row;                 // rem / 15 for rem < 60
+      // input pixel (dq + kd, row, col + kw): slot (dq * 4 + row) * 18 + col + 72 kd + kw of plane (kk & 1) [l: + 2]; tap b = + 1 slot
+      const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * ((kk & 1) * C21H_PIX + (dq * 4 + row) * S2_W + col + (kk >= 2 ? 1 : 0));
+      auto rd = [&](int pr, int piece) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(a2 + 16 * (72 * (pr >> 1) + 2 * (pr & 1)) + 16 * 2 * C21H_PIX * piece);
+      };
+      f32x4 acc[2] = {b4[0], b4[1]};
+      u32x4 bh[3], bl[3];
+      bh[0] = rd(0, 0);
+      bl[0] = rd(0, 1);
+      bh[1] = rd(1, 0);
+      bl[1] = rd(1, 1);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[nt][k] = k == 1 ? b4[nt] : (f32x4){0.f, 0.f, 0.f, 0.f};
-      f32x2 t[4][2];
-#pragma unroll
-      for (int kw = 0; kw < 4; ++kw) {
-        // this tap's transformed fragments (8 packed adds, one burst), the next tap's reads, 32 MFMAs
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) wino_input_pair(x, hf, t);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kw + 1 < 4) {
-#pragma unroll
-          for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(reg + ao[kw + 1] + C21W_DSTEP * dd);
-        } else if (P + 1 < 7) {
-#pragma unroll
-          for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(reg + ao[0] + 2 * C21W_DSTEP + C21W_DSTEP * dd);
+      for (int pr = 0; pr < 6; ++pr) {
+        if (pr + 2 < 6) {
+          bh[(pr + 2) % 3] = rd(pr + 2, 0);
+          bl[(pr + 2) % 3] = rd(pr + 2, 1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              acc[nt][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[nt][k][kw][e], t[k][e >> 1][e & 1], acc[nt][k], 0, 0, 0);
+        for (int nt = 0; nt < 2; ++nt) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[nt][pr][0]), __builtin_bit_cast(f16x8, bh[pr % 3]), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[nt][pr][0]), __builtin_bit_cast(f16x8, bl[pr % 3]), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[nt][pr][1]), __builtin_bit_cast(f16x8, bh[pr % 3]), acc[nt], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int kw = 0; kw < 4; ++kw) ao[kw] += 2 * C21W_DSTEP;
-      // rows 4 kk + r = channel 16 nt + 4 kk + r; column i = output column w' (15 is the dummy); depths 2 P and 2 P + 1
-      // (wave-uniform 64-bit bases + one 32-bit lane offset + immediates: the stores need no per-store address VALU)
-      float* const o0 = p.out + (((int64_t)u * A2_D + 2 * P) * S2_H + hb + wave) * (A2_W * 32);
-      float* const o1 = o0 + (int64_t)S2_H * (A2_W * 32);
-      const int lo = i * 32 + 4 * kk;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        // y0 = (a0 + a1) + a2, y1 = (a1 - a2) - a3 as packed adds (every VALU instruction here is paid in MFMA slots)
-        f32x2 s0[2], s1[2];
-        wino_output(acc[nt], s0, s1);
-        f32x4 y0, y1;
-        prelu_pairs<SLOPE01>(s0, s1, sl4[nt], y0, y1);
-        if (i < A2_W) {
-          *reinterpret_cast<f32x4*>(o0 + lo + 16 * nt) = y0;
-          *reinterpret_cast<f32x4*>(o1 + lo + 16 * nt) = y1;
-        }
+      if (16 * t + i < C21H_POS) {
+        float* const o = p.out + ((((int64_t)u * A2_D + dq) * S2_H + hb + row) * A2_W + col) * 32 + 4 * kk;
+        *reinterpret_cast<f32x4*>(o) = prelu4<SLOPE01>(acc[0], sl4[0]);
+        *reinterpret_cast<f32x4*>(o + 16) = prelu4<SLOPE01>(acc[1], sl4[1]);
       }
     }
     __syncthreads();
@@ -720,85 +670,61 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21w_kernel(const Conv21Params
   }
 }
 
-struct Conv22Params {
+// ---- conv2_2 + pool2 through two-piece f16 products: direct form, K = 32 = the 32 input channels of ONE tap, three MFMAs per
+// tap (H x h, H x l, L x h), 24 taps.  Item = (cube, pooled column j, third q of the output depths) as before; its input
+// [6 d][36 h][2 w][32 c] is split while it is staged: eight planes (four channel quarters x {h, l}) of 16-byte slots, a plane
+// split by the parity of the row (rows are 2 apart along a tile): slot ((r & 1) * 6 + d) * 36 + (r >> 1) * 2 + col.  The item's
+// 4 d x 15 rows x 2 columns = 120 positions are 7.5 tiles of 16; wave = (N tile nt, every other tile): the 48 weight blocks of an
+// N tile are 192 VGPRs.  Pool = max over adjacent lanes (the column pair), the even lane stores four channels. ----
+constexpr int C22H_PLANE = 2 * 6 * S2_H;             // 432 slots per plane
+constexpr int C22H_LDS_WORDS = 4 * 8 * C22H_PLANE;   // 55 296 bytes
+constexpr int C22H_POS = 4 * O2_H * 2;               // 120 positions per item
+
+struct Conv22hParams {
   const float* in;      // [n][14][36][15][32]
-  const f32x4* wfrag;   // [2 nt][24 taps][2 chunks][64]: e: W[16 nt + (l & 15)][16 chunk + 4 (l >> 4) + e][kd][kh], tap = 8 kd + kh
+  const u32x4* wblk;    // [2 nt][24 taps][2][64]: lane (co = 16 nt + (l & 15), kk): e: W[co][8 kk + e][kd][kh], tap = 8 kd + kh; H | L
   const float* bias;    // [32]
   const float* slope;   // [32]
   float* out;           // [n][12][15][7][32]
   int32_t n_utt;
-  unsigned long long* stamps;   // tuning builds only: [grid][4 waves][4] summed phase cycles
-  unsigned* queue;              // work-item counter (zeroed before the launch), or NULL
+  unsigned* queue;
 };
 
-// ---- conv2_2 + pool2 through the depth transform.  Its transformed weights are 4 x 8 x 32 x 32 floats = 512 VGPRs
-// x 64 lanes: exactly the registers of four waves at two workgroups per CU, so every weight lives in ONE wave and each
-// wave = (N tile nt, 16-channel K chunk ch) holds 32 fragments and produces PARTIAL sums over its half of K.  Item =
-// (cube, pooled column j, third q of the output depths): two depth pairs x two columns = four M tiles (16 output rows,
-// 15 real) of 8 row taps x 16 MFMAs per wave.  The two waves of an N tile swap partial sums through LDS: each writes the
-// output-transformed sums of the pair it does not finish, keeps those of the pair it does (ch finishes pair ch), and
-// after the barrier adds its partner's, then bias (carried by chunk 0's accumulator), PReLU, max over the column pair. ----
-constexpr int C22W_TD = 4;                                   // output depths per item
-constexpr int C22W_PIX = (C22W_TD + 2) * 2 * S2_H;           // [6 d][2 w][36 h] pixels of 32 channels at 32 p + 4 (p >> 1)
-constexpr int C22W_IN_FLOATS = 34 * (C22W_PIX + 4);
-constexpr int C22W_XCH_FLOATS = 2 * 2 * 2 * 2 * 64 * 4;      // [nt][pair][column][y][lane] f32x4
-constexpr int C22W_LDS_FLOATS = C22W_IN_FLOATS + C22W_XCH_FLOATS;
-constexpr int C22W_PLANE = 34 * 2 * S2_H, C22W_COL = 34 * S2_H;   // floats per depth plane / per column inside it
-
 template <bool SLOPE01>
-__global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params p) {
+__global__ __launch_bounds__(256, 2) void c3d2_conv22h_kernel(const Conv22hParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem_c22w[];
-  float* reg = smem_c22w;
-  float* exch = reg + C22W_IN_FLOATS;
+  unsigned* const reg = reinterpret_cast<unsigned*>(smem_c22w);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
-  const int nt = wave & 1, ch = wave >> 1;
-#ifdef SVK_TUNING
-  const unsigned long long clk_entry = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one counter for the whole chip
-#endif
-  f32x4 G[4][8];   // [k][kh], this wave's N tile and K chunk
+  const int nt = wave & 1, half = wave >> 1;
+  u32x4 W[24][2];
 #pragma unroll
-  for (int kh = 0; kh < 8; ++kh) {
-    const f32x4 g0 = p.wfrag[((nt * 24 + kh) * 2 + ch) * 64 + lane], g1 = p.wfrag[((nt * 24 + 8 + kh) * 2 + ch) * 64 + lane],
-                g2 = p.wfrag[((nt * 24 + 16 + kh) * 2 + ch) * 64 + lane];
-    G[0][kh] = g0;
-    G[1][kh] = 0.5f * ((g0 + g2) + g1);
-    G[2][kh] = 0.5f * ((g0 + g2) - g1);
-    G[3][kh] = g2;
+  for (int t = 0; t < 24; ++t) {
+    W[t][0] = p.wblk[((nt * 24 + t) * 2) * 64 + lane];
+    W[t][1] = p.wblk[((nt * 24 + t) * 2 + 1) * 64 + lane];
   }
-  const float b = ch == 0 ? p.bias[16 * nt + i] : 0.f, sl = p.slope[16 * nt + i];
-  const float* const a0 = reg + 68 * i + 4 * kk + 16 * ch;   // row 2 i of column 0 of plane 0, this lane's K piece
-  constexpr int PER_CUBE = O2_W * (O2_D / C22W_TD);           // 7 x 3 items
+  f32x4 b4, sl4;   // channels 16 nt + 4 kk .. + 3 of ONE position
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    b4[r] = p.bias[16 * nt + 4 * kk + r];
+    sl4[r] = p.slope[16 * nt + 4 * kk + r];
+  }
+  constexpr int PER_CUBE = O2_W * (O2_D / 4);   // 7 x 3 items
   const int n_items = p.n_utt * PER_CUBE;
-#ifdef SVK_TUNING
-  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
-  const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  __shared__ int q_next;   // dynamic work items: see c3d2_conv21w_kernel
+  __shared__ int q_next;
   int item = blockIdx.x;
   while (item < n_items) {
-    SVK_STAMP(ts0);
     unsigned q_ticket = 0;
     if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
     const int u = item / PER_CUBE, rem = item - u * PER_CUBE, q = rem / O2_W, j = rem - q * O2_W;
-    // stage [6 d][36 h][2 w][32 c] of the input as pixels p = (dl * 2 + w) * 36 + h (h fastest): 13.5 16-byte pieces per
-    // thread, seven in flight at a time
-    const float* src = p.in + ((int64_t)u * A2_D + C22W_TD * q) * (S2_H * A2_W * 32) + 2 * j * 32;
-    constexpr int NV = 7;
-    // piece e = t + 256 k of thread t: (16-byte piece e & 7, column wq = (e >> 3) & 1) are the thread's own, dh = (t >> 4) +
-    // 16 k.  Its LDS pixel is dh + 36 wq + 36 dl with dl = dh / 36, and 16 k + 36 dl is even, so the address is
-    // A0 + 544 k + 1 224 dl: for a compile-time k, dl is a constant plus ONE comparison of t >> 4 with the window's depth
-    // boundary -- two vector instructions per piece where the general form (a division by 36, the pixel, the pad) took a dozen
-    // (a fifth of this kernel's vector instructions, none of which overlaps an MFMA).
-    // (Measured, round 4: the loads of the NEXT item issued right behind the second barrier, in front of the epilogue's stores --
-    // 8 of the 14 pieces, more spills -- move 2.3 k cycles from this stamp into the epilogue and leave the kernel where it was.)
+    // stage + split: piece e = t + 256 k: channels 4 (e & 7) .. + 3 of pixel (dh = (t >> 4) + 16 k, column (e >> 3) & 1), dh = d * 36 + h
+    const float* src = p.in + ((int64_t)u * A2_D + 4 * q) * (S2_H * A2_W * 32) + 2 * j * 32;
     {
       int tl = threadIdx.x;
-      asm volatile("" : "+v"(tl));   // (keeps this arithmetic inside the item loop: hoisted, it costs registers the kernel spills)
+      asm volatile("" : "+v"(tl));
       const int piece = tl & 7, wq = (tl >> 3) & 1, dh0 = tl >> 4;
-      const int pixb = dh0 + 36 * wq;
-      float* const a0s = reg + 32 * pixb + 4 * (pixb >> 1) + 4 * piece;
       const float* const g0 = src + dh0 * (A2_W * 32) + wq * 32 + 4 * piece;
+      constexpr int NV = 7;   // (all 14 in flight spill: the 192 weight registers stay live)
 #pragma unroll
       for (int r0 = 0; r0 < 14; r0 += NV) {
         f32x4 sv[NV];
@@ -807,106 +733,68 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22w_kernel(const Conv22Params
           if (k < 13 || tl < 128) sv[k - r0] = *reinterpret_cast<const f32x4*>(g0 + (int64_t)(16 * k) * (A2_W * 32));
 #pragma unroll
         for (int k = r0; k < r0 + NV; ++k) {
-          const int dl_lo = (16 * k) / S2_H, cross = S2_H * (dl_lo + 1) - 16 * k;   // dh0 >= cross: the next depth
-          float* d = a0s + 544 * k + 1224 * dl_lo;
-          if (cross < 16) d = dh0 >= cross ? d + 1224 : d;
-          if (k < 13 || tl < 128) *reinterpret_cast<f32x4*>(d) = sv[k - r0];
+          // dh = dh0 + 16 k -> (d, h): 16 k = 36 d_lo + h_lo at compile time, one comparison for the carry
+          const int d_lo = (16 * k) / S2_H, h_lo = 16 * k - S2_H * d_lo;
+          int hh = dh0 + h_lo, d = d_lo;
+          if (h_lo + 15 >= S2_H) {
+            const bool carry = hh >= S2_H;
+            hh = carry ? hh - S2_H : hh;
+            d = carry ? d + 1 : d;
+          }
+          const int slot = ((hh & 1) * 6 + d) * S2_H + (hh >> 1) * 2 + wq;
+          unsigned* const dst = reg + 4 * ((piece >> 1) * C22H_PLANE + slot) + 2 * (piece & 1);
+          unsigned h0, l0, h1, l1;
+          split2(__builtin_shufflevector(sv[k - r0], sv[k - r0], 0, 1), h0, l0);
+          split2(__builtin_shufflevector(sv[k - r0], sv[k - r0], 2, 3), h1, l1);
+          if (k < 13 || tl < 128) {
+            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+            *reinterpret_cast<u32x2*>(dst + 4 * 4 * C22H_PLANE) = (u32x2){l0, l1};
+          }
         }
       }
     }
-    SVK_STAMP(ts1);
     if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + (int)gridDim.x : item + (int)gridDim.x;
     __syncthreads();
-    SVK_STAMP(ts2);
     const int item_next = q_next;
-    f32x4 own[2][2];   // [column][y]: the partial sums of the pair this wave finishes
-    // the first tile's first tap; every later tile's is read under the previous tile's last 16 MFMAs
-    f32x4 x[4];
-#pragma unroll
-    for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(a0 + 2 * C22W_PLANE * (1 - ch) + C22W_PLANE * dd);
+    // tiles t = half, half + 2, ...: positions P = 16 t + i -> (depth P / 30, row (P % 30) / 2, column P & 1)
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      const int P = pass ? ch : 1 - ch;   // the partner's pair first
+    for (int t = half; t < (C22H_POS + 15) / 16; t += 2) {
+      const int P = min(16 * t + i, C22H_POS - 1);
+      const int dq = (P * 2185) >> 16, r30 = P - 30 * dq, row = r30 >> 1;      // P / 30 for P < 120
+      // input pixel (dq + kd, 2 row + kh, col), channels 8 kk .. + 7: slot ((kh & 1) * 6 + dq + kd) * 36 + (row + kh / 2) * 2 + col of plane kk [l: + 4]
+      const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * (kk * C22H_PLANE + dq * S2_H + 2 * row + (i & 1));
+      auto rd = [&](int tap, int piece) -> u32x4 {
+        const int kd = tap >> 3, kh = tap & 7;
+        return *reinterpret_cast<const u32x4*>(a2 + 16 * (((kh & 1) * 6 + kd) * S2_H + (kh >> 1) * 2) + 16 * 4 * C22H_PLANE * piece);
+      };
+      f32x4 acc = b4;
+      u32x4 bh[3], bl[3];
+      bh[0] = rd(0, 0);
+      bl[0] = rd(0, 1);
+      bh[1] = rd(1, 0);
+      bl[1] = rd(1, 1);
 #pragma unroll
-      for (int wq = 0; wq < 2; ++wq) {
-        const float* ap = a0 + 2 * C22W_PLANE * P + C22W_COL * wq;
-        f32x4 acc[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = k == 1 ? (f32x4){b, b, b, b} : (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x2 t[4][2];
-#pragma unroll
-        for (int kh = 0; kh < 8; ++kh) {
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) wino_input_pair(x, hf, t);
-          __builtin_amdgcn_sched_barrier(0);
-          if (kh + 1 < 8) {
-            const int off = 32 * (kh + 1) + 4 * ((kh + 1) >> 1);
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C22W_PLANE * dd + off);
-          } else if (wq == 0) {          // the pair's second column
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C22W_COL + C22W_PLANE * dd);
-          } else if (pass == 0) {        // the second pass's pair (ch), column 0
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(a0 + 2 * C22W_PLANE * ch + C22W_PLANE * dd);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[k][e >> 1][e & 1], G[k][kh][e], acc[k], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+      for (int tap = 0; tap < 24; ++tap) {
+        if (tap + 2 < 24) {
+          bh[(tap + 2) % 3] = rd(tap + 2, 0);
+          bl[(tap + 2) % 3] = rd(tap + 2, 1);
         }
-        f32x2 s0[2], s1[2];
-        wino_output(acc, s0, s1);
-        const f32x4 y0 = __builtin_shufflevector(s0[0], s0[1], 0, 1, 2, 3), y1 = __builtin_shufflevector(s1[0], s1[1], 0, 1, 2, 3);
-        if (pass == 0) {
-          float* xo = exch + ((((nt * 2 + P) * 2 + wq) * 2) * 64 + lane) * 4;
-          *reinterpret_cast<f32x4*>(xo) = y0;
-          *reinterpret_cast<f32x4*>(xo + 256) = y1;
-        } else {
-          own[wq][0] = y0;
-          own[wq][1] = y1;
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[tap][0]), __builtin_bit_cast(f16x8, bh[tap % 3]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[tap][0]), __builtin_bit_cast(f16x8, bl[tap % 3]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[tap][1]), __builtin_bit_cast(f16x8, bh[tap % 3]), acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    SVK_STAMP(ts3);
-    __syncthreads();   // the partner's partial sums are in LDS; nobody reads the input region any more
-    SVK_STAMP(ts4);
-    SVK_STAMP_ADD(0, ts0, ts1);  // staging
-    SVK_STAMP_ADD(1, ts1, ts2);  // barrier 1
-    SVK_STAMP_ADD(2, ts2, ts3);  // 2 passes x 2 tiles of 8 taps x 16 MFMAs + transforms + exchange writes
-    SVK_STAMP_ADD(3, ts3, ts4);  // barrier 2 (the epilogue that follows is counted with the next item's staging)
-    {
-      const float* xi = exch + ((((nt * 2 + ch) * 2) * 2) * 64 + lane) * 4;   // pair ch, written by wave (nt, 1 - ch)
+      const f32x4 y = prelu4<SLOPE01>(acc, sl4);
+      f32x4 o;
 #pragma unroll
-      for (int y = 0; y < 2; ++y) {
-        const f32x4 v0 = own[0][y] + *reinterpret_cast<const f32x4*>(xi + 256 * y);
-        const f32x4 v1 = own[1][y] + *reinterpret_cast<const f32x4*>(xi + 512 + 256 * y);
-        // rows 4 kk + r = output row h'; pool over the column pair, PReLU first (model.py:156-158)
-        float* const o = p.out + ((((int64_t)u * O2_D + C22W_TD * q + 2 * ch + y) * O2_H) * O2_W + j) * 32 + 16 * nt;   // uniform
-        const int olane = 4 * kk * (O2_W * 32) + i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int hq = 4 * kk + r;
-          if (hq < O2_H) o[olane + r * (O2_W * 32)] = fmaxf(prelu_t<SLOPE01>(v0[r], sl), prelu_t<SLOPE01>(v1[r], sl));
-        }
-      }
+      for (int r = 0; r < 4; ++r) o[r] = max_with_lane_xor1(y[r]);
+      if ((i & 1) == 0 && 16 * t + i < C22H_POS)
+        *reinterpret_cast<f32x4*>(p.out + ((((int64_t)u * O2_D + 4 * q + dq) * O2_H + row) * O2_W + j) * 32 + 16 * nt + 4 * kk) = o;
     }
+    __syncthreads();
     item = item_next;
   }
-#ifdef SVK_TUNING
-  if (p.stamps && lane == 0) {
-    for (int k = 0; k < 2; ++k) p.stamps[((size_t)blockIdx.x * 4 + wave) * 4 + k] = stamp_acc[k];
-    p.stamps[((size_t)blockIdx.x * 4 + wave) * 4 + 2] = stamp_acc[2] + stamp_acc[3];   // (MFMA passes + barrier 2 in one slot;
-    // slot 3 of wave 0 / 1 carries the clock pair: shader cycles and 100 MHz ticks over the loop)
-    // (waves 2 / 3: the absolute 100 MHz time of the workgroup's entry into the kernel / of its leaving the loop)
-    p.stamps[((size_t)blockIdx.x * 4 + wave) * 4 + 3] = wave == 0 ? __builtin_amdgcn_s_memtime() - clk_c0
-                                                        : wave == 1 ? __builtin_amdgcn_s_memrealtime() - clk_r0
-                                                        : wave == 2 ? clk_entry : __builtin_amdgcn_s_memrealtime();
-  }
-#endif
 }
 
 // ---- conv3_1 (32 -> 64, kernel (3,1,3)) + BN + PReLU (model.py:126-128, :159-161), depth-transformed like the kernels
@@ -949,7 +837,7 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
       G[3][kw][ch] = g2;
     }
   // M = channel (A = the weights G), N = position (B = the transformed fragments): a lane ends up with channels 16 nt + 4 kk .. + 3
-  // of ONE position -- 16 contiguous bytes of the chunked output (round 4, as in c3d2_conv21w_kernel; bit-identical)
+  // of ONE position -- 16 contiguous bytes of the chunked output (round 4, as in c3d2_conv21h_kernel; bit-identical)
   f32x4 b4, sl4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -960,7 +848,7 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
   const int mi = i < 15 ? i : 14;
   const float* const a0 = reg + C31_PIXF * ((mi / 5) * 7 + mi % 5) + 4 * kk;
   const int n_items = p.n_utt * 5;
-  __shared__ int q_next;   // dynamic work items: see c3d2_conv21w_kernel (three workgroups share a CU here)
+  __shared__ int q_next;   // dynamic work items: see c3d2_conv21h_kernel (three workgroups share a CU here)
   int item = blockIdx.x;
   while (item < n_items) {
     unsigned q_ticket = 0;
@@ -1052,17 +940,17 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
 
 }  // namespace
 
-extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_w21frag,
-                               const float* d_bias21, const float* d_slope21, const float* d_w22frag,
+extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_w21blk,
+                               const float* d_bias21, const float* d_slope21, const void* d_w22blk,
                                const float* d_bias22, const float* d_slope22, int32_t flags, float* d_act2, float* d_out) {
   if (!ctx) return SVK_ERR_BAD_ARG;
   SVK_REQUIRE(ctx, n_utt >= 0, "n_utt negative");
   SVK_REQUIRE(ctx, (flags & ~2) == 0, "flags: only bit 1 (slopes in [0, 1]) is defined");
   if (n_utt == 0) return SVK_OK;
-  SVK_REQUIRE(ctx, d_in && d_w21frag && d_bias21 && d_slope21 && d_w22frag && d_bias22 && d_slope22 && d_act2 && d_out,
+  SVK_REQUIRE(ctx, d_in && d_w21blk && d_bias21 && d_slope21 && d_w22blk && d_bias22 && d_slope22 && d_act2 && d_out,
               "NULL buffer");
   SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_act2) |
-                     reinterpret_cast<uintptr_t>(d_w21frag) | reinterpret_cast<uintptr_t>(d_w22frag)) & 15) == 0,
+                     reinterpret_cast<uintptr_t>(d_w21blk) | reinterpret_cast<uintptr_t>(d_w22blk) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0,
               "buffers must be 16-byte aligned");
   SVK_REQUIRE(ctx, (int64_t)n_utt * 21 < ((int64_t)1 << 31), "too many cubes for one launch");
   // work-item counters of the kernels that share a CU between workgroups (slots of the handle's 256-byte scratch; svk_log_power
@@ -1073,14 +961,14 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   if (queues) SVK_HIP(ctx, hipMemsetAsync(queues, 0, 16, ctx->stream));
   const bool slope01 = (flags & 2) != 0;
   {
-    Conv21Params p{d_in, reinterpret_cast<const f32x4*>(d_w21frag), d_bias21, d_slope21, d_act2, n_utt, queues};
-    void (*kern)(const Conv21Params) = slope01 ? c3d2_conv21w_kernel<true> : c3d2_conv21w_kernel<false>;
-    const size_t lds = sizeof(float) * (size_t)C21W_LDS_FLOATS;
+    Conv21hParams p{d_in, reinterpret_cast<const u32x4*>(d_w21blk), d_bias21, d_slope21, d_act2, n_utt, queues};
+    void (*kern)(const Conv21hParams) = slope01 ? c3d2_conv21h_kernel<true> : c3d2_conv21h_kernel<false>;
+    const size_t lds = sizeof(unsigned) * (size_t)C21H_LDS_WORDS;
     if (lds > (size_t)ctx->lds_per_cu)
       return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage2 (conv2_1) needs %zu bytes of LDS per workgroup (device: %d)",
                       lds, ctx->lds_per_cu);
     SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t items = (int64_t)n_utt * (S2_H / C21W_TH);
+    const int64_t items = (int64_t)n_utt * (S2_H / 4);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess ||
         per_cu < 1)
@@ -1090,85 +978,18 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     SVK_LAUNCH_CHECK(ctx);
   }
   {
-    Conv22Params p{d_act2, reinterpret_cast<const f32x4*>(d_w22frag), d_bias22, d_slope22, d_out, n_utt, nullptr,
-                   queues ? queues + 1 : nullptr};
-    void (*kern)(const Conv22Params) = slope01 ? c3d2_conv22w_kernel<true> : c3d2_conv22w_kernel<false>;
-    const size_t lds = sizeof(float) * (size_t)C22W_LDS_FLOATS;
-    if (lds > (size_t)ctx->lds_per_cu)
-      return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_stage2 (conv2_2) needs %zu bytes of LDS per workgroup (device: %d)",
-                      lds, ctx->lds_per_cu);
+    Conv22hParams p{d_act2, reinterpret_cast<const u32x4*>(d_w22blk), d_bias22, d_slope22, d_out, n_utt, queues ? queues + 1 : nullptr};
+    void (*kern)(const Conv22hParams) = slope01 ? c3d2_conv22h_kernel<true> : c3d2_conv22h_kernel<false>;
+    const size_t lds = sizeof(unsigned) * (size_t)C22H_LDS_WORDS;
     SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t items = (int64_t)n_utt * (O2_W * (O2_D / C22W_TD));
+    const int64_t items = (int64_t)n_utt * 21;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess ||
         per_cu < 1)
       per_cu = 2;
-    const unsigned gridw = (unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu);
-#ifdef SVK_TUNING
-    const bool want_stamps_w = getenv("SVK_C3D2_STAMPS") != nullptr;
-    const size_t stamp_bytes_w = (size_t)gridw * 4 * 4 * sizeof(unsigned long long);
-    if (want_stamps_w) {
-      const int rc = svk_ensure_work(ctx, stamp_bytes_w);
-      if (rc != SVK_OK) return rc;
-      p.stamps = reinterpret_cast<unsigned long long*>(ctx->work);
-    }
-#endif
-    hipLaunchKernelGGL(kern, dim3(gridw), dim3(256), lds, ctx->stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(256), lds,
+                       ctx->stream, p);
     SVK_LAUNCH_CHECK(ctx);
-#ifdef SVK_TUNING
-    if (want_stamps_w) {
-      std::vector<unsigned long long> h((size_t)gridw * 16);
-      SVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      SVK_HIP(ctx, hipMemcpy(h.data(), p.stamps, stamp_bytes_w, hipMemcpyDeviceToHost));
-      const char* names[4] = {"staging (+ previous epilogue)", "barrier 1", "MFMA passes + exchange + barrier 2", ""};
-      const double per = (double)items / gridw;
-      {
-        std::vector<double> mhz;
-        for (unsigned b = 0; b < gridw; ++b) {
-          const unsigned long long c = h[((size_t)b * 4 + 0) * 4 + 3], r = h[((size_t)b * 4 + 1) * 4 + 3];
-          if (r) mhz.push_back(100.0 * (double)c / (double)r);
-        }
-        if (!mhz.empty()) {
-          std::sort(mhz.begin(), mhz.end());
-          fprintf(stderr, "conv22w in-kernel clock: median %.0f MHz (min %.0f, max %.0f)\n", mhz[mhz.size() / 2], mhz.front(), mhz.back());
-        }
-      }
-      {   // the launch on the chip-wide 100 MHz counter (microseconds from the first workgroup's entry)
-        std::vector<double> ent, beg, end;
-        for (unsigned b = 0; b < gridw; ++b) {
-          const double e = (double)h[((size_t)b * 4 + 2) * 4 + 3], x = (double)h[((size_t)b * 4 + 3) * 4 + 3];
-          ent.push_back(e);
-          end.push_back(x);
-          beg.push_back(x - (double)h[((size_t)b * 4 + 1) * 4 + 3]);
-        }
-        const double t0 = *std::min_element(ent.begin(), ent.end());
-        auto us = [&](std::vector<double>& v, const char* what) {
-          std::sort(v.begin(), v.end());
-          fprintf(stderr, "conv22w %s: first %.1f  median %.1f  last %.1f us after the first workgroup's entry\n", what, (v.front() - t0) / 100.0,
-                  (v[v.size() / 2] - t0) / 100.0, (v.back() - t0) / 100.0);
-        };
-        us(ent, "kernel entry");
-        us(beg, "loop start");
-        us(end, "loop end");
-      }
-      {   // spread over workgroups of the loop's total cycles (wave 0): static item assignment makes the slowest one the kernel's time
-        std::vector<double> tot;
-        for (unsigned b = 0; b < gridw; ++b) tot.push_back((double)(h[(size_t)b * 16 + 0] + h[(size_t)b * 16 + 1] + h[(size_t)b * 16 + 2]));
-        std::sort(tot.begin(), tot.end());
-        fprintf(stderr, "conv22w loop cycles per workgroup: min %.0f  median %.0f  p90 %.0f  max %.0f\n", tot.front(), tot[tot.size() / 2],
-                tot[tot.size() * 9 / 10], tot.back());
-      }
-      for (int w = 0; w < 4; ++w) {
-        fprintf(stderr, "conv22w stamps wave %d (cycles per item, %d workgroups per CU):", w, per_cu);
-        for (int k = 0; k < 3; ++k) {
-          double sum = 0;
-          for (unsigned b = 0; b < gridw; ++b) sum += (double)h[((size_t)b * 4 + w) * 4 + k];
-          fprintf(stderr, "  %s %.0f", names[k], sum / gridw / per);
-        }
-        fprintf(stderr, "\n");
-      }
-    }
-#endif
   }
   return SVK_OK;
 }

@@ -474,18 +474,21 @@ class Engine:
 
     def c3d2_stage2(self, act1, tables):
         """svk_c3d2_stage2: [n, 16, 36, 18, 16] (svk_c3d2_stage1's output) -> conv2_1 -> conv2_2 -> pool2 with their
-        BN + PReLU -> [n, 12, 15, 7, 32] f32 (channels last), both convolutions depth-transformed."""
+        BN + PReLU -> [n, 12, 15, 7, 32] f32 (channels last), both convolutions through two-piece f16 products."""
         torch = _torch()
         n = act1.shape[0]
         if tuple(act1.shape[1:]) != (16, 36, 18, 16) or not act1.is_contiguous():
             raise ValueError("c3d2_stage2 wants the activation [n, 16, 36, 18, 16]")
         w21, b21, s21, w22, b22, s22 = tables[:6]
+        if w21.dtype != torch.float16 or w22.dtype != torch.float16 or tuple(w21.shape) != (2, 6, 2, 64, 8) or tuple(w22.shape) != (2, 24, 2, 64, 8):
+            raise ValueError("c3d2_stage2 wants the half-pair weight blocks of FusedEmbedder.stage2_tables()")
         slope01 = bool(tables[6]) if len(tables) > 6 else False
         act2 = torch.empty((n, 14, 36, 15, 32), dtype=torch.float32, device=self.device)
         out = torch.empty((n, 12, 15, 7, 32), dtype=torch.float32, device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_stage2(self.ctx, self._ptr(act1), n, self._ptr(w21), self._ptr(b21), self._ptr(s21),
-                                       self._ptr(w22), self._ptr(b22), self._ptr(s22), 2 if slope01 else 0,
+                                       self._ptr(w22), self._ptr(b22), self._ptr(s22),
+                                       2 if slope01 else 0,
                                        self._ptr(act2), self._ptr(out)), self.ctx)
         return out
 

@@ -246,8 +246,8 @@ class FusedEmbedder:
     def stage2_tables(self):
         """Operand fragments of `svk_c3d2_stage2` (conv2_1 16 -> 32 k(3,1,4); conv2_2 32 -> 32 k(3,8,1) stride
         (1,2,1) + pool), BN folded, or None when the layers differ:
-          w21frag [2 nt][12][64][4]   : lane (co = 16 nt + (l & 15), kk = l >> 4): W[co][4 kk + e][kd][kw], tap 4 kd + kw
-          w22frag [2 nt][24][2][64][4]: W[co][16 chunk + 4 kk + e][kd][kh], tap 8 kd + kh"""
+          w21blk  [2 nt][6][2][64][8] halves: conv2_1 through two-piece f16 products (H | L blocks of tap pairs; see the code)
+          w22blk  [2 nt][24][2][64][8] halves: conv2_2, one tap per K = 32 block (H | L)"""
         hit = getattr(self, "_stage2", False)
         if hit is not False:
             return hit
@@ -260,20 +260,30 @@ class FusedEmbedder:
         lane = torch.arange(64, device=dev)
         ch, kq = lane & 15, lane >> 4
         a = w1.contiguous()[:, :, :, 0, :]                                   # [co][ci][kd][kw]
-        f21 = torch.empty((2, 12, 64, 4), dtype=torch.float32, device=dev)
+        # conv2_1 runs two-piece f16 products (see stage1_tables): [2 nt][6 pairs][2: H | L][64 lanes][8 halves], pair = 2 kd + kw / 2,
+        # lane (co = 16 nt + (l & 15), kk = l >> 4): element e = W[co][ci = 8 (kk & 1) + e][kd][kw + (kk >= 2)]
+        e8 = torch.arange(8, device=dev)
+        ci8 = 8 * (kq & 1)[:, None] + e8[None, :]
+        f21 = torch.empty((2, 6, 2, 64, 8), dtype=torch.float16, device=dev)
         for nt in range(2):
             for kd in range(3):
-                for kw in range(4):
-                    for e in range(4):
-                        f21[nt, 4 * kd + kw, :, e] = a[16 * nt + ch, 4 * kq + e, kd, kw]
+                for kw2 in range(2):
+                    kw = 2 * kw2 + (kq >= 2).long()
+                    w = a[(16 * nt + ch)[:, None], ci8, kd, kw[:, None]]
+                    h = w.to(torch.float16)
+                    f21[nt, 2 * kd + kw2, 0] = h
+                    f21[nt, 2 * kd + kw2, 1] = (w - h.to(torch.float32)).to(torch.float16)
         bmat = w2.contiguous()[:, :, :, :, 0]                                # [co][ci][kd][kh]
-        f22 = torch.empty((2, 24, 2, 64, 4), dtype=torch.float32, device=dev)
+        # conv2_2: [2 nt][24 taps][2: H | L][64 lanes][8 halves], tap = 8 kd + kh, element e = W[co][ci = 8 kk + e][kd][kh] (K = 32 = one tap)
+        ci32 = 8 * kq[:, None] + e8[None, :]
+        f22 = torch.empty((2, 24, 2, 64, 8), dtype=torch.float16, device=dev)
         for nt in range(2):
             for kd in range(3):
                 for kh in range(8):
-                    for chunk in range(2):
-                        for e in range(4):
-                            f22[nt, 8 * kd + kh, chunk, :, e] = bmat[16 * nt + ch, 16 * chunk + 4 * kq + e, kd, kh]
+                    w = bmat[(16 * nt + ch)[:, None], ci32, kd, kh]
+                    h = w.to(torch.float16)
+                    f22[nt, 8 * kd + kh, 0] = h
+                    f22[nt, 8 * kd + kh, 1] = (w - h.to(torch.float32)).to(torch.float16)
 
         def per_channel(t, n):
             return t.expand(n).contiguous() if t.numel() == 1 else t.contiguous()
