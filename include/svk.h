@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 109 /* 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
+#define SVK_VERSION 109 /* 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 / svk_c3d2_conv31 run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -286,14 +286,14 @@ int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* 
                     const float* d_slope21, const void* d_w22blk, const float* d_bias22, const float* d_slope22,
                     int32_t flags, float* d_act2, float* d_out);
 
-/* conv3_1 (32 -> 64, kernel (3,1,3)) -> BN -> PReLU, model.py:126-128 + :159-161, one f32-MFMA kernel through Winograd's
- * F(2, 3) along depth.
+/* conv3_1 (32 -> 64, kernel (3,1,3)) -> BN -> PReLU, model.py:126-128 + :159-161, one kernel on v_mfma_f32_16x16x32_f16
+ * through two-piece products like svk_c3d2_stage1 (direct form, one tap per K = 32 block).
  *   d_in    [n_utt][12][15][7][32]   = svk_c3d2_stage2's output
- *   d_wfrag [4 nt][9 taps][2 chunks][64][4]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: W31[co][16 chunk + 4 kk + e][kd][kw],
- *           tap 3 kd + kw (BatchNorm folded);  d_bias / d_slope [64]
+ *   d_wblk  [4 nt][9 taps][2][64][8 halves]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: W31[co][ci = 8 kk + e][kd][kw],
+ *           tap 3 kd + kw (BatchNorm folded); block 0 = H = f16(w), block 1 = L = f16(w - H);  d_bias / d_slope [64]
  *   flags   bit 1: the caller asserts every PReLU slope lies in [0, 1]; every other bit must be 0
  *   d_out   [n_utt][10 d][8 chunks of 8 channels][5 w][15 h][8]: chunked and column-major, what svk_c3d2_conv32t stages from */
-int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
+int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_wblk, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);
 
 /* The last block, model.py:132-139 (definitions) + :165-170 (forward): conv4_1 (64 -> 128, kernel (3,1,3)) -> BN -> PReLU,

@@ -2,7 +2,7 @@
 //   c3d2_stage1h_kernel   cube + conv1_1 + conv1_2 + pool1 on v_mfma_f32_16x16x32_f16 through two-piece f16 products (round 4)
 //   c3d2_conv21h_kernel   conv2_1, two-piece f16 products
 //   c3d2_conv22h_kernel   conv2_2 + pool2, two-piece f16 products
-//   c3d2_conv31w_kernel   conv3_1 on v_mfma_f32_16x16x4_f32, depth-transformed (Winograd F(2, 3) along depth); writes the chunked, column-major layout c3d2_tail_kernel<Conv32T> stages
+//   c3d2_conv31h_kernel   conv3_1, two-piece f16 products; writes the chunked, column-major layout c3d2_tail_kernel<Conv32T> stages
 // (conv3_2, conv4_1, conv4_2 and FC5 live in c3d2_tail.hip.)  BatchNorm (eval mode) is folded into weights and biases by
 // the host (model.FusedEmbedder).  Work items come from device-wide counters.  What earlier rounds built and superseded is
 // under tools/experiments/ with its measured numbers: the direct-form f32 kernels, the t-plane first block, the K-split conv3_2
@@ -145,22 +145,9 @@ __device__ __forceinline__ void dma_patch_w(const Stage1Params& p, ItemPos it, i
     }
 }
 
-// Input transform of the depth-Winograd form for one element pair (hf = 0: elements 0, 1; 1: elements 2, 3) of the four
-// depth fragments x: t0 = x0 - x2, t1 = x1 + x2, t2 = x2 - x1, t3 = x1 - x3, as four v_pk_add_f32 (written out: the
-// compiler emits the packed form now and then for sums and never for differences, which use the negate modifiers).
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
-  f32x2 d;
-  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
-  f32x2 d;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
 // prelu for 0 <= slope <= 1 straight off MFMA accumulators: fmaxf() on a value the compiler cannot prove canonical costs a
 // third instruction (v_max x, x in front of the real one) and the product is one v_mul per value; written as vectors it is one
-// v_pk_mul_f32 per PAIR + one v_max_f32 per value (12 -> 6 instructions per conv1_1 tile; the same product, the same
+// v_pk_mul_f32 per PAIR + one v_max_f32 per value (12 -> 6 instructions per four values; the same product, the same
 // maximum: bit-identical for every finite and infinite input, NaN stays NaN).
 // (the product is left to the compiler -- it selects v_pk_mul_f32 for a two-float vector product and, unlike for an asm
 // statement, counts the wait states between an MFMA and the first instruction that reads its result; the v_max behind it
@@ -186,59 +173,6 @@ __device__ __forceinline__ f32x4 prelu4(f32x4 v, f32x4 slope) {
     for (int r = 0; r < 4; ++r) o[r] = prelu(v[r], slope[r]);
   }
   return o;
-}
-// The packed product on values a VALU instruction produced (never straight off an MFMA: see pk_mul): as an asm statement it is
-// ONE v_pk_mul_f32 whatever pair of registers the allocator picked (the compiler's own choice falls back to two v_mul_f32 now and
-// then).
-__device__ __forceinline__ f32x2 pk_mul_valu(f32x2 a, f32x2 b) {
-  f32x2 d;
-  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-__device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
-__device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
-// The output transform y(2 P) = (a0 + a1) + a2, y(2 P + 1) = (a1 - a2) - a3 of four accumulators as eight packed adds in TWO
-// rounds of four independent ones: the compiler puts a wait state in front of an asm statement that reads the register the
-// instruction before it wrote, so a dependent chain written link by link costs an s_nop per link.
-__device__ __forceinline__ void wino_output(const f32x4 (&a)[4], f32x2 (&y0)[2], f32x2 (&y1)[2]) {
-  const f32x2 u0 = pk_add(lo2(a[0]), lo2(a[1])), u1 = pk_add(hi2(a[0]), hi2(a[1]));
-  const f32x2 w0 = pk_sub(lo2(a[1]), lo2(a[2])), w1 = pk_sub(hi2(a[1]), hi2(a[2]));
-  y0[0] = pk_add(u0, lo2(a[2]));
-  y0[1] = pk_add(u1, hi2(a[2]));
-  y1[0] = pk_sub(w0, lo2(a[3]));
-  y1[1] = pk_sub(w1, hi2(a[3]));
-}
-// PReLU of the two outputs of wino_output() with a lane's four slopes: four packed products, then eight v_max_f32 (12
-// instructions for 8 values; fmaxf(v, slope * v) compiled to 24: a product and a canonicalising v_max x, x per value on top)
-template <bool SLOPE01>
-__device__ __forceinline__ void prelu_pairs(f32x2 (&y0)[2], f32x2 (&y1)[2], f32x4 slope, f32x4& o0, f32x4& o1) {
-  if (SLOPE01) {
-    const f32x2 m00 = pk_mul_valu(y0[0], lo2(slope)), m01 = pk_mul_valu(y0[1], hi2(slope));
-    const f32x2 m10 = pk_mul_valu(y1[0], lo2(slope)), m11 = pk_mul_valu(y1[1], hi2(slope));
-    o0[0] = max_raw(y0[0][0], m00[0]);
-    o0[1] = max_raw(y0[0][1], m00[1]);
-    o0[2] = max_raw(y0[1][0], m01[0]);
-    o0[3] = max_raw(y0[1][1], m01[1]);
-    o1[0] = max_raw(y1[0][0], m10[0]);
-    o1[1] = max_raw(y1[0][1], m10[1]);
-    o1[2] = max_raw(y1[1][0], m11[0]);
-    o1[3] = max_raw(y1[1][1], m11[1]);
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      o0[r] = prelu(y0[r >> 1][r & 1], slope[r]);
-      o1[r] = prelu(y1[r >> 1][r & 1], slope[r]);
-    }
-  }
-}
-__device__ __forceinline__ void wino_input_pair(const f32x4 (&x)[4], int hf, f32x2 (&t)[4][2]) {
-  f32x2 xh[4];
-#pragma unroll
-  for (int dd = 0; dd < 4; ++dd) xh[dd] = hf ? __builtin_shufflevector(x[dd], x[dd], 2, 3) : __builtin_shufflevector(x[dd], x[dd], 0, 1);
-  t[0][hf] = pk_sub(xh[0], xh[2]);
-  t[1][hf] = pk_add(xh[1], xh[2]);
-  t[2][hf] = pk_sub(xh[2], xh[1]);
-  t[3][hf] = pk_sub(xh[1], xh[3]);
 }
 
 
@@ -797,20 +731,19 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22h_kernel(const Conv22hParam
   }
 }
 
-// ---- conv3_1 (32 -> 64, kernel (3,1,3)) + BN + PReLU (model.py:126-128, :159-161), depth-transformed like the kernels
-// above.  No taps along h, so item = (cube, block of 3 rows): region 12 depths x 3 rows x 7 columns of 32 channels
-// (36 KB as pixels of 36 floats: pixel stride 9 sixteen-byte slots, odd, so pixels that differ mod 16 never share a bank
-// slot; the 15 pixels of a tile span 19, three lanes of a quarter wave take a second pass).  M tile = 3 rows x 5 output
-// columns of one depth pair (15 positions + 1 dummy), five tiles per item; wave = N tile (16 of the 64 output channels),
-// 4 k x 3 kw x 2 chunks = 24 weight fragments = 96 VGPRs; 96 MFMAs per tile where the direct form issues 144. ----
-constexpr int C31_PIXF = 36;
-constexpr int C31_PIX = 12 * 3 * 7;                           // pixel p = (d * 3 + hl) * 7 + w
-constexpr int C31_LDS_FLOATS = C31_PIXF * C31_PIX;
-constexpr int C31_PLANE = C31_PIXF * 21;                      // floats per depth plane
+// ---- conv3_1 (32 -> 64, kernel (3,1,3)) + BN + PReLU (model.py:126-128, :159-161) through two-piece f16 products: direct
+// form, K = 32 = the 32 input channels of ONE tap, three MFMAs per tap, 9 taps.  No taps along h, so item = (cube, block of 3
+// rows): region 12 depths x 3 rows x 7 columns of 32 channels, split into (h, l) while staged: eight planes (four channel quarters
+// x {h, l}) of 16-byte slots, slot = pixel (d * 3 + row) * 7 + col (32 KB; three workgroups per CU).  The item's 10 d x 3 rows x
+// 5 columns = 150 positions are 9.4 tiles of 16 consecutive positions; wave = N tile (16 of the 64 output channels: 18 weight
+// blocks = 72 VGPRs), every wave walks all ten tiles.  Output chunked and column-major, 16-byte stores. ----
+constexpr int C31H_PLANE = 12 * 3 * 7;                        // 252 slots per plane
+constexpr int C31H_LDS_WORDS = 4 * 8 * C31H_PLANE;            // 32 256 bytes
+constexpr int C31H_POS = 10 * 3 * 5;                          // 150 positions per item
 
 struct Conv31Params {
   const float* in;      // [n][12][15][7][32]
-  const f32x4* wfrag;   // [4 nt][9 taps][2 chunks][64]: e: W[16 nt + (l & 15)][16 chunk + 4 (l >> 4) + e][kd][kw], tap = 3 kd + kw
+  const u32x4* wblk;    // [4 nt][9 taps][2][64]: lane (co = 16 nt + (l & 15), kk): e: W[co][8 kk + e][kd][kw], tap = 3 kd + kw; H | L
   const float* bias;    // [64]
   const float* slope;   // [64]
   float* out;           // chunked and column-major: [n][10][8 chunks][5 w][15 h][8] (what svk_c3d2_conv32t stages)
@@ -819,34 +752,23 @@ struct Conv31Params {
 };
 
 template <bool SLOPE01>
-__global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params p) {
+__global__ __launch_bounds__(256, 3) void c3d2_conv31h_kernel(const Conv31Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem_c31[];
-  float* reg = smem_c31;
+  unsigned* const reg = reinterpret_cast<unsigned*>(smem_c31);
   const int lane = threadIdx.x & 63, nt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kk = lane >> 4;
-  f32x4 G[4][3][2];   // [k][kw][chunk]
+  u32x4 W[9][2];
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      const f32x4 g0 = p.wfrag[((nt * 9 + kw) * 2 + ch) * 64 + lane], g1 = p.wfrag[((nt * 9 + 3 + kw) * 2 + ch) * 64 + lane],
-                  g2 = p.wfrag[((nt * 9 + 6 + kw) * 2 + ch) * 64 + lane];
-      G[0][kw][ch] = g0;
-      G[1][kw][ch] = 0.5f * ((g0 + g2) + g1);
-      G[2][kw][ch] = 0.5f * ((g0 + g2) - g1);
-      G[3][kw][ch] = g2;
-    }
-  // M = channel (A = the weights G), N = position (B = the transformed fragments): a lane ends up with channels 16 nt + 4 kk .. + 3
-  // of ONE position -- 16 contiguous bytes of the chunked output (round 4, as in c3d2_conv21h_kernel; bit-identical)
-  f32x4 b4, sl4;
+  for (int t = 0; t < 9; ++t) {
+    W[t][0] = p.wblk[((nt * 9 + t) * 2) * 64 + lane];
+    W[t][1] = p.wblk[((nt * 9 + t) * 2 + 1) * 64 + lane];
+  }
+  f32x4 b4, sl4;   // channels 16 nt + 4 kk .. + 3 of ONE position
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     b4[r] = p.bias[16 * nt + 4 * kk + r];
     sl4[r] = p.slope[16 * nt + 4 * kk + r];
   }
-  // B column of this lane: position m = i -> (row hl = m / 5, column w' = m % 5); m = 15 is a dummy (reads position 14)
-  const int mi = i < 15 ? i : 14;
-  const float* const a0 = reg + C31_PIXF * ((mi / 5) * 7 + mi % 5) + 4 * kk;
   const int n_items = p.n_utt * 5;
   __shared__ int q_next;   // dynamic work items: see c3d2_conv21h_kernel (three workgroups share a CU here)
   int item = blockIdx.x;
@@ -854,83 +776,73 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31w_kernel(const Conv31Params
     unsigned q_ticket = 0;
     if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
     const int u = item / 5, rb = item - u * 5;
-    // stage [12 d][3 rows][7 w][32 c]: per depth 672 contiguous floats = 168 sixteen-byte pieces; 2 016 in all, eight
-    // per thread, four in flight at a time (168 VGPRs at three workgroups per CU)
+    // stage + split [12 d][3 rows][7 w][32 c]: per depth 672 contiguous floats = 168 sixteen-byte pieces; 2 016 in all, eight per
+    // thread.  piece e = t + 256 k = channels 4 (e & 7) .. + 3 of pixel e >> 3 (168 d is a multiple of 8: the pixel index has no d
+    // in it and is linear in k); the source is 4 e + 2 688 d floats, and for a compile-time k the depth d = e / 168 is a constant
+    // plus at most two comparisons of t with the window's boundaries
     const float* src = p.in + ((int64_t)u * 12 * 15 + 3 * rb) * (7 * 32);
-    // piece e = t + 256 k of thread t.  168 d is a multiple of 8, so the LDS address 36 (21 d + (r >> 3)) + 4 (r & 7) with
-    // r = e - 168 d is 36 (e >> 3) + 4 (e & 7): no d in it, linear in k.  The source is 4 e + 2 688 d floats, and for a
-    // compile-time k the depth d = e / 168 is a constant plus at most two comparisons of t with the window's boundaries.
     {
       int tl = threadIdx.x;
       asm volatile("" : "+v"(tl));   // (keeps this arithmetic inside the item loop)
-      float* const a0s = reg + C31_PIXF * (tl >> 3) + 4 * (tl & 7);
+      const int c4 = tl & 7;
+      unsigned* const a0s = reg + 4 * ((c4 >> 1) * C31H_PLANE + (tl >> 3)) + 2 * (c4 & 1);
       const float* const g0 = src + 4 * tl;
       constexpr int DSTEP = 15 * 7 * 32 - 4 * 168;   // floats the source gains per depth on top of 4 e
+      f32x4 sv[8];
 #pragma unroll
-      for (int r0 = 0; r0 < 8; r0 += 4) {
-        f32x4 sv[4];
+      for (int k = 0; k < 8; ++k) {
+        const int d_lo = (256 * k) / 168, c1 = 168 * (d_lo + 1) - 256 * k, c2 = c1 + 168;   // t >= c1 (c2): one (two) depths on
+        const float* g = g0 + 1024 * k + DSTEP * d_lo;
+        if (c1 < 256) g = tl >= c1 ? g + DSTEP : g;
+        if (c2 < 256) g = tl >= c2 ? g + DSTEP : g;
+        if (256 * k + 255 < 2016 || tl < 2016 - 256 * k) sv[k] = *reinterpret_cast<const f32x4*>(g);
+      }
 #pragma unroll
-        for (int k = r0; k < r0 + 4; ++k) {
-          const int d_lo = (256 * k) / 168, c1 = 168 * (d_lo + 1) - 256 * k, c2 = c1 + 168;   // t >= c1 (c2): one (two) depths on
-          const float* g = g0 + 1024 * k + DSTEP * d_lo;
-          if (c1 < 256) g = tl >= c1 ? g + DSTEP : g;
-          if (c2 < 256) g = tl >= c2 ? g + DSTEP : g;
-          if (256 * k + 255 < 2016 || tl < 2016 - 256 * k) sv[k - r0] = *reinterpret_cast<const f32x4*>(g);
+      for (int k = 0; k < 8; ++k) {
+        unsigned h0, l0, h1, l1;
+        split2(__builtin_shufflevector(sv[k], sv[k], 0, 1), h0, l0);
+        split2(__builtin_shufflevector(sv[k], sv[k], 2, 3), h1, l1);
+        if (256 * k + 255 < 2016 || tl < 2016 - 256 * k) {
+          *reinterpret_cast<u32x2*>(a0s + 4 * 32 * k) = (u32x2){h0, h1};
+          *reinterpret_cast<u32x2*>(a0s + 4 * 32 * k + 4 * 4 * C31H_PLANE) = (u32x2){l0, l1};
         }
-#pragma unroll
-        for (int k = r0; k < r0 + 4; ++k)
-          if (256 * k + 255 < 2016 || tl < 2016 - 256 * k) *reinterpret_cast<f32x4*>(a0s + 32 * C31_PIXF * k) = sv[k - r0];
       }
     }
     if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + (int)gridDim.x : item + (int)gridDim.x;
     __syncthreads();
     const int item_next = q_next;
-    // the first pair's first fragments; every later pair's are read under the previous pair's last 16 MFMAs
-    f32x4 x[4];
-#pragma unroll
-    for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(a0 + C31_PLANE * dd);
 #pragma unroll 1
-    for (int P = 0; P < 5; ++P) {
-      const float* ap = a0 + 2 * C31_PLANE * P;
-      f32x4 acc[4];
+    for (int t = 0; t < (C31H_POS + 15) / 16; ++t) {
+      const int P = min(16 * t + i, C31H_POS - 1);
+      const int dq = (P * 4370) >> 16, r15 = P - 15 * dq;                       // P / 15 for P < 150
+      const int row = (r15 * 13108) >> 16, col = r15 - 5 * row;                 // r15 / 5 for r15 < 15
+      // input pixel (dq + kd, row, col + kw), channels 8 kk .. + 7: slot (dq * 3 + row) * 7 + col + 21 kd + kw of plane kk [l: + 4]
+      const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * (kk * C31H_PLANE + (dq * 3 + row) * 7 + col);
+      auto rd = [&](int tap, int piece) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(a2 + 16 * (21 * (tap / 3) + tap % 3) + 16 * 4 * C31H_PLANE * piece);
+      };
+      f32x4 acc = b4;
+      u32x4 bh[3], bl[3];
+      bh[0] = rd(0, 0);
+      bl[0] = rd(0, 1);
+      bh[1] = rd(1, 0);
+      bl[1] = rd(1, 1);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = k == 1 ? b4 : (f32x4){0.f, 0.f, 0.f, 0.f};
-      f32x2 t[4][2];
-#pragma unroll
-      for (int st = 0; st < 6; ++st) {   // step = (column tap kw, 16-channel chunk)
-        const int kw = st >> 1, ch = st & 1;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) wino_input_pair(x, hf, t);
-        __builtin_amdgcn_sched_barrier(0);
-        if (st + 1 < 6) {
-          const int off = C31_PIXF * ((st + 1) >> 1) + 16 * ((st + 1) & 1);
-#pragma unroll
-          for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + C31_PLANE * dd + off);
-        } else if (P + 1 < 5) {
-#pragma unroll
-          for (int dd = 0; dd < 4; ++dd) x[dd] = *reinterpret_cast<const f32x4*>(ap + 2 * C31_PLANE + C31_PLANE * dd);
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 2 < 9) {
+          bh[(tap + 2) % 3] = rd(tap + 2, 0);
+          bl[(tap + 2) % 3] = rd(tap + 2, 1);
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[k][kw][ch][e], t[k][e >> 1][e & 1], acc[k], 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[tap][0]), __builtin_bit_cast(f16x8, bh[tap % 3]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[tap][0]), __builtin_bit_cast(f16x8, bl[tap % 3]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[tap][1]), __builtin_bit_cast(f16x8, bh[tap % 3]), acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // rows 4 kk + r = channel 16 nt + 4 kk + r; column i = position m -> (row 3 rb + m / 5, column m % 5); depths 2 P, 2 P + 1.
-      // Chunked, column-major output [d][chunk = 2 nt + (kk >> 1)][w][h][8]: the lane's position offset (m % 5) * 15 + m / 5 is a
-      // per-lane constant (the M = position order needed a byte table per store)
-      float* const o = p.out + (((int64_t)u * 10 + 2 * P) * 8 + 2 * nt) * (5 * 15 * 8);   // wave-uniform
-      const int olane = (kk >> 1) * (5 * 15 * 8) + 4 * (kk & 1) + ((mi % 5) * 15 + mi / 5 + 3 * rb) * 8;
-      constexpr int ostep = 8 * 5 * 15 * 8;   // one output depth further
-      f32x2 s0[2], s1[2];
-      wino_output(acc, s0, s1);
-      f32x4 y0, y1;
-      prelu_pairs<SLOPE01>(s0, s1, sl4, y0, y1);
-      if (i < 15) {
-        *reinterpret_cast<f32x4*>(o + olane) = y0;
-        *reinterpret_cast<f32x4*>(o + ostep + olane) = y1;
+      // chunked, column-major output [d][chunk = 2 nt + (kk >> 1)][w][h][8]: the lane's four channels are 16 contiguous bytes
+      if (16 * t + i < C31H_POS) {
+        float* const o = p.out + ((((int64_t)u * 10 + dq) * 8 + 2 * nt + (kk >> 1)) * 5 + col) * (15 * 8) + (3 * rb + row) * 8 + 4 * (kk & 1);
+        *reinterpret_cast<f32x4*>(o) = prelu4<SLOPE01>(acc, sl4);
       }
     }
     __syncthreads();
@@ -994,22 +906,22 @@ extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
   return SVK_OK;
 }
 
-extern "C" int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
+extern "C" int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_wblk, const float* d_bias,
                                const float* d_slope, int32_t flags, float* d_out) {
   if (!ctx) return SVK_ERR_BAD_ARG;
   SVK_REQUIRE(ctx, n_utt >= 0, "n_utt negative");
   SVK_REQUIRE(ctx, (flags & ~2) == 0, "flags: only bit 1 (slopes in [0, 1]) is defined");
   if (n_utt == 0) return SVK_OK;
-  SVK_REQUIRE(ctx, d_in && d_wfrag && d_bias && d_slope && d_out, "NULL buffer");
-  SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_wfrag)) & 15) == 0,
+  SVK_REQUIRE(ctx, d_in && d_wblk && d_bias && d_slope && d_out, "NULL buffer");
+  SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_wblk) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0,
               "buffers must be 16-byte aligned");
   SVK_REQUIRE(ctx, (int64_t)n_utt * 5 < ((int64_t)1 << 31), "too many cubes for one launch");
   const bool static_items31 = getenv("SVK_C3D2_STATIC_ITEMS") != nullptr;
   unsigned* const queue31 = static_items31 ? nullptr : reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 80);
   if (queue31) SVK_HIP(ctx, hipMemsetAsync(queue31, 0, 4, ctx->stream));
-  Conv31Params p{d_in, reinterpret_cast<const f32x4*>(d_wfrag), d_bias, d_slope, d_out, n_utt, queue31};
-  void (*kern)(const Conv31Params) = (flags & 2) ? c3d2_conv31w_kernel<true> : c3d2_conv31w_kernel<false>;
-  const size_t lds = sizeof(float) * (size_t)C31_LDS_FLOATS;
+  Conv31Params p{d_in, reinterpret_cast<const u32x4*>(d_wblk), d_bias, d_slope, d_out, n_utt, queue31};
+  void (*kern)(const Conv31Params) = (flags & 2) ? c3d2_conv31h_kernel<true> : c3d2_conv31h_kernel<false>;
+  const size_t lds = sizeof(unsigned) * (size_t)C31H_LDS_WORDS;
   if (lds > (size_t)ctx->lds_per_cu)
     return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_conv31 needs %zu bytes of LDS per workgroup (device: %d)", lds,
                     ctx->lds_per_cu);

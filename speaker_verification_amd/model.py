@@ -294,8 +294,8 @@ class FusedEmbedder:
 
     def conv31_tables(self):
         """Operand fragments of `svk_c3d2_conv31` (conv3_1: 32 -> 64, k(3,1,3), stride 1, no pool), BN folded, or None
-        when the layer differs:  wfrag [4 nt][9][2][64][4]: lane (co = 16 nt + (l & 15), kk = l >> 4):
-        W[co][16 chunk + 4 kk + e][kd][kw], tap 3 kd + kw."""
+        when the layer differs:  wblk [4 nt][9][2: H | L][64][8 halves]: lane (co = 16 nt + (l & 15), kk = l >> 4):
+        W[co][8 kk + e][kd][kw], tap 3 kd + kw (two-piece f16 products, see stage1_tables)."""
         hit = getattr(self, "_conv31", False)
         if hit is not False:
             return hit
@@ -309,13 +309,15 @@ class FusedEmbedder:
         lane = torch.arange(64, device=dev)
         ch, kq = lane & 15, lane >> 4
         a = w.contiguous()[:, :, :, 0, :]                                    # [co][ci][kd][kw]
-        frag = torch.empty((4, 9, 2, 64, 4), dtype=torch.float32, device=dev)
+        ci = 8 * kq[:, None] + torch.arange(8, device=dev)[None, :]          # K = 32 = the 32 input channels of one tap
+        frag = torch.empty((4, 9, 2, 64, 8), dtype=torch.float16, device=dev)
         for nt in range(4):
             for kd in range(3):
                 for kw in range(3):
-                    for chunk in range(2):
-                        for e in range(4):
-                            frag[nt, 3 * kd + kw, chunk, :, e] = a[16 * nt + ch, 16 * chunk + 4 * kq + e, kd, kw]
+                    wv = a[(16 * nt + ch)[:, None], ci, kd, kw]
+                    h = wv.to(torch.float16)
+                    frag[nt, 3 * kd + kw, 0] = h
+                    frag[nt, 3 * kd + kw, 1] = (wv - h.to(torch.float32)).to(torch.float16)
         slope = sl.expand(64).contiguous() if sl.numel() == 1 else sl.contiguous()
         self._conv31 = (frag.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
         return self._conv31
