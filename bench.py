@@ -7,7 +7,7 @@ One STEP = one pass of the whole path over BASELINE.json's corpus, 148 642 synth
 sharded over the N ranks (rank r owns the contiguous range of ceil(148 642 / N) clips; STRONG scaling:
 the total is fixed), PCM resident in HBM:
     int16 PCM -> energy VAD (an index of the voiced frames) -> fused pre-emphasis + log-mel(40) front end reading through it
-    -> CMVN -> 20x80x40 cube (never materialised) -> C3D2 embedding (f32 MFMA, seven libsvk kernels: svk_c3d2_stage1 / stage2 /
+    -> CMVN -> 20x80x40 cube (never materialised) -> C3D2 embedding (seven libsvk MFMA kernels: svk_c3d2_stage1 / stage2 /
     conv31 / conv32t / conv41 / conv42 / fc5) -> all-gather of the [clips,128] shards (RCCL) -> 4 874 x 40 cosine score matrix (MFMA).
 value = 148 642 clips x steps / max-over-ranks time.  Nothing in the step is a framework operator: torch supplies
 device memory, streams, events and torch.distributed.  Weights: the committed checkpoint trained on synthetic speakers that

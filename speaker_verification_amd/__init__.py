@@ -5,7 +5,7 @@ Drop-in call surface of MingmChen/Speaker_Verification for ONE hot path
 `model.C3D2`, `siamese.Siamese`, `evaluation`.  Compute runs in hand-written
 gfx950 HIP kernels behind the C-ABI of `include/svk.h` (`libsvk.so`, loaded by
 `_lib.py` through ctypes), the whole C3D2 inference forward included (seven
-f32-MFMA kernels, reached through `model.C3D2.forward` itself in eval mode);
+MFMA kernels, reached through `model.C3D2.forward` itself in eval mode);
 PyTorch-ROCm supplies device memory, streams, `torch.distributed` and the
 training forward / backward.
 
