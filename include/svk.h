@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 109 /* 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 / svk_c3d2_conv31 run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
+#define SVK_VERSION 109 /* 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 / svk_c3d2_conv31 / svk_c3d2_conv32t run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -315,11 +315,13 @@ int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* 
  *                    added in a fixed order: bitwise repeatable);  d_out [n_utt][128]                                  */
 int svk_c3d2_conv41(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);
-/* conv3_2 (64 -> 64, kernel (3,7,1)) -> BN -> PReLU, model.py:129-131 + :162-164, in the shape of the last block:
+/* conv3_2 (64 -> 64, kernel (3,7,1)) -> BN -> PReLU, model.py:129-131 + :162-164, one kernel on v_mfma_f32_16x16x32_f16
+ * through two-piece products like svk_c3d2_stage1 (direct form; per (cube, column) work items; csrc/c3d2.hip):
  *   d_in    [n_utt][10][8][5][15][8] = svk_c3d2_conv31's output
- *   d_wfrag [4 nt][8 chunks][7 kh][4 k][64][2] (host-transformed G, as for svk_c3d2_conv41);  d_bias / d_slope [64]
+ *   d_wblk  [4 nt][2 kb][21 taps][2][64][8 halves]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: W32[co][ci = 32 kb + 8 kk + e][kd][kh],
+ *           tap 7 kd + kh (BatchNorm folded); block 0 = H = f16(w), block 1 = L = f16(w - H);  d_bias / d_slope [64]
  *   d_out   [n_utt][8][8][45][8]     = what svk_c3d2_conv41 takes                                                       */
-int svk_c3d2_conv32t(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
+int svk_c3d2_conv32t(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_wblk, const float* d_bias,
                      const float* d_slope, int32_t flags, float* d_out);
 int svk_c3d2_conv42(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);

@@ -737,8 +737,9 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22h_kernel(const Conv22hParam
 // x {h, l}) of 16-byte slots, slot = pixel (d * 3 + row) * 7 + col (32 KB; three workgroups per CU).  The item's 10 d x 3 rows x
 // 5 columns = 150 positions are 9.4 tiles of 16 consecutive positions; wave = N tile (16 of the 64 output channels: 18 weight
 // blocks = 72 VGPRs), every wave walks all ten tiles.  Output chunked and column-major, 16-byte stores. ----
-constexpr int C31H_PLANE = 12 * 3 * 7;                        // 252 slots per plane
-constexpr int C31H_LDS_WORDS = 4 * 8 * C31H_PLANE;            // 32 256 bytes
+constexpr int C31H_PLANE = 256;                               // 12 * 3 * 7 = 252 slots per plane, padded to a multiple of 16: the lanes of an LDS
+                                                              // lane group sit in different planes (kk) and must not land on each other's slots
+constexpr int C31H_LDS_WORDS = 4 * 8 * C31H_PLANE;            // 32 768 bytes
 constexpr int C31H_POS = 10 * 3 * 5;                          // 150 positions per item
 
 struct Conv31Params {
@@ -850,6 +851,145 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31h_kernel(const Conv31Params
   }
 }
 
+// ---- conv3_2 (64 -> 64, kernel (3,7,1)) + BN + PReLU (model.py:129-131, :162-164) through two-piece f16 products, direct form:
+// 21 taps x two K = 32 blocks (channels 0-31 | 32-63) x three MFMAs.  No taps along w, and conv3_1 writes its output chunked and
+// COLUMN-major, so item = (cube, column): 10 d x 15 h x 64 c = eighty 480-byte runs, split into (h, l) while staged: sixteen planes
+// (eight channel chunks x {h, l}) of 16-byte slots, slot = d * 15 + h (38 KB).  Outputs 8 d x 9 h = 72 positions = 4.5 tiles.  The
+// weight blocks of an N tile and ONE K block are 168 VGPRs: wave = (N tile nt, K block kb), eight waves; the two waves of an N tile
+// swap partial sums through LDS (kb 0 finishes tiles 0 - 2, kb 1 tiles 3 - 4).  The next item's runs are loaded into registers in
+// front of the tiles and parked behind them: one workgroup per CU, its memory latency under its own matrix work.
+// (As an instance of the f32 batch-GEMM template of c3d2_tail.hip, Winograd F(2,3) along depth: 1.34 - 1.62 ms per 4 018 cubes.) ----
+constexpr int C32H_PLANE = 160;                               // 10 * 15 = 150 slots per plane, padded to a multiple of 16 (see C31H_PLANE)
+constexpr int C32H_LDS_WORDS = 4 * 16 * C32H_PLANE;           // 40 960 bytes
+constexpr int C32H_XCH_FLOATS = 8 * 5 * 64 * 4;               // [wave = nt + 4 kb][tile][lane] f32x4: every wave's partial sums
+constexpr int C32H_POS = 8 * 9;                               // 72 positions per item
+
+struct Conv32hParams {
+  const float* in;      // [n][10][8 chunks][5 w][15 h][8]
+  const u32x4* wblk;    // [4 nt][2 kb][21 taps][2][64]: lane (co = 16 nt + (l & 15), kk): e: W[co][32 kb + 8 kk + e][kd][kh], tap = 7 kd + kh; H | L
+  const float* bias;    // [64]
+  const float* slope;   // [64]
+  float* out;           // [n][8 d][8 chunks][45 = 9 h x 5 w][8]
+  int32_t n_utt;
+  unsigned* queue;
+};
+
+template <bool SLOPE01>
+__global__ __launch_bounds__(512) void c3d2_conv32h_kernel(const Conv32hParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_c32[];
+  unsigned* const reg = reinterpret_cast<unsigned*>(smem_c32);
+  float* const xch = smem_c32 + C32H_LDS_WORDS;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  const int nt = wave & 3, kb = wave >> 2;
+  u32x4 W[21][2];
+#pragma unroll
+  for (int t = 0; t < 21; ++t) {
+    W[t][0] = p.wblk[(((nt * 2 + kb) * 21 + t) * 2) * 64 + lane];
+    W[t][1] = p.wblk[(((nt * 2 + kb) * 21 + t) * 2 + 1) * 64 + lane];
+  }
+  f32x4 b4, sl4;   // channels 16 nt + 4 kk .. + 3 of ONE position (the bias rides in K block 0's accumulators)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    b4[r] = kb == 0 ? p.bias[16 * nt + 4 * kk + r] : 0.f;
+    sl4[r] = p.slope[16 * nt + 4 * kk + r];
+  }
+  const int n_items = p.n_utt * 5;
+  __shared__ int q_next;
+  // piece e = t + 512 k (five per thread, 2 400 in all): run e / 30 = d * 8 + chunk, h = (e % 30) / 2, channels 4 (e & 1) .. + 3 of the chunk
+  f32x4 sv[5];
+  auto load_item = [&](int it) {
+    const int u = it / 5, w = it - 5 * u;
+    const float* const src = p.in + (int64_t)u * (10 * 8 * 5 * 120) + w * 120;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int e = (int)threadIdx.x + 512 * k;
+      const int run = (e * 2185) >> 16, r = e - 30 * run;       // e / 30 for e < 2 400
+      if (k < 4 || threadIdx.x < 2400 - 4 * 512) sv[k] = *reinterpret_cast<const f32x4*>(src + run * 600 + 4 * r);
+    }
+  };
+  auto park_item = [&]() {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int e = (int)threadIdx.x + 512 * k;
+      const int run = (e * 2185) >> 16, r = e - 30 * run;
+      const int d = run >> 3, chunk = run & 7;
+      unsigned* const dst = reg + 4 * (chunk * C32H_PLANE + d * 15 + (r >> 1)) + 2 * (r & 1);
+      unsigned h0, l0, h1, l1;
+      split2(__builtin_shufflevector(sv[k], sv[k], 0, 1), h0, l0);
+      split2(__builtin_shufflevector(sv[k], sv[k], 2, 3), h1, l1);
+      if (k < 4 || threadIdx.x < 2400 - 4 * 512) {
+        *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+        *reinterpret_cast<u32x2*>(dst + 4 * 8 * C32H_PLANE) = (u32x2){l0, l1};
+      }
+    }
+  };
+  // items: the first two of a workgroup at a fixed stride, every later one drawn from the device-wide counter ONE item ahead (the
+  // next item's runs are fetched during this item; its ticket's round trip runs under this item's tiles)
+  int item = blockIdx.x, item_next = item + (int)gridDim.x;
+  if (item < n_items) {
+    load_item(item);
+    park_item();
+  }
+  __syncthreads();
+  while (item < n_items) {
+    unsigned q_ticket = 0;
+    if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
+    const int u = item / 5, w = item - 5 * u;
+    if (item_next < n_items) load_item(item_next);
+#pragma unroll 1
+    for (int t = 0; t < 5; ++t) {
+      const int P = min(16 * t + i, C32H_POS - 1);
+      const int dq = (P * 7282) >> 16, row = P - 9 * dq;                        // P / 9 for P < 72
+      // input pixel (dq + kd, row + kh), channels 32 kb + 8 kk .. + 7: slot (dq + kd) * 15 + row + kh of plane 4 kb + kk [l: + 8]
+      const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * ((4 * kb + kk) * C32H_PLANE + dq * 15 + row);
+      auto rd = [&](int tap, int piece) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(a2 + 16 * (15 * (tap / 7) + tap % 7) + 16 * 8 * C32H_PLANE * piece);
+      };
+      f32x4 a = b4;
+      u32x4 bh[2], bl[2];   // (one tap ahead: a second set ahead is eight registers more)
+      bh[0] = rd(0, 0);
+      bl[0] = rd(0, 1);
+#pragma unroll
+      for (int tap = 0; tap < 21; ++tap) {
+        if (tap + 1 < 21) {
+          bh[(tap + 1) & 1] = rd(tap + 1, 0);
+          bl[(tap + 1) & 1] = rd(tap + 1, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[tap][0]), __builtin_bit_cast(f16x8, bh[tap & 1]), a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[tap][0]), __builtin_bit_cast(f16x8, bl[tap & 1]), a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[tap][1]), __builtin_bit_cast(f16x8, bh[tap & 1]), a, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // partial sums over this wave's K block -> LDS (kept in registers for the tiles a wave finishes they cost 12 VGPRs this kernel
+      // does not have: the 168 weight registers and the 20 of the next item's runs leave room for one accumulator)
+      *reinterpret_cast<f32x4*>(xch + ((wave * 5 + t) * 64 + lane) * 4) = a;
+    }
+    __syncthreads();   // both K blocks' partial sums are in LDS; nobody reads the planes any more
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const bool mine = kb == 0 ? t < 3 : t >= 3;   // wave-uniform: K block 0's wave finishes tiles 0 - 2, K block 1's tiles 3 - 4
+      if (mine) {
+        const int P = 16 * t + i;
+        const int Pc = min(P, C32H_POS - 1);
+        const int dq = (Pc * 7282) >> 16, row = Pc - 9 * dq;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xch + ((nt * 5 + t) * 64 + lane) * 4) +
+                        *reinterpret_cast<const f32x4*>(xch + (((nt + 4) * 5 + t) * 64 + lane) * 4);
+        if (P < C32H_POS) {
+          float* const o = p.out + ((((int64_t)u * 8 + dq) * 8 + 2 * nt + (kk >> 1)) * 45 + row * 5 + w) * 8 + 4 * (kk & 1);
+          *reinterpret_cast<f32x4*>(o) = prelu4<SLOPE01>(v, sl4);
+        }
+      }
+    }
+    if (item_next < n_items) park_item();
+    if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + 2 * (int)gridDim.x : item_next + (int)gridDim.x;
+    __syncthreads();   // the next item's planes are written; the exchange buffer is free
+    item = item_next;
+    item_next = q_next;
+  }
+}
+
 }  // namespace
 
 extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_w21blk,
@@ -933,6 +1073,30 @@ extern "C" int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, c
     per_cu = 2;
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, (int64_t)per_cu * ctx->num_cu)), dim3(256), lds, ctx->stream,
                      p);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+extern "C" int svk_c3d2_conv32t(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_wblk, const float* d_bias,
+                                const float* d_slope, int32_t flags, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_utt >= 0, "n_utt negative");
+  SVK_REQUIRE(ctx, (flags & ~2) == 0, "flags: only bit 1 (slopes in [0, 1]) is defined");
+  if (n_utt == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_in && d_wblk && d_bias && d_slope && d_out, "NULL buffer");
+  SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_wblk) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0,
+              "buffers must be 16-byte aligned");
+  SVK_REQUIRE(ctx, (int64_t)n_utt * 5 + 2 * (int64_t)ctx->num_cu < ((int64_t)1 << 31), "too many cubes for one launch");
+  unsigned* const queue = getenv("SVK_C3D2_STATIC_ITEMS") ? nullptr : reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 96);
+  if (queue) SVK_HIP(ctx, hipMemsetAsync(queue, 0, 4, ctx->stream));
+  Conv32hParams p{d_in, reinterpret_cast<const u32x4*>(d_wblk), d_bias, d_slope, d_out, n_utt, queue};
+  void (*kern)(const Conv32hParams) = (flags & 2) ? c3d2_conv32h_kernel<true> : c3d2_conv32h_kernel<false>;
+  const size_t lds = sizeof(float) * (size_t)(C32H_LDS_WORDS + C32H_XCH_FLOATS);
+  if (lds + 64 > (size_t)ctx->lds_per_cu)
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_conv32t needs %zu bytes of LDS per workgroup (device: %d)", lds, ctx->lds_per_cu);
+  SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t items = (int64_t)n_utt * 5;
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, ctx->num_cu)), dim3(512), lds, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }

@@ -47,7 +47,7 @@ __device__ __forceinline__ float prelu_t(float v, float slope) {
 
 constexpr int GROUP = 16;   // cubes per work item = rows of an M tile
 
-// conv4_1: input [n][8 d][8 chunks][45 = 9 h x 5 w][8] (svk_c3d2_conv32 with the chunked-output flag), output
+// conv4_1: input [n][8 d][8 chunks][45 = 9 h x 5 w][8] (svk_c3d2_conv32t), output
 // [n][6 d][16 chunks][27 = 9 h x 3 w][8].  Item = (group, pair P of 3, row block rb of 3): rows 3 rb .. 3 rb + 2, taps along w.
 struct Conv41 {
   static constexpr int NT = 9;                         // M tiles (output positions) per work item
@@ -74,25 +74,7 @@ struct Conv42 {
   __device__ static int in_pix_start(int) { return 0; }
   __device__ static int out_pix(int t, int) { return t; }
 };
-// conv3_2 (64 -> 64, kernel (3,7,1); model.py:129-131, :162-164) in the same shape: input = svk_c3d2_conv31's output in its
-// chunked, column-major form [n][10 d][8 chunks][5 w][15 h][8] (flags bit 3 there), output [n][8 d][8 chunks][45 = 9 h x 5 w][8]
-// = what conv4_1 stages from.  Item = (group, pair P of 4, column w of 5): 9 output rows = 9 tiles, taps along h = a shift of one
-// staged pixel.  N = 64: four waves per workgroup, TWO workgroups per CU (66 KB of LDS each).  Against the round-2 kernel
-// (c3d2_conv32w_kernel: transform per fragment read, 45 positions padded to 48, 41 % LDS bank conflicts): no VALU in the
-// loop, no padding.
-struct Conv32T {
-  static constexpr int NT = 9;
-  static constexpr int TAPS = 7, TAP_PIX = 1;
-  static constexpr int D_IN = 10, NCHUNK = 8, PIX_IN = 75, PIXN = 15;
-  static constexpr int D_OUT = 8, PIX_OUT = 45;
-  static constexpr int SC = 1;
-  static constexpr int PAIRS = 4, BLOCKS = 5;
-  static constexpr int NWAVES = 4;
-  __device__ static constexpr int pix0(int p) { return p; }
-  __device__ static int in_pix_start(int blk) { return 15 * blk; }
-  __device__ static int out_pix(int t, int blk) { return 5 * t + blk; }
-};
-
+// (conv3_2 ran as a third instance of this template in round 3 and the first half of round 4; it is c3d2_conv32h_kernel in c3d2.hip now.)
 template <class L>
 struct TailGeom {
   static constexpr int PLANE = L::PIXN * 8;                                   // floats per t plane of one cube and chunk
@@ -513,11 +495,6 @@ extern "C" int svk_c3d2_fc5(svk_ctx* ctx, const float* d_in, int32_t n_utt, cons
                      0, ctx->stream, d_work, d_bias, d_out, n_vec, (int64_t)n_utt * 128);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
-}
-
-extern "C" int svk_c3d2_conv32t(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
-                                const float* d_slope, int32_t flags, float* d_out) {
-  return launch_tail<Conv32T>(ctx, "svk_c3d2_conv32t", d_in, n_utt, d_wfrag, d_bias, d_slope, flags, d_out);
 }
 
 extern "C" int svk_c3d2_conv41(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,

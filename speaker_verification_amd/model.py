@@ -354,11 +354,36 @@ class FusedEmbedder:
         return (frag.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
 
     def conv32t_tables(self):
-        """`svk_c3d2_conv32t` (conv3_2: 64 -> 64, k(3,7,1)) in the last block's operand format (host-transformed)."""
+        """`svk_c3d2_conv32t` (conv3_2: 64 -> 64, k(3,7,1)), two-piece f16 products (see stage1_tables):
+        wblk [4 nt][2 kb][21 taps][2: H | L][64 lanes][8 halves], element e = W[co = 16 nt + (l & 15)][32 kb + 8 kk + e][kd][kh],
+        tap 7 kd + kh; bias, slope [64].  None when the layer differs."""
         hit = getattr(self, "_conv32t", False)
-        if hit is False:
-            hit = self._conv32t = self._tail_conv_tables(5, (64, 64, 3, 7, 1), "h")
-        return hit
+        if hit is not False:
+            return hit
+        self._conv32t = None
+        if len(self.stages) < 6:
+            return None
+        w, b, sl, st, pool, _ = self.stages[5]
+        if tuple(w.shape) != (64, 64, 3, 7, 1) or tuple(st) != (1, 1, 1) or pool:
+            return None
+        dev = w.device
+        lane = torch.arange(64, device=dev)
+        ch, kq = lane & 15, lane >> 4
+        a = w.contiguous()[:, :, :, :, 0]                                    # [co][ci][kd][kh]
+        e8 = torch.arange(8, device=dev)[None, :]
+        blk = torch.empty((4, 2, 21, 2, 64, 8), dtype=torch.float16, device=dev)
+        for nt in range(4):
+            for kb in range(2):
+                ci = 32 * kb + 8 * kq[:, None] + e8
+                for kd in range(3):
+                    for kh in range(7):
+                        wv = a[(16 * nt + ch)[:, None], ci, kd, kh]
+                        h = wv.to(torch.float16)
+                        blk[nt, kb, 7 * kd + kh, 0] = h
+                        blk[nt, kb, 7 * kd + kh, 1] = (wv - h.to(torch.float32)).to(torch.float16)
+        slope = sl.expand(64).contiguous() if sl.numel() == 1 else sl.contiguous()
+        self._conv32t = (blk.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
+        return self._conv32t
 
     def conv41_tables(self):
         """`svk_c3d2_conv41` (conv4_1: 64 -> 128, k(3,1,3), stride 1, no pool), BN folded, depth-transformed by the host."""
