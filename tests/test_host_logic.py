@@ -223,7 +223,7 @@ def test_tail_operand_tables_against_naive_indexing():
     m.load_state_dict(perturb_inference_state(m.state_dict(), 4))
     e = m.fused_inference()
     rnd = random.Random(1)
-    for name, li, axis in (("conv41", 6, "w"), ("conv42", 7, "h"), ("conv32t", 5, "h")):
+    for name, li, axis in (("conv41", 6, "w"), ("conv42", 7, "h")):
         frag = getattr(e, name + "_tables")()[0]
         w = e.stages[li][0]
         g0, g1, g2 = w[:, :, 0], w[:, :, 1], w[:, :, 2]
@@ -241,6 +241,60 @@ def test_tail_operand_tables_against_naive_indexing():
         K = 1152 * d + 16 * st + 4 * (lane >> 4) + el               # ((d * 16 + chunk) * 9 + pixel) * 8 + c8
         c8, pix, chunk = K % 8, (K // 8) % 9, (K // 72) % 16
         assert frag[d, nt, st, lane, el] == e.fc_w[16 * nt + (lane & 15), (8 * chunk + c8) * 36 + d * 9 + pix]
+
+
+def test_half_pair_weight_blocks_against_naive_indexing():
+    """The host tables of the kernels that multiply through two-piece f16 products (svk_c3d2_stage1 / stage2 / conv31 / conv32t;
+    include/svk.h): H = f16(w), L = f16(w - H) in the lane order of v_mfma_f32_16x16x32_f16's A operand -- element by element
+    against the BN-folded weights, and H + L back to the weight within 2^-21 (or the last bit of an f16 subnormal)."""
+    import random
+    import torch
+    from speaker_verification_amd.model import perturb_inference_state, seeded_model
+    m = seeded_model(5, 8)
+    m.load_state_dict(perturb_inference_state(m.state_dict(), 6))
+    e = m.fused_inference()
+    rnd = random.Random(2)
+
+    def check(blk, want):          # blk [2: H | L] halves, want: the f32 weight the pair stands for
+        h, l = blk[0].float(), blk[1].float()
+        assert h == float(torch.tensor(want).to(torch.float16))
+        assert abs((h + l) - want) <= max(2.0 ** -21 * abs(want), 2.0 ** -25)
+
+    w1blk, b1, _, w2blk, b2 = e.stage1_tables()[:5]
+    w1, w2 = e.stages[0][0], e.stages[1][0]
+    assert tuple(w1blk.shape) == (2, 64, 8) and tuple(w2blk.shape) == (14, 2, 64, 8) and w1blk.dtype == torch.float16
+    pairs = [((p // 4, 2 * (p % 4)), (p // 4, 2 * (p % 4) + 1)) for p in range(12)] + [((0, 8), (1, 8)), ((2, 8), None)]
+    for _ in range(400):
+        lane, el = rnd.randrange(64), rnd.randrange(8)
+        co, kk = lane & 15, lane >> 4
+        t = 8 * (kk & 1) + el                                        # conv1_1: tap t = 5 kd + kw, 15 = the zero column
+        want = float(w1[co, 0, t // 5, 0, t % 5]) if t < 15 else 0.0
+        assert float(w1blk[0, lane, el]) == float(torch.tensor(want).to(torch.float16))
+        if kk >= 2:
+            assert float(w1blk[1, lane, el]) == 0.0                  # the L block multiplies the h half of the patch only
+        else:
+            check(w1blk[:, lane, el], want)
+        pr = rnd.randrange(14)
+        tap = pairs[pr][0] if kk < 2 else pairs[pr][1]
+        want = float(w2[co, 8 * (kk & 1) + el, tap[0], tap[1], 0]) if tap is not None else 0.0
+        check(w2blk[pr, :, lane, el], want)
+    w21blk, _, _, w22blk = e.stage2_tables()[:4]
+    w21, w22 = e.stages[2][0], e.stages[3][0]
+    assert tuple(w21blk.shape) == (2, 6, 2, 64, 8) and tuple(w22blk.shape) == (2, 24, 2, 64, 8)
+    w31blk, w32blk = e.conv31_tables()[0], e.conv32t_tables()[0]
+    w31, w32 = e.stages[4][0], e.stages[5][0]
+    assert tuple(w31blk.shape) == (4, 9, 2, 64, 8) and tuple(w32blk.shape) == (4, 2, 21, 2, 64, 8)
+    for _ in range(400):
+        lane, el = rnd.randrange(64), rnd.randrange(8)
+        co, kk = lane & 15, lane >> 4
+        nt, pr = rnd.randrange(2), rnd.randrange(6)                  # conv2_1: pair 2 kd + kw / 2, tap b = kw + 1 for kk >= 2
+        check(w21blk[nt, pr, :, lane, el], float(w21[16 * nt + co, 8 * (kk & 1) + el, pr // 2, 0, 2 * (pr % 2) + (kk >= 2)]))
+        tap = rnd.randrange(24)                                      # conv2_2: one tap per K = 32 block
+        check(w22blk[nt, tap, :, lane, el], float(w22[16 * nt + co, 8 * kk + el, tap // 8, tap % 8, 0]))
+        nt, tap = rnd.randrange(4), rnd.randrange(9)
+        check(w31blk[nt, tap, :, lane, el], float(w31[16 * nt + co, 8 * kk + el, tap // 3, 0, tap % 3]))
+        kb, tap = rnd.randrange(2), rnd.randrange(21)
+        check(w32blk[nt, kb, tap, :, lane, el], float(w32[16 * nt + co, 32 * kb + 8 * kk + el, tap // 7, tap % 7, 0]))
 
 
 def test_upload_groups_of_a_host_arena():
