@@ -74,14 +74,14 @@ F16_MFMA_FLOP = 16384            # v_mfma_f32_16x16x32_f16: 16 x 16 x 32 multipl
 # summaries, SURVEY 8(a)'s direct-form multiply-adds per cube (millions), and the MFMA wave-instructions the kernel issues
 # per cube BY CONSTRUCTION (items x tiles x taps x 4-deep steps) -- replaced at run time by the committed
 # SQ_INSTS_MFMA counter of profiles/rNN_frontend_pmc.json when that file has the kernel (they agree to 1e-4).
-# Blocks 1 - 3 run on the F16 matrix pipe through two-piece products (three f16 products per f32 product): their rows carry
+# conv1_1 .. conv4_1 run on the F16 matrix pipe through two-piece products (three f16 products per f32 product): their rows carry
 # that pipe's FLOP per MFMA and peak; the others the f32 pipe's.
 NETWORK_KERNELS = (
     ("stage1", ("c3d2_stage1h_kernel",), 12.4416 + 143.327232, 36 * (100 * 2 + 36 * 42), F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # 36 items x (100 conv1_1 tiles x 2 + 36 conv1_2 tiles x 14 tap pairs x 3)
     ("stage2", ("c3d2_conv21h_kernel", "c3d2_conv22h_kernel"), 46.44864 + 66.3552, 9 * 53 * 36 + 21 * 8 * 2 * 72, F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # conv2_1: 9 items x 53 tiles x 6 pairs x 3 x 2 N tiles; conv2_2: 21 items x 8 tiles x 2 N tiles x 24 taps x 3
     ("conv3_1", ("c3d2_conv31h_kernel",), 13.824, 5 * 10 * 4 * 27, F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # 5 items x 10 tiles x 4 N tiles x 9 taps x 3
     ("conv3_2", ("c3d2_conv32h_kernel",), 30.96576, 5 * 5 * 4 * 126, F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # 5 items x 5 tiles x 4 N tiles x 21 taps x 2 K blocks x 3
-    ("conv4_1", ("c3d2_tail_kernel<Conv41>",), 11.943936, 7776, MFMA_FLOP, F32_MATRIX_PEAK_TFLOPS),    # 9 items x 4 phases x 24 steps x 18 x 8 waves / 16 cubes
+    ("conv4_1", ("c3d2_conv41h_kernel",), 11.943936, 11 * 8 * 54, F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # 11 tiles x 8 N tiles x 9 taps x 2 K blocks x 3
     ("conv4_2", ("c3d2_tail_kernel<Conv42>",), 12.386304, 8064, MFMA_FLOP, F32_MATRIX_PEAK_TFLOPS),
     ("fc5", ("fc5_kernel",), 0.589824, 576, MFMA_FLOP, F32_MATRIX_PEAK_TFLOPS),                        # 4 K ranges x 72 steps x 16 x 8 waves / 64 cubes
 )
@@ -1087,7 +1087,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             # f32 in, f32 out, f32 accumulation everywhere; the first two blocks' PRODUCTS are three f16 piece products per f32 product
             # (22-bit operands: 1e-6 of the activation scale from the f32 kernel it replaces, parity bars unchanged)
-            "dtype": "f32 (conv1_1 .. conv3_2: two-piece f16 products, f32 accumulation)",
+            "dtype": "f32 (conv1_1 .. conv4_1: two-piece f16 products, f32 accumulation)",
             "data": "synthetic (seeded formant 'voices', 3 s / 16 kHz int16, generated on device); C3D2 weights: %s"
                     % ("seeded random init" if args.random_init else
                        "the committed checkpoint trained on synthetic speakers disjoint from the corpus's (tools/train_synth_checkpoint.py)"),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 109 /* 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 / svk_c3d2_conv31 / svk_c3d2_conv32t run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
+#define SVK_VERSION 110 /* 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 / svk_c3d2_conv31 / svk_c3d2_conv32t run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -296,25 +296,6 @@ int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* 
 int svk_c3d2_conv31(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_wblk, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);
 
-/* The last block, model.py:132-139 (definitions) + :165-170 (forward): conv4_1 (64 -> 128, kernel (3,1,3)) -> BN -> PReLU,
- * conv4_2 (128 -> 128, kernel (3,7,1)) -> BN -> PReLU, flatten, FC5 (4 608 -> 128) -- GEMMs over the BATCH on
- * v_mfma_f32_16x16x4_f32 (csrc/c3d2_tail.hip): an M tile is one output position of 16 cubes, the convolutions run
- * through Winograd's F(2, 3) along depth with the input transform applied once while a chunk is staged into LDS and the
- * weight transform applied by the HOST.  Activations between these kernels are chunked: [cube][depth][channel / 8][pixel][channel % 8].
- *   svk_c3d2_conv41  d_in  [n_utt][8][8][45][8]   = svk_c3d2_conv32t's output
- *                    d_wfrag [8 nt][8 chunks][3 kw][4 k][64][2]: lane (co = 16 nt + (l & 15), kk = l >> 4), e:
- *                            G_k[co][8 chunk + 2 kk + e][kw], G0 = g0, G1 = (g0 + g1 + g2) / 2, G2 = (g0 - g1 + g2) / 2,
- *                            G3 = g2 over the three depth taps g of the BN-folded weights;  d_bias / d_slope [128]
- *                    d_out [n_utt][6][16][27 = 9 h x 3 w][8]
- *   svk_c3d2_conv42  d_in  = that;  d_wfrag [8 nt][16 chunks][7 kh][4 k][64][2] likewise;  d_out [n_utt][4][16][9 = 3 h x 3 w][8]
- *   flags            bit 1: the caller asserts every PReLU slope lies in [0, 1]
- *   svk_c3d2_fc5     d_in  [n_utt][4 608] = svk_c3d2_conv42's output, K index ((d * 16 + chunk) * 9 + pixel) * 8 + channel % 8
- *                    d_wfrag [4 d][8 nt][72][64][4]: lane (j = 16 nt + (l & 15), kk = l >> 4), e: W5[j][column of K index
- *                            1 152 d + 16 step + 4 kk + e] (model.py:168 flattens NCDHW: column = channel * 36 + d * 9 + pixel)
- *                    d_bias [128];  d_work: svk_c3d2_fc5_workspace_floats(n_utt) floats (partial sums of the four K ranges,
- *                    added in a fixed order: bitwise repeatable);  d_out [n_utt][128]                                  */
-int svk_c3d2_conv41(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
-                    const float* d_slope, int32_t flags, float* d_out);
 /* conv3_2 (64 -> 64, kernel (3,7,1)) -> BN -> PReLU, model.py:129-131 + :162-164, one kernel on v_mfma_f32_16x16x32_f16
  * through two-piece products like svk_c3d2_stage1 (direct form; per (cube, column) work items; csrc/c3d2.hip):
  *   d_in    [n_utt][10][8][5][15][8] = svk_c3d2_conv31's output
@@ -323,6 +304,30 @@ int svk_c3d2_conv41(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float*
  *   d_out   [n_utt][8][8][45][8]     = what svk_c3d2_conv41 takes                                                       */
 int svk_c3d2_conv32t(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_wblk, const float* d_bias,
                      const float* d_slope, int32_t flags, float* d_out);
+/* conv4_1 (64 -> 128, kernel (3,1,3)) -> BN -> PReLU, model.py:132-135 + :165-166, one kernel on v_mfma_f32_16x16x32_f16
+ * through two-piece products like svk_c3d2_stage1 (direct form; one cube per work item, staged whole; csrc/c3d2.hip):
+ *   d_in    [n_utt][8][8][45][8]     = svk_c3d2_conv32t's output
+ *   d_wblk  [8 nt][9 taps][2 kb][2][64][8 halves]: lane (co = 16 nt + (l & 15), kk = l >> 4), e: W41[co][ci = 32 kb + 8 kk + e][kd][kw],
+ *           tap 3 kd + kw (BatchNorm folded); block 0 = H = f16(w), block 1 = L = f16(w - H);  d_bias / d_slope [128]
+ *   flags   bit 1: the caller asserts every PReLU slope lies in [0, 1]; every other bit must be 0
+ *   d_out   [n_utt][6][16][27 = 9 h x 3 w][8]: chunked [cube][depth][channel / 8][pixel][channel % 8], what svk_c3d2_conv42 takes */
+int svk_c3d2_conv41(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_wblk, const float* d_bias,
+                    const float* d_slope, int32_t flags, float* d_out);
+/* The end of the network, model.py:136-139 (definitions) + :167-170 (forward): conv4_2 (128 -> 128, kernel (3,7,1)) -> BN -> PReLU,
+ * flatten, FC5 (4 608 -> 128) -- GEMMs over the BATCH on v_mfma_f32_16x16x4_f32 (csrc/c3d2_tail.hip): an M tile is one output
+ * position of 16 cubes; conv4_2 runs through Winograd's F(2, 3) along depth with the input transform applied once while a
+ * chunk is staged into LDS and the weight transform applied by the HOST.
+ *   svk_c3d2_conv42  d_in  [n_utt][6][16][27][8] = svk_c3d2_conv41's output
+ *                    d_wfrag [8 nt][16 chunks][7 kh][4 k][64][2]: lane (co = 16 nt + (l & 15), kk = l >> 4), e:
+ *                            G_k[co][8 chunk + 2 kk + e][kh], G0 = g0, G1 = (g0 + g1 + g2) / 2, G2 = (g0 - g1 + g2) / 2,
+ *                            G3 = g2 over the three depth taps g of the BN-folded weights;  d_bias / d_slope [128]
+ *                    d_out [n_utt][4][16][9 = 3 h x 3 w][8]
+ *   flags            bit 1: the caller asserts every PReLU slope lies in [0, 1]
+ *   svk_c3d2_fc5     d_in  [n_utt][4 608] = svk_c3d2_conv42's output, K index ((d * 16 + chunk) * 9 + pixel) * 8 + channel % 8
+ *                    d_wfrag [4 d][8 nt][72][64][4]: lane (j = 16 nt + (l & 15), kk = l >> 4), e: W5[j][column of K index
+ *                            1 152 d + 16 step + 4 kk + e] (model.py:168 flattens NCDHW: column = channel * 36 + d * 9 + pixel)
+ *                    d_bias [128];  d_work: svk_c3d2_fc5_workspace_floats(n_utt) floats (partial sums of the four K ranges,
+ *                    added in a fixed order: bitwise repeatable);  d_out [n_utt][128]                                  */
 int svk_c3d2_conv42(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
                     const float* d_slope, int32_t flags, float* d_out);
 size_t svk_c3d2_fc5_workspace_floats(int32_t n_utt);

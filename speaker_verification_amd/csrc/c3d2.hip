@@ -990,6 +990,125 @@ __global__ __launch_bounds__(512) void c3d2_conv32h_kernel(const Conv32hParams p
   }
 }
 
+// ---- conv4_1 (64 -> 128, kernel (3,1,3)) + BN + PReLU (model.py:132-135, :165-166) through two-piece f16 products, direct form:
+// 9 taps x two K = 32 blocks x three MFMAs.  Item = ONE CUBE: its whole input [8 d][8 chunks][45 = 9 h x 5 w][8] (92 KB) is split
+// while staged into sixteen planes (eight channel chunks x {h, l}) of 16-byte slots, slot = d * 45 + pixel; outputs 6 d x 9 h x 3 w =
+// 162 positions = 10.1 tiles; wave = N tile (eight waves: 128 output channels; 36 weight blocks = 144 VGPRs), every wave walks all
+// eleven tiles.  The next cube is loaded into registers in front of the tiles and parked behind them.
+// (As an instance of the f32 batch-GEMM template of c3d2_tail.hip, Winograd F(2,3) along depth: 0.54 - 0.69 ms per 4 018 cubes.) ----
+constexpr int C41H_PLANE = 368;                               // 8 * 45 = 360 slots per plane, padded to a multiple of 16
+constexpr int C41H_LDS_WORDS = 4 * 16 * C41H_PLANE;           // 94 208 bytes
+constexpr int C41H_POS = 6 * 9 * 3;                           // 162 positions per cube
+constexpr int C41H_PIECES = 8 * 8 * 45 * 2;                   // 5 760 sixteen-byte pieces per cube
+
+struct Conv41hParams {
+  const float* in;      // [n][8][8 chunks][45][8]
+  const u32x4* wblk;    // [8 nt][9 taps][2 kb][2][64]: lane (co = 16 nt + (l & 15), kk): e: W[co][32 kb + 8 kk + e][kd][kw], tap = 3 kd + kw; H | L
+  const float* bias;    // [128]
+  const float* slope;   // [128]
+  float* out;           // [n][6 d][16 chunks][27 = 9 h x 3 w][8]
+  int32_t n_utt;
+  unsigned* queue;
+};
+
+template <bool SLOPE01>
+__global__ __launch_bounds__(512) void c3d2_conv41h_kernel(const Conv41hParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_c41[];
+  unsigned* const reg = reinterpret_cast<unsigned*>(smem_c41);
+  const int lane = threadIdx.x & 63, nt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  u32x4 W[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      W[t][kb][0] = p.wblk[(((nt * 9 + t) * 2 + kb) * 2) * 64 + lane];
+      W[t][kb][1] = p.wblk[(((nt * 9 + t) * 2 + kb) * 2 + 1) * 64 + lane];
+    }
+  f32x4 b4, sl4;   // channels 16 nt + 4 kk .. + 3 of ONE position
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    b4[r] = p.bias[16 * nt + 4 * kk + r];
+    sl4[r] = p.slope[16 * nt + 4 * kk + r];
+  }
+  const int n_items = p.n_utt;
+  __shared__ int q_next;
+  // piece e = t + 512 k (twelve per thread, 5 760 in all): run e / 90 = d * 8 + chunk, pixel (e % 90) / 2, channels 4 (e & 1) .. + 3
+  constexpr int NPC = (C41H_PIECES + 511) / 512;
+  f32x4 sv[NPC];
+  auto load_item = [&](int it) {
+    const float* const src = p.in + (int64_t)it * (8 * 8 * 45 * 8) + 4 * (int)threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NPC; ++k)
+      if (k < NPC - 1 || threadIdx.x < C41H_PIECES - (NPC - 1) * 512) sv[k] = *reinterpret_cast<const f32x4*>(src + 2048 * k);
+  };
+  auto park_item = [&]() {
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+      const int e = (int)threadIdx.x + 512 * k;
+      const int run = (e * 46604) >> 22, r = e - 90 * run;        // e / 90 for e < 5 760
+      const int d = run >> 3, chunk = run & 7;
+      unsigned* const dst = reg + 4 * (chunk * C41H_PLANE + d * 45 + (r >> 1)) + 2 * (r & 1);
+      unsigned h0, l0, h1, l1;
+      split2(__builtin_shufflevector(sv[k], sv[k], 0, 1), h0, l0);
+      split2(__builtin_shufflevector(sv[k], sv[k], 2, 3), h1, l1);
+      if (k < NPC - 1 || threadIdx.x < C41H_PIECES - (NPC - 1) * 512) {
+        *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+        *reinterpret_cast<u32x2*>(dst + 4 * 8 * C41H_PLANE) = (u32x2){l0, l1};
+      }
+    }
+  };
+  int item = blockIdx.x, item_next = item + (int)gridDim.x;   // the counter is drawn one item ahead, as in c3d2_conv32h_kernel
+  if (item < n_items) {
+    load_item(item);
+    park_item();
+  }
+  __syncthreads();
+  while (item < n_items) {
+    unsigned q_ticket = 0;
+    if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
+    if (item_next < n_items) load_item(item_next);
+#pragma unroll 1
+    for (int t = 0; t < (C41H_POS + 15) / 16; ++t) {
+      const int P = min(16 * t + i, C41H_POS - 1);
+      const int dq = (P * 2428) >> 16, r27 = P - 27 * dq;                       // P / 27 for P < 162
+      const int h = (r27 * 21846) >> 16, wq = r27 - 3 * h;                      // r27 / 3 for r27 < 27
+      // input pixel (dq + kd, h, wq + kw), channels 32 kb + 8 kk .. + 7: slot (dq + kd) * 45 + 5 h + wq + kw of plane 4 kb + kk [l: + 8]
+      const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * (kk * C41H_PLANE + dq * 45 + 5 * h + wq);
+      auto rd = [&](int st, int piece) -> u32x4 {   // step st = 2 tap + kb
+        const int tap = st >> 1, kb = st & 1;
+        return *reinterpret_cast<const u32x4*>(a2 + 16 * (45 * (tap / 3) + tap % 3) + 16 * 4 * C41H_PLANE * kb + 16 * 8 * C41H_PLANE * piece);
+      };
+      f32x4 a = b4;
+      u32x4 bh[2], bl[2];
+      bh[0] = rd(0, 0);
+      bl[0] = rd(0, 1);
+#pragma unroll
+      for (int st = 0; st < 18; ++st) {
+        if (st + 1 < 18) {
+          bh[(st + 1) & 1] = rd(st + 1, 0);
+          bl[(st + 1) & 1] = rd(st + 1, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[st >> 1][st & 1][0]), __builtin_bit_cast(f16x8, bh[st & 1]), a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[st >> 1][st & 1][0]), __builtin_bit_cast(f16x8, bl[st & 1]), a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W[st >> 1][st & 1][1]), __builtin_bit_cast(f16x8, bh[st & 1]), a, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (16 * t + i < C41H_POS) {
+        float* const o = p.out + ((((int64_t)item * 6 + dq) * 16 + 2 * nt + (kk >> 1)) * 27 + r27) * 8 + 4 * (kk & 1);
+        *reinterpret_cast<f32x4*>(o) = prelu4<SLOPE01>(a, sl4);
+      }
+    }
+    __syncthreads();   // nobody reads the planes any more
+    if (item_next < n_items) park_item();
+    if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + 2 * (int)gridDim.x : item_next + (int)gridDim.x;
+    __syncthreads();   // the next cube's planes are written
+    item = item_next;
+    item_next = q_next;
+  }
+}
+
 }  // namespace
 
 extern "C" int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_w21blk,
@@ -1097,6 +1216,29 @@ extern "C" int svk_c3d2_conv32t(svk_ctx* ctx, const float* d_in, int32_t n_utt, 
   SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t items = (int64_t)n_utt * 5;
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(items, ctx->num_cu)), dim3(512), lds, ctx->stream, p);
+  SVK_LAUNCH_CHECK(ctx);
+  return SVK_OK;
+}
+
+extern "C" int svk_c3d2_conv41(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_wblk, const float* d_bias,
+                               const float* d_slope, int32_t flags, float* d_out) {
+  if (!ctx) return SVK_ERR_BAD_ARG;
+  SVK_REQUIRE(ctx, n_utt >= 0, "n_utt negative");
+  SVK_REQUIRE(ctx, (flags & ~2) == 0, "flags: only bit 1 (slopes in [0, 1]) is defined");
+  if (n_utt == 0) return SVK_OK;
+  SVK_REQUIRE(ctx, d_in && d_wblk && d_bias && d_slope && d_out, "NULL buffer");
+  SVK_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_wblk) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0,
+              "buffers must be 16-byte aligned");
+  SVK_REQUIRE(ctx, (int64_t)n_utt + 2 * (int64_t)ctx->num_cu < ((int64_t)1 << 31), "too many cubes for one launch");
+  unsigned* const queue = getenv("SVK_C3D2_STATIC_ITEMS") ? nullptr : reinterpret_cast<unsigned*>(static_cast<char*>(ctx->scratch) + 100);
+  if (queue) SVK_HIP(ctx, hipMemsetAsync(queue, 0, 4, ctx->stream));
+  Conv41hParams p{d_in, reinterpret_cast<const u32x4*>(d_wblk), d_bias, d_slope, d_out, n_utt, queue};
+  void (*kern)(const Conv41hParams) = (flags & 2) ? c3d2_conv41h_kernel<true> : c3d2_conv41h_kernel<false>;
+  const size_t lds = sizeof(unsigned) * (size_t)C41H_LDS_WORDS;
+  if (lds + 64 > (size_t)ctx->lds_per_cu)
+    return svk_fail(ctx, SVK_ERR_UNSUPPORTED, "svk_c3d2_conv41 needs %zu bytes of LDS per workgroup (device: %d)", lds, ctx->lds_per_cu);
+  SVK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(n_utt, ctx->num_cu)), dim3(512), lds, ctx->stream, p);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
 }

@@ -1,20 +1,21 @@
-// The C3D2 embedding network's last block on v_mfma_f32_16x16x4_f32 (model.py:132-139 definitions, :165-170 forward):
-//   c3d2_tail_kernel<Conv41>   conv4_1 (64 -> 128, kernel (3,1,3)) + BN + PReLU
+// The end of the C3D2 embedding network on v_mfma_f32_16x16x4_f32 (model.py:136-139 definitions, :167-170 forward; conv4_1
+// runs on the f16 matrix pipe in csrc/c3d2.hip, where conv3_2 went before it -- both were instances of this template first:
+// tools/experiments/conv32_f32_template_instance.patch, conv41_f32_template_instance.patch):
 //   c3d2_tail_kernel<Conv42>   conv4_2 (128 -> 128, kernel (3,7,1)) + BN + PReLU
 //   fc5_kernel / fc5_reduce_kernel   FC5 (4 608 -> 128), K split four ways, partial sums added in a fixed order
 // BatchNorm (eval mode) is folded into weights and biases by the host (model.FusedEmbedder).
 //
-// These layers are GEMM-shaped over the BATCH: per cube they have 162 / 36 / 1 output positions but K = 576 / 2 688 /
-// 4 608 and N = 128, and their weights (0.3 / 1.7 / 2.4 MB) fit no register file.  Both convolutions are 3 taps deep with
-// depth stride 1, so Winograd's F(2, 3) along depth applies as in csrc/c3d2.hip: for an output depth pair (2 P, 2 P + 1),
+// These layers are GEMM-shaped over the BATCH: per cube they have 36 / 1 output positions but K = 2 688 / 4 608 and
+// N = 128, and their weights (1.7 / 2.4 MB) fit no register file.  conv4_2 is 3 taps deep with depth stride 1, so
+// Winograd's F(2, 3) along depth applies: for an output depth pair (2 P, 2 P + 1),
 //     t0 = x0 - x2,  t1 = x1 + x2,  t2 = x2 - x1,  t3 = x1 - x3            (input depths x0 .. x3 = 2 P .. 2 P + 3)
 //     a_k = sum over (row / column tap, input channel) of t_k G_k          (G: transformed weights, made by the HOST here)
 //     y(2 P) = a0 + a1 + a2,   y(2 P + 1) = a1 - a2 - a3                   (4 MFMAs where the direct form issues 6)
 //
-// Shape of the convolution kernel (one template, two instances):
+// Shape of the convolution kernel (a template over the layer's geometry; conv4_2 is the instance left):
 //   * M tile = ONE output position of SIXTEEN cubes (lane i = cube): every tile is full whatever the layer's 9 or 27
 //     positions per depth pair -- tiles cut inside a cube would be 27 of 32 and 9 of 16 rows full;
-//   * work item = (group of 16 cubes, depth pair[, block of 3 rows for conv4_1]) = 9 positions = 9 M tiles; the workgroup's
+//   * work item = (group of 16 cubes, depth pair[, block of rows]) = 9 positions = 9 M tiles; the workgroup's
 //     eight waves own one 16-channel N tile each: 9 tiles x 4 transformed accumulators = 144 VGPRs, two waves per SIMD;
 //   * K runs over (8-channel chunk, tap, k).  A chunk of the item's input is staged in LDS ALREADY TRANSFORMED: the
 //     staging threads load the four depths of a (cube, pixel, 4 channels) piece, form t0 .. t3 once and park them as
@@ -47,20 +48,6 @@ __device__ __forceinline__ float prelu_t(float v, float slope) {
 
 constexpr int GROUP = 16;   // cubes per work item = rows of an M tile
 
-// conv4_1: input [n][8 d][8 chunks][45 = 9 h x 5 w][8] (svk_c3d2_conv32t), output
-// [n][6 d][16 chunks][27 = 9 h x 3 w][8].  Item = (group, pair P of 3, row block rb of 3): rows 3 rb .. 3 rb + 2, taps along w.
-struct Conv41 {
-  static constexpr int NT = 9;                         // M tiles (output positions) per work item
-  static constexpr int TAPS = 3, TAP_PIX = 1;          // a tap moves one pixel (w)
-  static constexpr int D_IN = 8, NCHUNK = 8, PIX_IN = 45, PIXN = 15;   // PIXN: staged pixels per plane (3 rows x 5)
-  static constexpr int D_OUT = 6, PIX_OUT = 27;
-  static constexpr int SC = 2;                         // chunks per phase (between two barriers)
-  static constexpr int PAIRS = 3, BLOCKS = 3;
-  static constexpr int NWAVES = 8;                     // N tiles = waves per workgroup (128 output channels), one workgroup per CU
-  __device__ static constexpr int pix0(int p) { return 5 * (p / 3) + p % 3; }   // tile p = (row hl, column w') -> staged pixel
-  __device__ static int in_pix_start(int blk) { return 15 * blk; }
-  __device__ static int out_pix(int t, int blk) { return 9 * blk + t; }          // output pixel of tile t
-};
 // conv4_2: input = conv4_1's output, output [n][4 d][16 chunks][9 = 3 h x 3 w][8].  Item = (group, pair P of 2), taps along h.
 struct Conv42 {
   static constexpr int NT = 9;
@@ -125,8 +112,8 @@ __global__ __launch_bounds__(64 * L::NWAVES, 2) void c3d2_tail_kernel(const Tail
   const int i = lane & 15, kk = lane >> 4;
   // The MFMA's M side is the CHANNEL (A = the streamed weight fragment), its N side the cube (B = the staged activations): a lane
   // ends up with channels 16 nt + 4 kk .. + 3 of cube i -- 16 contiguous bytes of the chunked output, one 16-byte store per
-  // (tile, depth) where the other order (M = cube) issued four 4-byte stores (round 4: 72 -> 18 store instructions per item and
-  // wave in conv4_1; the same products in the same order: bit-identical)
+  // (tile, depth) where the other order (M = cube) issued four 4-byte stores (round 4: a quarter of the store instructions; the same products
+  // in the same order: bit-identical)
   f32x4 bias4, slope4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -495,11 +482,6 @@ extern "C" int svk_c3d2_fc5(svk_ctx* ctx, const float* d_in, int32_t n_utt, cons
                      0, ctx->stream, d_work, d_bias, d_out, n_vec, (int64_t)n_utt * 128);
   SVK_LAUNCH_CHECK(ctx);
   return SVK_OK;
-}
-
-extern "C" int svk_c3d2_conv41(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,
-                               const float* d_slope, int32_t flags, float* d_out) {
-  return launch_tail<Conv41>(ctx, "svk_c3d2_conv41", d_in, n_utt, d_wfrag, d_bias, d_slope, flags, d_out);
 }
 
 extern "C" int svk_c3d2_conv42(svk_ctx* ctx, const float* d_in, int32_t n_utt, const float* d_wfrag, const float* d_bias,

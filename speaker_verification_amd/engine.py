@@ -512,12 +512,17 @@ class Engine:
         chunked [n, 8 d, 8 chunks, 45 = 9 h x 5 w, 8] (the shape of the last block: M tile = one position of 16 cubes)."""
         if tuple(act.shape[1:]) != (10, 8, 5, 15, 8) or not act.is_contiguous():
             raise ValueError("c3d2_conv32t wants the chunked activation [n, 10, 8, 5, 15, 8]")
-        return self._c3d2_tail_conv(self.lib.svk_c3d2_conv32t, act, tables, (8, 8, 45, 8))
+        return self._c3d2_tail_conv(self.lib.svk_c3d2_conv32t, act, tables, (8, 8, 45, 8), (4, 2, 21, 2, 64, 8), "float16")
 
-    def _c3d2_tail_conv(self, fn, act, tables, out_shape):
+    def _c3d2_tail_conv(self, fn, act, tables, out_shape, w_shape, w_dtype):
         torch = _torch()
         n = act.shape[0]
         wfrag, bias, slope = tables[:3]
+        if tuple(wfrag.shape) != w_shape or wfrag.dtype != getattr(torch, w_dtype) or not wfrag.is_contiguous():
+            raise ValueError("weight blocks: want %s of %s, got %s of %s" % (w_shape, w_dtype, tuple(wfrag.shape), wfrag.dtype))
+        co = out_shape[1] * 8
+        if bias.numel() != co or slope.numel() != co or bias.dtype != torch.float32 or slope.dtype != torch.float32:
+            raise ValueError("bias / slope: want %d float32 values each" % co)
         slope01 = bool(tables[3]) if len(tables) > 3 else False
         out = torch.empty((n,) + out_shape, dtype=torch.float32, device=self.device)
         self._stream()
@@ -527,16 +532,16 @@ class Engine:
 
     def c3d2_conv41(self, act, tables):
         """svk_c3d2_conv41: chunked [n, 8 d, 8 chunks, 45, 8] (svk_c3d2_conv32t's output) -> conv4_1 + BN + PReLU
-        -> chunked [n, 6 d, 16 chunks, 27 = 9 h x 3 w, 8] (a GEMM over the batch: M tile = one position of 16 cubes)."""
+        -> chunked [n, 6 d, 16 chunks, 27 = 9 h x 3 w, 8]."""
         if tuple(act.shape[1:]) != (8, 8, 45, 8) or not act.is_contiguous():
             raise ValueError("c3d2_conv41 wants the chunked activation [n, 8, 8, 45, 8]")
-        return self._c3d2_tail_conv(self.lib.svk_c3d2_conv41, act, tables, (6, 16, 27, 8))
+        return self._c3d2_tail_conv(self.lib.svk_c3d2_conv41, act, tables, (6, 16, 27, 8), (8, 9, 2, 2, 64, 8), "float16")
 
     def c3d2_conv42(self, act, tables):
         """svk_c3d2_conv42: chunked [n, 6, 16, 27, 8] -> conv4_2 + BN + PReLU -> chunked [n, 4 d, 16 chunks, 9 = 3 h x 3 w, 8]."""
         if tuple(act.shape[1:]) != (6, 16, 27, 8) or not act.is_contiguous():
             raise ValueError("c3d2_conv42 wants the chunked activation [n, 6, 16, 27, 8]")
-        return self._c3d2_tail_conv(self.lib.svk_c3d2_conv42, act, tables, (4, 16, 9, 8))
+        return self._c3d2_tail_conv(self.lib.svk_c3d2_conv42, act, tables, (4, 16, 9, 8), (8, 16, 7, 4, 64, 2), "float32")
 
     def c3d2_fc5(self, act, tables):
         """svk_c3d2_fc5: chunked [n, 4, 16, 9, 8] (= [n, 4 608]) -> FC5 -> [n, 128] embeddings."""

@@ -331,7 +331,7 @@ class FusedEmbedder:
         return torch.stack((g0, 0.5 * ((g0 + g2) + g1), 0.5 * ((g0 + g2) - g1), g2))
 
     def _tail_conv_tables(self, li, shape, taps_axis):
-        """Operand fragments of `svk_c3d2_conv41` / `svk_c3d2_conv42` from stage `li`, or None when the layer differs:
+        """Operand fragments of `svk_c3d2_conv42` from stage `li`, or None when the layer differs:
         wfrag [8 nt][chunks of 8 input channels][taps][4 k][64 lanes][2]: lane (co = 16 nt + (l & 15), kk = l >> 4),
         element e = G_k[co][8 chunk + 2 kk + e][tap]."""
         if len(self.stages) <= li:
@@ -386,11 +386,36 @@ class FusedEmbedder:
         return self._conv32t
 
     def conv41_tables(self):
-        """`svk_c3d2_conv41` (conv4_1: 64 -> 128, k(3,1,3), stride 1, no pool), BN folded, depth-transformed by the host."""
+        """`svk_c3d2_conv41` (conv4_1: 64 -> 128, k(3,1,3), stride 1, no pool), two-piece f16 products (see stage1_tables):
+        wblk [8 nt][9 taps][2 kb][2: H | L][64 lanes][8 halves], element e = W[co = 16 nt + (l & 15)][32 kb + 8 kk + e][kd][kw],
+        tap 3 kd + kw; bias, slope [128].  None when the layer differs."""
         hit = getattr(self, "_conv41", False)
-        if hit is False:
-            hit = self._conv41 = self._tail_conv_tables(6, (128, 64, 3, 1, 3), "w")
-        return hit
+        if hit is not False:
+            return hit
+        self._conv41 = None
+        if len(self.stages) < 7:
+            return None
+        w, b, sl, st, pool, _ = self.stages[6]
+        if tuple(w.shape) != (128, 64, 3, 1, 3) or tuple(st) != (1, 1, 1) or pool:
+            return None
+        dev = w.device
+        lane = torch.arange(64, device=dev)
+        ch, kq = lane & 15, lane >> 4
+        a = w.contiguous()[:, :, :, 0, :]                                    # [co][ci][kd][kw]
+        e8 = torch.arange(8, device=dev)[None, :]
+        blk = torch.empty((8, 9, 2, 2, 64, 8), dtype=torch.float16, device=dev)
+        for nt in range(8):
+            for kb in range(2):
+                ci = 32 * kb + 8 * kq[:, None] + e8
+                for kd in range(3):
+                    for kw in range(3):
+                        wv = a[(16 * nt + ch)[:, None], ci, kd, kw]
+                        h = wv.to(torch.float16)
+                        blk[nt, 3 * kd + kw, kb, 0] = h
+                        blk[nt, 3 * kd + kw, kb, 1] = (wv - h.to(torch.float32)).to(torch.float16)
+        slope = sl.expand(128).contiguous() if sl.numel() == 1 else sl.contiguous()
+        self._conv41 = (blk.contiguous(), b.contiguous(), slope, bool(((sl >= 0) & (sl <= 1)).all()))
+        return self._conv41
 
     def conv42_tables(self):
         """`svk_c3d2_conv42` (conv4_2: 128 -> 128, k(3,7,1), stride 1, no pool)."""

@@ -214,8 +214,8 @@ def test_ragged_batches_sort_cap_and_merge_the_tail():
 
 
 def test_tail_operand_tables_against_naive_indexing():
-    """The host tables of svk_c3d2_conv41 / conv42 / conv32t / fc5 (model.FusedEmbedder): depth-transformed weights in the MFMA
-    lane order of include/svk.h, FC5's columns permuted to conv4_2's chunked output order -- against element-wise indexing."""
+    """The host tables of svk_c3d2_conv42 / fc5 (model.FusedEmbedder): depth-transformed weights in the MFMA lane order of
+    include/svk.h, FC5's columns permuted to conv4_2's chunked output order -- against element-wise indexing."""
     import random
     import torch
     from speaker_verification_amd.model import perturb_inference_state, seeded_model
@@ -223,7 +223,7 @@ def test_tail_operand_tables_against_naive_indexing():
     m.load_state_dict(perturb_inference_state(m.state_dict(), 4))
     e = m.fused_inference()
     rnd = random.Random(1)
-    for name, li, axis in (("conv41", 6, "w"), ("conv42", 7, "h")):
+    for name, li, axis in (("conv42", 7, "h"),):
         frag = getattr(e, name + "_tables")()[0]
         w = e.stages[li][0]
         g0, g1, g2 = w[:, :, 0], w[:, :, 1], w[:, :, 2]
@@ -244,8 +244,8 @@ def test_tail_operand_tables_against_naive_indexing():
 
 
 def test_half_pair_weight_blocks_against_naive_indexing():
-    """The host tables of the kernels that multiply through two-piece f16 products (svk_c3d2_stage1 / stage2 / conv31 / conv32t;
-    include/svk.h): H = f16(w), L = f16(w - H) in the lane order of v_mfma_f32_16x16x32_f16's A operand -- element by element
+    """The host tables of the kernels that multiply through two-piece f16 products (svk_c3d2_stage1 / stage2 / conv31 / conv32t /
+    conv41; include/svk.h): H = f16(w), L = f16(w - H) in the lane order of v_mfma_f32_16x16x32_f16's A operand -- element by element
     against the BN-folded weights, and H + L back to the weight within 2^-21 (or the last bit of an f16 subnormal)."""
     import random
     import torch
@@ -281,9 +281,10 @@ def test_half_pair_weight_blocks_against_naive_indexing():
     w21blk, _, _, w22blk = e.stage2_tables()[:4]
     w21, w22 = e.stages[2][0], e.stages[3][0]
     assert tuple(w21blk.shape) == (2, 6, 2, 64, 8) and tuple(w22blk.shape) == (2, 24, 2, 64, 8)
-    w31blk, w32blk = e.conv31_tables()[0], e.conv32t_tables()[0]
-    w31, w32 = e.stages[4][0], e.stages[5][0]
+    w31blk, w32blk, w41blk = e.conv31_tables()[0], e.conv32t_tables()[0], e.conv41_tables()[0]
+    w31, w32, w41 = e.stages[4][0], e.stages[5][0], e.stages[6][0]
     assert tuple(w31blk.shape) == (4, 9, 2, 64, 8) and tuple(w32blk.shape) == (4, 2, 21, 2, 64, 8)
+    assert tuple(w41blk.shape) == (8, 9, 2, 2, 64, 8) and w41blk.dtype == torch.float16
     for _ in range(400):
         lane, el = rnd.randrange(64), rnd.randrange(8)
         co, kk = lane & 15, lane >> 4
@@ -295,6 +296,8 @@ def test_half_pair_weight_blocks_against_naive_indexing():
         check(w31blk[nt, tap, :, lane, el], float(w31[16 * nt + co, 8 * kk + el, tap // 3, 0, tap % 3]))
         kb, tap = rnd.randrange(2), rnd.randrange(21)
         check(w32blk[nt, kb, tap, :, lane, el], float(w32[16 * nt + co, 32 * kb + 8 * kk + el, tap // 7, tap % 7, 0]))
+        nt, tap = rnd.randrange(8), rnd.randrange(9)
+        check(w41blk[nt, tap, kb, :, lane, el], float(w41[16 * nt + co, 32 * kb + 8 * kk + el, tap // 3, 0, tap % 3]))
 
 
 def test_upload_groups_of_a_host_arena():

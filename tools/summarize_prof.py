@@ -21,7 +21,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OURS = ("frontend_kernel", "cmvn_kernel", "vad_kernel", "vad_small_kernel", "vad_flags_kernel", "vad_walk_kernel", "vad_copy_kernel",
         "cube_gather_kernel", "cosine_kernel", "cosine_tiled_kernel",
         "inv_norm_kernel", "draw_crops_kernel", "decimate_kernel", "resample_kernel",
-        "c3d2_stage1h_kernel", "c3d2_conv21h_kernel", "c3d2_conv22h_kernel", "c3d2_conv31h_kernel", "c3d2_conv32h_kernel",
+        "c3d2_stage1h_kernel", "c3d2_conv21h_kernel", "c3d2_conv22h_kernel", "c3d2_conv31h_kernel", "c3d2_conv32h_kernel", "c3d2_conv41h_kernel",
         "cmvnw_kernel", "spectrum_pow2_kernel",
         "spectrum_dft_kernel", "spectrum_fft_kernel", "mel_features_kernel", "c3d2_tail_kernel", "fc5_reduce_kernel", "fc5_kernel")
 
@@ -31,7 +31,7 @@ def short(name):
         if k in name:
             extra = ""
             if k == "c3d2_tail_kernel":
-                extra = "<Conv41>" if "Conv41" in name else "<Conv42>"
+                extra = "<Conv42>"
             if "frontend_kernel" in name:
                 extra = "<int16,nfft1024>" if "<short, true" in name else "<int16,nfft512>" if "<short, false" in name \
                     else "<f32,nfft1024>" if "<float, true" in name else "<f32,nfft512>"

@@ -41,7 +41,7 @@ kernels = {
     "stage2": (lambda x=rnd(n, 16, 36, 18, 16): eng.c3d2_stage2(x, emb.stage2_tables()), (9 * 53 * 36 + 21 * 8 * 2 * 72) / 2, 112.80384e6),
     "conv3_1": (lambda x=rnd(n, 12, 15, 7, 32): eng.c3d2_conv31(x, emb.conv31_tables()), 5 * 10 * 4 * 27 / 2, 13.824e6),
     "conv3_2": (lambda x=rnd(n, 10, 8, 5, 15, 8): eng.c3d2_conv32t(x, emb.conv32t_tables()), 5 * 5 * 4 * 126 / 2, 30.96576e6),
-    "conv4_1": (lambda x=rnd(n, 8, 8, 45, 8): eng.c3d2_conv41(x, emb.conv41_tables()), 7776, 11.943936e6),
+    "conv4_1": (lambda x=rnd(n, 8, 8, 45, 8): eng.c3d2_conv41(x, emb.conv41_tables()), 11 * 8 * 54 / 2, 11.943936e6),
     "conv4_2": (lambda x=rnd(n, 6, 16, 27, 8): eng.c3d2_conv42(x, emb.conv42_tables()), 8064, 12.386304e6),
     "fc5": (lambda x=rnd(n, 4, 16, 9, 8): eng.c3d2_fc5(x, emb.fc5_tables()), 576, 0.589824e6),
 }
