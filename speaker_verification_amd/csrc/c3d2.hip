@@ -208,10 +208,12 @@ constexpr int HPAIRS = 14;                                   // tap pairs of con
 // (h, l) of two f32 values as two packed-half words: {h0, h1}, {l0, l1}
 __device__ __forceinline__ void split2(f32x2 v, unsigned& h, unsigned& l) {
   const f16x2 hh = __builtin_convertvector(v, f16x2);
-  const f32x2 back = __builtin_convertvector(hh, f32x2);
-  const f16x2 ll = __builtin_convertvector(v - back, f16x2);
   h = __builtin_bit_cast(unsigned, hh);
-  l = __builtin_bit_cast(unsigned, ll);
+  // l = f16(x - f32(h)) as ONE instruction per value: v_fma_mix reads h as a half and x as a float, multiplies by -1 and rounds the
+  // f32 result (exact: x - h has at most 13 significant bits) into one half of the destination -- where the compiler's own code is
+  // two v_cvt_f32_f16, a packed subtract and v_cvt_pk_f16_f32.  Bit-identical on 2^22 random pairs incl. denormals, NaN, infinities.
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(v[0]));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(v[1]));
 }
 
 // max(x, x of lane ^ 1) as ONE instruction (DPP quad_perm [1, 0, 3, 2] on the first source).  Written out: four calls of
@@ -607,11 +609,14 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21h_kernel(const Conv21hParam
 // ---- conv2_2 + pool2 through two-piece f16 products: direct form, K = 32 = the 32 input channels of ONE tap, three MFMAs per
 // tap (H x h, H x l, L x h), 24 taps.  Item = (cube, pooled column j, third q of the output depths) as before; its input
 // [6 d][36 h][2 w][32 c] is split while it is staged: eight planes (four channel quarters x {h, l}) of 16-byte slots, a plane
-// split by the parity of the row (rows are 2 apart along a tile): slot ((r & 1) * 6 + d) * 36 + (r >> 1) * 2 + col.  The item's
+// split by the parity of the row (rows are 2 apart along a tile): slot ((r & 1) * 6 + d) * 46 + (r >> 1) * 2 + col.  The item's
 // 4 d x 15 rows x 2 columns = 120 positions are 7.5 tiles of 16; wave = (N tile nt, every other tile): the 48 weight blocks of an
 // N tile are 192 VGPRs.  Pool = max over adjacent lanes (the column pair), the even lane stores four channels. ----
-constexpr int C22H_PLANE = 2 * 6 * S2_H;             // 432 slots per plane
-constexpr int C22H_LDS_WORDS = 4 * 8 * C22H_PLANE;   // 55 296 bytes
+// Depth pitch 46, not 36: a tile's positions run on from one depth's 30 to the next, and with 46 = 30 (mod 16) so do their slots mod 16
+// -- the sixteen lanes of an LDS lane group stay on sixteen different 16-byte bank groups in the three of 7.5 tiles that straddle depths
+constexpr int C22H_DP = 46;
+constexpr int C22H_PLANE = 560;                      // 2 * 6 * 46 = 552 slots per plane, padded to a multiple of 16
+constexpr int C22H_LDS_WORDS = 4 * 8 * C22H_PLANE;   // 71 680 bytes
 constexpr int C22H_POS = 4 * O2_H * 2;               // 120 positions per item
 
 struct Conv22hParams {
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22h_kernel(const Conv22hParam
             hh = carry ? hh - S2_H : hh;
             d = carry ? d + 1 : d;
           }
-          const int slot = ((hh & 1) * 6 + d) * S2_H + (hh >> 1) * 2 + wq;
+          const int slot = ((hh & 1) * 6 + d) * C22H_DP + (hh >> 1) * 2 + wq;
           unsigned* const dst = reg + 4 * ((piece >> 1) * C22H_PLANE + slot) + 2 * (piece & 1);
           unsigned h0, l0, h1, l1;
           split2(__builtin_shufflevector(sv[k - r0], sv[k - r0], 0, 1), h0, l0);
@@ -695,11 +700,11 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22h_kernel(const Conv22hParam
     for (int t = half; t < (C22H_POS + 15) / 16; t += 2) {
       const int P = min(16 * t + i, C22H_POS - 1);
       const int dq = (P * 2185) >> 16, r30 = P - 30 * dq, row = r30 >> 1;      // P / 30 for P < 120
-      // input pixel (dq + kd, 2 row + kh, col), channels 8 kk .. + 7: slot ((kh & 1) * 6 + dq + kd) * 36 + (row + kh / 2) * 2 + col of plane kk [l: + 4]
-      const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * (kk * C22H_PLANE + dq * S2_H + 2 * row + (i & 1));
+      // input pixel (dq + kd, 2 row + kh, col), channels 8 kk .. + 7: slot ((kh & 1) * 6 + dq + kd) * 46 + (row + kh / 2) * 2 + col of plane kk [l: + 4]
+      const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * (kk * C22H_PLANE + dq * C22H_DP + 2 * row + (i & 1));
       auto rd = [&](int tap, int piece) -> u32x4 {
         const int kd = tap >> 3, kh = tap & 7;
-        return *reinterpret_cast<const u32x4*>(a2 + 16 * (((kh & 1) * 6 + kd) * S2_H + (kh >> 1) * 2) + 16 * 4 * C22H_PLANE * piece);
+        return *reinterpret_cast<const u32x4*>(a2 + 16 * (((kh & 1) * 6 + kd) * C22H_DP + (kh >> 1) * 2) + 16 * 4 * C22H_PLANE * piece);
       };
       f32x4 acc = b4;
       u32x4 bh[3], bl[3];
@@ -859,8 +864,11 @@ __global__ __launch_bounds__(256, 3) void c3d2_conv31h_kernel(const Conv31Params
 // swap partial sums through LDS (kb 0 finishes tiles 0 - 2, kb 1 tiles 3 - 4).  The next item's runs are loaded into registers in
 // front of the tiles and parked behind them: one workgroup per CU, its memory latency under its own matrix work.
 // (As an instance of the f32 batch-GEMM template of c3d2_tail.hip, Winograd F(2,3) along depth: 1.34 - 1.62 ms per 4 018 cubes.) ----
-constexpr int C32H_PLANE = 160;                               // 10 * 15 = 150 slots per plane, padded to a multiple of 16 (see C31H_PLANE)
-constexpr int C32H_LDS_WORDS = 4 * 16 * C32H_PLANE;           // 40 960 bytes
+// depth pitch 25, not 15: a tile's positions run on from one depth's 9 rows to the next, and with 25 = 9 (mod 16) so do their slots
+// mod 16 (see C22H_DP)
+constexpr int C32H_DP = 25;
+constexpr int C32H_PLANE = 256;                               // 10 * 25 = 250 slots per plane, padded to a multiple of 16 (see C31H_PLANE)
+constexpr int C32H_LDS_WORDS = 4 * 16 * C32H_PLANE;           // 65 536 bytes
 constexpr int C32H_XCH_FLOATS = 8 * 5 * 64 * 4;               // [wave = nt + 4 kb][tile][lane] f32x4: every wave's partial sums
 constexpr int C32H_POS = 8 * 9;                               // 72 positions per item
 
@@ -914,7 +922,7 @@ __global__ __launch_bounds__(512) void c3d2_conv32h_kernel(const Conv32hParams p
       const int e = (int)threadIdx.x + 512 * k;
       const int run = (e * 2185) >> 16, r = e - 30 * run;
       const int d = run >> 3, chunk = run & 7;
-      unsigned* const dst = reg + 4 * (chunk * C32H_PLANE + d * 15 + (r >> 1)) + 2 * (r & 1);
+      unsigned* const dst = reg + 4 * (chunk * C32H_PLANE + d * C32H_DP + (r >> 1)) + 2 * (r & 1);
       unsigned h0, l0, h1, l1;
       split2(__builtin_shufflevector(sv[k], sv[k], 0, 1), h0, l0);
       split2(__builtin_shufflevector(sv[k], sv[k], 2, 3), h1, l1);
@@ -941,10 +949,10 @@ __global__ __launch_bounds__(512) void c3d2_conv32h_kernel(const Conv32hParams p
     for (int t = 0; t < 5; ++t) {
       const int P = min(16 * t + i, C32H_POS - 1);
       const int dq = (P * 7282) >> 16, row = P - 9 * dq;                        // P / 9 for P < 72
-      // input pixel (dq + kd, row + kh), channels 32 kb + 8 kk .. + 7: slot (dq + kd) * 15 + row + kh of plane 4 kb + kk [l: + 8]
-      const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * ((4 * kb + kk) * C32H_PLANE + dq * 15 + row);
+      // input pixel (dq + kd, row + kh), channels 32 kb + 8 kk .. + 7: slot (dq + kd) * 25 + row + kh of plane 4 kb + kk [l: + 8]
+      const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * ((4 * kb + kk) * C32H_PLANE + dq * C32H_DP + row);
       auto rd = [&](int tap, int piece) -> u32x4 {
-        return *reinterpret_cast<const u32x4*>(a2 + 16 * (15 * (tap / 7) + tap % 7) + 16 * 8 * C32H_PLANE * piece);
+        return *reinterpret_cast<const u32x4*>(a2 + 16 * (C32H_DP * (tap / 7) + tap % 7) + 16 * 8 * C32H_PLANE * piece);
       };
       f32x4 a = b4;
       u32x4 bh[2], bl[2];   // (one tap ahead: a second set ahead is eight registers more)
@@ -992,12 +1000,15 @@ __global__ __launch_bounds__(512) void c3d2_conv32h_kernel(const Conv32hParams p
 
 // ---- conv4_1 (64 -> 128, kernel (3,1,3)) + BN + PReLU (model.py:132-135, :165-166) through two-piece f16 products, direct form:
 // 9 taps x two K = 32 blocks x three MFMAs.  Item = ONE CUBE: its whole input [8 d][8 chunks][45 = 9 h x 5 w][8] (92 KB) is split
-// while staged into sixteen planes (eight channel chunks x {h, l}) of 16-byte slots, slot = d * 45 + pixel; outputs 6 d x 9 h x 3 w =
+// while staged into sixteen planes (eight channel chunks x {h, l}) of 16-byte slots, slot = d * 59 + 9 w + h; outputs 6 d x 9 h x 3 w =
 // 162 positions = 10.1 tiles; wave = N tile (eight waves: 128 output channels; 36 weight blocks = 144 VGPRs), every wave walks all
 // eleven tiles.  The next cube is loaded into registers in front of the tiles and parked behind them.
 // (As an instance of the f32 batch-GEMM template of c3d2_tail.hip, Winograd F(2,3) along depth: 0.54 - 0.69 ms per 4 018 cubes.) ----
-constexpr int C41H_PLANE = 368;                               // 8 * 45 = 360 slots per plane, padded to a multiple of 16
-constexpr int C41H_LDS_WORDS = 4 * 16 * C41H_PLANE;           // 94 208 bytes
+// A plane holds [8 d][5 w][9 h] at depth pitch 59: positions are walked (depth, column, row) with the row fastest, 27 per depth, and
+// 59 = 27 (mod 16), so sixteen consecutive positions are sixteen consecutive slots mod 16 at every tap (see C22H_DP)
+constexpr int C41H_DP = 59;
+constexpr int C41H_PLANE = 480;                               // 8 * 59 = 472 slots per plane, padded to a multiple of 16
+constexpr int C41H_LDS_WORDS = 4 * 16 * C41H_PLANE;           // 122 880 bytes
 constexpr int C41H_POS = 6 * 9 * 3;                           // 162 positions per cube
 constexpr int C41H_PIECES = 8 * 8 * 45 * 2;                   // 5 760 sixteen-byte pieces per cube
 
@@ -1048,7 +1059,8 @@ __global__ __launch_bounds__(512) void c3d2_conv41h_kernel(const Conv41hParams p
       const int e = (int)threadIdx.x + 512 * k;
       const int run = (e * 46604) >> 22, r = e - 90 * run;        // e / 90 for e < 5 760
       const int d = run >> 3, chunk = run & 7;
-      unsigned* const dst = reg + 4 * (chunk * C41H_PLANE + d * 45 + (r >> 1)) + 2 * (r & 1);
+      const int pix = r >> 1, ph = (pix * 13) >> 6, pw = pix - 5 * ph;       // pixel = 5 h + w; pix / 5 for pix < 45
+      unsigned* const dst = reg + 4 * (chunk * C41H_PLANE + d * C41H_DP + 9 * pw + ph) + 2 * (r & 1);
       unsigned h0, l0, h1, l1;
       split2(__builtin_shufflevector(sv[k], sv[k], 0, 1), h0, l0);
       split2(__builtin_shufflevector(sv[k], sv[k], 2, 3), h1, l1);
@@ -1071,13 +1083,13 @@ __global__ __launch_bounds__(512) void c3d2_conv41h_kernel(const Conv41hParams p
 #pragma unroll 1
     for (int t = 0; t < (C41H_POS + 15) / 16; ++t) {
       const int P = min(16 * t + i, C41H_POS - 1);
-      const int dq = (P * 2428) >> 16, r27 = P - 27 * dq;                       // P / 27 for P < 162
-      const int h = (r27 * 21846) >> 16, wq = r27 - 3 * h;                      // r27 / 3 for r27 < 27
-      // input pixel (dq + kd, h, wq + kw), channels 32 kb + 8 kk .. + 7: slot (dq + kd) * 45 + 5 h + wq + kw of plane 4 kb + kk [l: + 8]
-      const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * (kk * C41H_PLANE + dq * 45 + 5 * h + wq);
+      const int dq = (P * 2428) >> 16, r27 = P - 27 * dq;                       // P / 27 for P < 162;  r27 = 9 wq + h
+      const int wq = (r27 * 7282) >> 16, h = r27 - 9 * wq;                      // r27 / 9 for r27 < 27
+      // input pixel (dq + kd, h, wq + kw), channels 32 kb + 8 kk .. + 7: slot (dq + kd) * 59 + 9 (wq + kw) + h of plane 4 kb + kk [l: + 8]
+      const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * (kk * C41H_PLANE + dq * C41H_DP + r27);
       auto rd = [&](int st, int piece) -> u32x4 {   // step st = 2 tap + kb
         const int tap = st >> 1, kb = st & 1;
-        return *reinterpret_cast<const u32x4*>(a2 + 16 * (45 * (tap / 3) + tap % 3) + 16 * 4 * C41H_PLANE * kb + 16 * 8 * C41H_PLANE * piece);
+        return *reinterpret_cast<const u32x4*>(a2 + 16 * (C41H_DP * (tap / 3) + 9 * (tap % 3)) + 16 * 4 * C41H_PLANE * kb + 16 * 8 * C41H_PLANE * piece);
       };
       f32x4 a = b4;
       u32x4 bh[2], bl[2];
@@ -1096,7 +1108,7 @@ __global__ __launch_bounds__(512) void c3d2_conv41h_kernel(const Conv41hParams p
         __builtin_amdgcn_sched_barrier(0);
       }
       if (16 * t + i < C41H_POS) {
-        float* const o = p.out + ((((int64_t)item * 6 + dq) * 16 + 2 * nt + (kk >> 1)) * 27 + r27) * 8 + 4 * (kk & 1);
+        float* const o = p.out + ((((int64_t)item * 6 + dq) * 16 + 2 * nt + (kk >> 1)) * 27 + 3 * h + wq) * 8 + 4 * (kk & 1);
         *reinterpret_cast<f32x4*>(o) = prelu4<SLOPE01>(a, sl4);
       }
     }
