@@ -28,7 +28,7 @@ The JSON line also carries
                    of libsvk.so, git HEAD) and whether that differs from the sources this run uses;
   roofline_network -- the same two fractions for EVERY network kernel (stage2 = conv2_1 + conv2_2, conv3_1, conv3_2,
                    conv4_1, conv4_2, fc5) with each one's share of the step; roofline_stage2 = its stage2 row;
-                   each row names its pipe and peak (the first block: f16, the others f32);
+                   each row names its pipe and peak (conv1_1 .. conv4_1: f16, conv4_2 and fc5: f32);
                    valu_per_mfma / fp32_lanes_busy: the other vector instructions per MFMA (committed SQ_INSTS_VALU)
                    and, for the f32 rows, frac x (1 + valu_per_mfma x 4 / 32) -- f32 MFMA and f32 VALU never co-execute on
                    this chip, so this is the share of the SIMDs' FP32 issue slots that is occupied at all (the rest are stalls);
@@ -1125,12 +1125,12 @@ def main():
                              "algorithmic_frac": e2e_tflops / (F32_MATRIX_PEAK_TFLOPS * world),
                              "gflop_per_utt": C3D2_GFLOP_PER_UTT,
                              "note": "whole step.  frac = utterances/s x the time the matrix pipes need, at their dense peaks, for the "
-                                     "MFMA work the network kernels ISSUE per utterance (sum over the roofline_network rows: the "
-                                     "first block on the f16 pipe at 16 x the f32 rate, the others on the f32 pipe; with every "
+                                     "MFMA work the network kernels ISSUE per utterance (sum over the roofline_network rows: "
+                                     "conv1_1 .. conv4_1 on the f16 pipe at 16 x the f32 rate, conv4_2 and FC5 on the f32 pipe; with every "
                                      "kernel on the f32 pipe this is rounds 2 - 4's definition); algorithmic_frac = utterances/s x "
                                      "SURVEY 8(d)'s 676.6 MFLOP of direct-form f32 sums / the f32 matrix peak (ceiling 232 k utt/s "
-                                     "per GPU on that pipe) -- conv2_1 .. conv4_2 run through Winograd F(2,3) along depth and issue "
-                                     "2/3 of theirs, the first block issues 3 f16 products per f32 product at 16 x the rate"},
+                                     "per GPU on that pipe) -- conv4_2 runs through Winograd F(2,3) along depth and issues 2/3 of "
+                                     "its products, conv1_1 .. conv4_1 issue 3 f16 products per f32 product at 16 x the rate"},
             "eer": {"eer": eer, "auc": auc, "eer_device": eer_dev, "auc_device": auc_dev, "pairs": int(labels.size),
                     "short_clips": bad,
                     "note": ("random-init C3D2 (--random-init): an EER near 0.5 is that of an untrained network; the statement is "

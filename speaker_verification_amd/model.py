@@ -1,7 +1,7 @@
 """C3D2 speaker-embedding network (`/root/reference/model.py:104-191`): the PyTorch module -- what checkpoints load
-into and what training differentiates -- and `FusedEmbedder`, its inference form: seven hand-written MFMA kernels of
-libsvk (`svk_c3d2_stage1`, `svk_c3d2_stage2`, `svk_c3d2_conv31`, `svk_c3d2_conv32t`: csrc/c3d2.hip, csrc/c3d2_tail.hip;
-`svk_c3d2_conv41`, `svk_c3d2_conv42`, `svk_c3d2_fc5`: csrc/c3d2_tail.hip).
+into and what training differentiates -- and `FusedEmbedder`, its inference form: seven hand-written MFMA entry points of
+libsvk (`svk_c3d2_stage1`, `svk_c3d2_stage2`, `svk_c3d2_conv31`, `svk_c3d2_conv32t`, `svk_c3d2_conv41`: csrc/c3d2.hip, two-piece
+f16 products; `svk_c3d2_conv42`, `svk_c3d2_fc5`: csrc/c3d2_tail.hip, f32).
 
 Same constructor arguments, same sub-module names (a reference-format checkpoint's `state_dict` loads unchanged), same
 `forward(x, development=True)`, `load_checkpoint(d)` and `create_Speaker_Model(u)` as the reference.  Input convention
