@@ -1802,6 +1802,15 @@ def test_c3d2_tail_kernels(eng):
     # error paths: wrong layouts are refused by the host layer, NULL buffers by the library
     with pytest.raises(ValueError):
         eng.c3d2_conv41(torch.zeros((21, 10, 15, 5, 64), device=eng.device), t41)
+    # ... and so are weight blocks of another layer's shape or dtype (the kernel would read them out of bounds) and short bias / slope rows
+    with pytest.raises(ValueError, match="weight blocks"):
+        eng.c3d2_conv41(xc, (t42[0],) + t41[1:])
+    with pytest.raises(ValueError, match="weight blocks"):
+        eng.c3d2_conv41(xc, (t41[0].float(),) + t41[1:])
+    with pytest.raises(ValueError, match="weight blocks"):
+        eng.c3d2_conv42(eng.c3d2_conv41(xc, t41), (t41[0],) + t42[1:])
+    with pytest.raises(ValueError, match="bias / slope"):
+        eng.c3d2_conv41(xc, (t41[0], t41[1][:64], t41[2], True))
     assert eng.lib.svk_c3d2_conv41(eng.ctx, None, 1, None, None, None, 0, None) == -1
     assert eng.lib.svk_c3d2_conv42(eng.ctx, None, 1, None, None, None, 0, None) == -1
     assert eng.lib.svk_c3d2_fc5(eng.ctx, None, 1, None, None, None, None) == -1
@@ -1809,9 +1818,9 @@ def test_c3d2_tail_kernels(eng):
 
 
 def test_c3d2_conv32_in_the_last_blocks_shape(eng, monkeypatch):
-    """svk_c3d2_conv32t (conv3_2 -> BN -> PReLU, model.py:129-131,162-164, as a GEMM over the batch like conv4_1 / conv4_2:
-    M tile = one output position of 16 cubes, two four-wave workgroups per CU, work items from a device-wide counter) against
-    the same layer on torch-CPU with unfolded BatchNorm: batches of 1, 3, 37 and 700 cubes (880 items on 512 workgroups); the
+    """svk_c3d2_conv32t (conv3_2 -> BN -> PReLU, model.py:129-131,162-164; a per-(cube, column) kernel on the f16 matrix pipe,
+    two waves per N tile splitting K, work items from a device-wide counter one ahead) against
+    the same layer on torch-CPU with unfolded BatchNorm: batches of 1, 3, 37 and 700 cubes (3 500 items on 256 workgroups); the
     column-major chunked output of conv3_1 it stages from; both item assignments."""
     model, emb, state = _net(eng, 95, 96)
     t32t, t31 = emb.conv32t_tables(), emb.conv31_tables()
