@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 111 /* 0.1.11: conv1_1's weight block in the K order [h | l | h | l] (d_w1blk); 0.1.10: svk_c3d2_conv41 on the f16 matrix pipe (half-pair blocks); 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 / svk_c3d2_conv31 / svk_c3d2_conv32t run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
+#define SVK_VERSION 110 /* 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 / svk_c3d2_conv31 / svk_c3d2_conv32t run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -254,9 +254,8 @@ int svk_roc_eer(svk_ctx* ctx, const float* d_scores, const uint8_t* d_labels, in
  * transform's adds do not distribute over pieces), two taps per K = 32 block.  The host folds the BatchNorm statistics into
  * weights / biases, splits the weights and lays them out in the lane order of the MFMA's A operand (lane l = (co = l & 15,
  * kk = l >> 4), eight halves: K = 8 kk + e):
- *   d_w1blk [2][64][8 halves]: conv1_1, element e = tap t = 8 (kk >> 1) + e (t = 5 kd + kw; t = 15 -> 0):
- *                        block 0 = H for every kk, block 1 = L for even kk and 0 for odd kk (the kernel's B operand carries
- *                        [h taps 0-7 | l taps 0-7 | h taps 8-15 | l taps 8-15] along K: since 0.1.11);   d_bias1 [16]
+ *   d_w1blk [2][64][8 halves]: conv1_1, element e = tap t = 8 (kk & 1) + e (t = 5 kd + kw; t = 15 -> 0):
+ *                        block 0 = H for every kk, block 1 = L for kk < 2 and 0 for kk >= 2;   d_bias1 [16]
  *   d_w2blk [14][2][64][8 halves]: conv1_2's tap pairs (a | b): pr < 12 -> a = (kd = pr / 4, kh = 2 (pr % 4)), b = (kd, kh + 1);
  *                        pr = 12 -> (0, 8) | (1, 8); pr = 13 -> (2, 8) | none (zeros).  Element e =
  *                        W2[co][ci = 8 (kk & 1) + e][tap a if kk < 2 else b]; block 0 = H pieces, block 1 = L pieces;

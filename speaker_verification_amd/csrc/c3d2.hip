@@ -62,7 +62,7 @@ struct Stage1Params {
   const float* feat;
   const int32_t* crop;
   int32_t n_utt, max_frames;
-  const u32x4* w1blk;    // [2][64]: conv1_1's A blocks (8 halves per lane, tap 8 (kk >> 1) + e): H for every kk, L for even kk | 0 for odd
+  const u32x4* w1blk;    // [2][64]: conv1_1's A blocks (8 halves per lane): [H taps 0-15 | H taps 0-15], [L taps 0-15 | 0]
   const float* bias1;
   const float* slope1;
   const u32x4* w2blk;    // [14 pairs][2][64]: [H_a | H_b], [L_a | L_b]; lane (co = l & 15, kk): ci = 8 (kk & 1) + e, tap a (kk < 2) / b
@@ -89,7 +89,7 @@ __device__ __forceinline__ int fetch_starts(const Stage1Params& p, ItemPos it, i
   return cr[lane < PD ? lane : 0];
 }
 
-constexpr int WPW = 8;                                     // floats per patch row in LDS: [ww 0 1 2 | - | ww 3 4 5 | -] (rows 4 - 7 of eight: halves swapped)
+constexpr int WPW = 8;                                     // floats per patch row in LDS: [ww 0 1 2 | - | ww 3 4 5 | -]
 constexpr int WP_FLOATS = PD * NFRAME * WPW;               // 7 680
 
 // The item's cube patch by LDS-DMA (global_load_lds_dwordx3; round 3): patch[dd][h][.] = feat[u][crop[u][8 q + dd] + h][2 j ..
@@ -106,15 +106,13 @@ constexpr int WP_FLOATS = PD * NFRAME * WPW;               // 7 680
 // int32) goes the slow way, lane by lane, with zeros outside -- a wave-uniform branch the pipeline's own crops never take.
 struct PatchPiece { const float* src; float* dst; int rows; bool inside; int start, h0; };
 __device__ __forceinline__ void patch_piece_issue(const Stage1Params& p, const PatchPiece& pc, int lane) {
-  // rows 4 - 7 of every eight keep their halves SWAPPED in LDS ([ww 3 4 5 | - | ww 0 1 2 | -]): conv1_1's reads of rows r and r + 4 then
-  // fall into different banks (see there).  A piece starts at a multiple of 32 rows, so the row's bit 2 is rl's
-  const int rl = lane >> 1, half = lane & 1, shalf = half ^ ((rl >> 2) & 1);
+  const int rl = lane >> 1, half = lane & 1;
   if (pc.inside) {
-    if (rl < pc.rows) __builtin_amdgcn_global_load_lds(pc.src + rl * NCOEF + 3 * shalf, pc.dst, 12, 0, 0);
+    if (rl < pc.rows) __builtin_amdgcn_global_load_lds(pc.src + rl * NCOEF + 3 * half, pc.dst, 12, 0, 0);
   } else if (rl < pc.rows) {
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;
     if ((unsigned)pc.start < (unsigned)p.max_frames && pc.h0 + rl < p.max_frames - pc.start) {
-      const float* src = pc.src + rl * NCOEF + 3 * shalf;
+      const float* src = pc.src + rl * NCOEF + 3 * half;
       v0 = src[0];
       v1 = src[1];
       v2 = src[2];
@@ -297,23 +295,19 @@ __global__ __launch_bounds__(512) void c3d2_stage1h_kernel(const Stage1Params p)
 
     // ---- (1) conv1_1 + PReLU -> act1 as (h, l): 100 tiles of 16 pixels, tile tt = wave + 8 m ----
     {
-      // B = [h taps 0-7 | l taps 0-7 | h taps 8-15 | l taps 8-15] by kk; tap t = (kd, kw) = (t / 5, t % 5), t = 15: the zero column.
-      // The two K quarters of an LDS lane group (lanes 0 - 31: kk 0, 1) read the SAME words -- sixteen addresses per group, one for
-      // every pixel of the tile -- and rows 4 - 7 of a tile keep their two halves swapped in LDS (patch_piece_issue), so these land
-      // in sixteen different banks: one LDS cycle per group and read, where [h | h | l | l] took two (32 addresses on 24 banks)
+      // B = [h taps 0-7 | h taps 8-15 | l taps 0-7 | l taps 8-15] by kk; tap t = (kd, kw) = (t / 5, t % 5), t = 15: the zero column
       const unsigned* pw[8];
       const unsigned* const pbase = reinterpret_cast<const unsigned*>(patch) + 8 * WPW * wave + (i >> 1) * WPW;
-      const int swp = 4 * ((i >> 3) & 1);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int t0 = e, t1 = 8 + e;                                  // kk >> 1 = 0 / 1
+        const int t0 = e, t1 = 8 + e;                                  // kk & 1 = 0 / 1
         const int o0 = (t0 / 5) * (NFRAME * WPW), c0 = t0 % 5;
         const int o1 = t1 < 15 ? (t1 / 5) * (NFRAME * WPW) : 0, c1 = t1 < 15 ? t1 % 5 : 0;
         const int colA = (i & 1) + c0, colB = (i & 1) + c1;
-        const int offA = o0 + ((colA + (colA >= 3 ? 1 : 0)) ^ swp), offB = o1 + ((colB + (colB >= 3 ? 1 : 0)) ^ swp);
-        pw[e] = pbase + ((kk >> 1) ? offB : offA);
+        const int offA = o0 + colA + (colA >= 3 ? 1 : 0), offB = o1 + colB + (colB >= 3 ? 1 : 0);
+        pw[e] = pbase + ((kk & 1) ? offB : offA);
       }
-      const unsigned sel = (kk & 1) == 0 ? 0x05040100u : 0x07060302u;  // the h halves / the l halves of two words
+      const unsigned sel = kk < 2 ? 0x05040100u : 0x07060302u;         // the h halves / the l halves of two words
       // pixel 16 tt + i = (dd = tt / 10, r = 8 (tt % 10) + (i >> 1), col = i & 1): slot 8 tt + 2 (i >> 2) + (i & 1) of the plane
       // (quarter kk >> 1 [+ 2 for l], parity (i >> 1) & 1); the lane's four channels are bytes 8 (kk & 1) .. + 7 of the slot
       unsigned* const aw = act + 4 * ((((kk >> 1) * 2 + ((i >> 1) & 1)) * HPLANE) + 8 * wave + 2 * (i >> 2) + (i & 1)) + 2 * (kk & 1);

@@ -204,8 +204,7 @@ class FusedEmbedder:
         conv1_2 split into halves H = f16(w), L = f16(w - H) and laid out in the lane order of v_mfma_f32_16x16x32_f16's A
         operand (lane l = (co = l & 15, kk = l >> 4), eight halves: K = 8 kk + e), or None when the first block is not C3D2's
         (1 -> 16 k(3,1,5); 16 -> 16 k(3,9,1) stride (1,2,1); pool).
-          w1blk [2][64][8]      : conv1_1, tap t = 8 (kk >> 1) + e (t = 5 kd + kw; 15 -> 0): H for every kk | L for even kk, 0 for odd kk
-                                  (the B operand carries [h taps 0-7 | l taps 0-7 | h taps 8-15 | l taps 8-15] along K)
+          w1blk [2][64][8]      : conv1_1, tap t = 8 (kk & 1) + e (t = 5 kd + kw; 15 -> 0): H for every kk | L for kk < 2, 0 above
           w2blk [14][2][64][8]  : conv1_2, tap pairs (a | b): ci = 8 (kk & 1) + e at tap a (kk < 2) / b (kk >= 2); H | L"""
         hit = getattr(self, "_stage1", False)
         if hit is not False:
@@ -225,9 +224,9 @@ class FusedEmbedder:
         co, kk = lane & 15, lane >> 4
         e = torch.arange(8, device=dev)
         w1c = torch.cat([w1.contiguous().view(16, 15), torch.zeros((16, 1), device=dev)], 1)     # [co][t], t = 15: zero
-        t = 8 * (kk >> 1)[:, None] + e[None, :]                                                   # [64][8]
+        t = 8 * (kk & 1)[:, None] + e[None, :]                                                    # [64][8]
         h1, l1 = halves(w1c[co[:, None], t])
-        w1blk = torch.stack([h1, torch.where(((kk & 1) == 0)[:, None], l1, torch.zeros_like(l1))])   # [2][64][8]
+        w1blk = torch.stack([h1, torch.where((kk < 2)[:, None], l1, torch.zeros_like(l1))])       # [2][64][8]
         w2c = w2.contiguous()[:, :, :, :, 0]                                                      # [co][ci][kd][kh]
         pairs = [((p // 4, 2 * (p % 4)), (p // 4, 2 * (p % 4) + 1)) for p in range(12)] + [((0, 8), (1, 8)), ((2, 8), None)]
         ci = 8 * (kk & 1)[:, None] + e[None, :]

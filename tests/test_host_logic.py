@@ -267,11 +267,11 @@ def test_half_pair_weight_blocks_against_naive_indexing():
     for _ in range(400):
         lane, el = rnd.randrange(64), rnd.randrange(8)
         co, kk = lane & 15, lane >> 4
-        t = 8 * (kk >> 1) + el                                       # conv1_1: tap t = 5 kd + kw, 15 = the zero column
+        t = 8 * (kk & 1) + el                                        # conv1_1: tap t = 5 kd + kw, 15 = the zero column
         want = float(w1[co, 0, t // 5, 0, t % 5]) if t < 15 else 0.0
         assert float(w1blk[0, lane, el]) == float(torch.tensor(want).to(torch.float16))
-        if kk & 1:
-            assert float(w1blk[1, lane, el]) == 0.0                  # the L block multiplies the h halves of the patch only
+        if kk >= 2:
+            assert float(w1blk[1, lane, el]) == 0.0                  # the L block multiplies the h half of the patch only
         else:
             check(w1blk[:, lane, el], want)
         pr = rnd.randrange(14)
