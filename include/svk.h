@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 110 /* 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 / svk_c3d2_conv31 / svk_c3d2_conv32t run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
+#define SVK_VERSION 111 /* 0.1.9: conv1_2's last tap as ONE [h | l] fragment (d_w2blk pair 13 = [H | H], [L | 0]: 41 MFMAs per tile, not 42); half-pair domain stated; 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 / svk_c3d2_conv31 / svk_c3d2_conv32t run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -257,9 +257,16 @@ int svk_roc_eer(svk_ctx* ctx, const float* d_scores, const uint8_t* d_labels, in
  *   d_w1blk [2][64][8 halves]: conv1_1, element e = tap t = 8 (kk & 1) + e (t = 5 kd + kw; t = 15 -> 0):
  *                        block 0 = H for every kk, block 1 = L for kk < 2 and 0 for kk >= 2;   d_bias1 [16]
  *   d_w2blk [14][2][64][8 halves]: conv1_2's tap pairs (a | b): pr < 12 -> a = (kd = pr / 4, kh = 2 (pr % 4)), b = (kd, kh + 1);
- *                        pr = 12 -> (0, 8) | (1, 8); pr = 13 -> (2, 8) | none (zeros).  Element e =
- *                        W2[co][ci = 8 (kk & 1) + e][tap a if kk < 2 else b]; block 0 = H pieces, block 1 = L pieces;
+ *                        pr = 12 -> (0, 8) | (1, 8).  Element e = W2[co][ci = 8 (kk & 1) + e][tap a if kk < 2 else b];
+ *                        block 0 = H pieces, block 1 = L pieces.  pr = 13 is the last tap (2, 8) ALONE, which the kernel reads
+ *                        as one [h | l] fragment: block 0 = its H pieces at every kk, block 1 = its L pieces for kk < 2, 0 above;
  *                        d_bias2 [16];   d_slope1 / d_slope2 [16] PReLU slopes per channel
+ * DOMAIN of the half-pair kernels (this one, svk_c3d2_stage2 / conv31 / conv32t / conv41): a value carries 22 significant bits
+ * while |x| >= 2^-3, an absolute error floor of 2^-25 below that, and must stay under 65 504 (an f16's largest finite value; the
+ * reference's features -- log mel energies, MFCCs, CMVN output -- are within +-100).  Weights have the same floor, which is why
+ * the host fixes every channel's scale before it splits them (model.FusedEmbedder: activations of channel c are carried times
+ * the power of two nearest 1 / (|gamma_c| + |beta_c|) of its BatchNorm, the next layer's weights take the inverse: exact, and
+ * the tables no longer depend on how a checkpoint distributes a channel's scale between one layer and the next).
  * d_feat [n_utt][max_frames][40] f32, d_crop_idx [n_utt][20] as for svk_cube_gather (a start outside the clip -> zero rows).
  * d_out: the activation after the pool, float32, channels last: [n_utt][16 d][36 h][18 w][16 c]
  * flags bit 1 (value 2) = the caller asserts every PReLU slope lies in [0, 1] (then prelu(v) = max(v, slope v): two

@@ -65,7 +65,8 @@ struct Stage1Params {
   const u32x4* w1blk;    // [2][64]: conv1_1's A blocks (8 halves per lane): [H taps 0-15 | H taps 0-15], [L taps 0-15 | 0]
   const float* bias1;
   const float* slope1;
-  const u32x4* w2blk;    // [14 pairs][2][64]: [H_a | H_b], [L_a | L_b]; lane (co = l & 15, kk): ci = 8 (kk & 1) + e, tap a (kk < 2) / b
+  const u32x4* w2blk;    // [14 pairs][2][64]: [H_a | H_b], [L_a | L_b]; lane (co = l & 15, kk): ci = 8 (kk & 1) + e, tap a (kk < 2) / b;
+                         // pair 13 (one tap): [H_a | H_a], [L_a | 0]
   const float* bias2;
   const float* slope2;
   float* out;
@@ -368,9 +369,12 @@ __global__ __launch_bounds__(512) void c3d2_stage1h_kernel(const Stage1Params p)
         const char* const a2 = reinterpret_cast<const char*>(act) + base + (kk >= 2 ? 16 * HPLANE : 0);
         const char* const a3 = reinterpret_cast<const char*>(act) + base + (kk >= 2 ? 16 * 80 : 0);
         f32x4 acc = b2v;
-        // pair pr: 0 .. 11 = (kd = pr / 4, kh = 2 (pr % 4) | + 1) off a2; 12 = taps (0, 8) | (1, 8) off a3; 13 = tap (2, 8) | none
+        // pair pr: 0 .. 11 = (kd = pr / 4, kh = 2 (pr % 4) | + 1) off a2; 12 = taps (0, 8) | (1, 8) off a3; 13 = the LAST tap (2, 8)
+        // alone, as [h | l] in ONE fragment (lanes kk >= 2 read the l planes): [H | H] x [h | l] + [L | 0] x [h | l] are its three
+        // piece products in two MFMAs and one read, where [h | -] and [l | -] against [H | 0], [L | 0] were three and two
         auto rd = [&](int pr, int piece) -> u32x4 {
-          const char* ad = pr < 12 ? a2 + 1280 * (pr / 4) + 32 * (pr % 4) : pr == 12 ? a3 + 32 * 4 : a3 + 2 * 1280 + 32 * 4 - (kk >= 2 ? 16 * 80 : 0);
+          const char* ad = pr < 12 ? a2 + 1280 * (pr / 4) + 32 * (pr % 4) : pr == 12 ? a3 + 32 * 4
+                                   : a3 + 2 * 1280 + 32 * 4 + (kk >= 2 ? 16 * 4 * HPLANE - 16 * 80 : 0);
           return *reinterpret_cast<const u32x4*>(ad + 16 * 4 * HPLANE * piece);
         };
         // fragments TWO pairs ahead (three rotating sets): a pair is 48 cycles of MFMA, less than an LDS round trip
@@ -383,11 +387,12 @@ __global__ __launch_bounds__(512) void c3d2_stage1h_kernel(const Stage1Params p)
         for (int pr = 0; pr < HPAIRS; ++pr) {
           if (pr + 2 < HPAIRS) {
             bh[(pr + 2) % 3] = rd(pr + 2, 0);
-            bl[(pr + 2) % 3] = rd(pr + 2, 1);
+            if (pr + 2 < HPAIRS - 1) bl[(pr + 2) % 3] = rd(pr + 2, 1);
           }
           __builtin_amdgcn_sched_barrier(0);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][0]), __builtin_bit_cast(f16x8, bh[pr % 3]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][0]), __builtin_bit_cast(f16x8, bl[pr % 3]), acc, 0, 0, 0);
+          if (pr < HPAIRS - 1)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][0]), __builtin_bit_cast(f16x8, bl[pr % 3]), acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W2[pr][1]), __builtin_bit_cast(f16x8, bh[pr % 3]), acc, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }

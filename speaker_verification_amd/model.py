@@ -128,17 +128,42 @@ class FusedEmbedder:
         self.device = model.conv1_1.weight.device       # tables are built where the weights live; kernels need the GPU
         self._eng = None
         self.stages = []
+        self.act_scale = []     # per layer: the power of two per channel its output is carried in (all ones for an ordinary checkpoint)
         with torch.no_grad():
+            s_in = None
             for tag, _, _, _, stride, pool in _LAYERS:
                 conv = getattr(model, "conv" + tag)
                 bn = getattr(model, "batch_norm" + tag)
                 act = getattr(model, "PReLu" + tag)
                 scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-                w = (conv.weight * scale.view(-1, 1, 1, 1, 1)).contiguous()
-                b = ((conv.bias - bn.running_mean) * scale + bn.bias).contiguous()
-                self.stages.append((w, b, act.weight.detach().clone(), tuple(conv.stride), pool, False))
+                w = conv.weight * scale.view(-1, 1, 1, 1, 1)
+                b = (conv.bias - bn.running_mean) * scale + bn.bias
+                # Activations travel as half pairs (include/svk.h): 22 bits while a value's pieces are normal halves, an absolute
+                # floor of 2^-25 below 2^-3 and nothing above 65 504.  A network is the same function when channel c of a layer is
+                # scaled by a > 0 (its BatchNorm's gamma and beta times a -- PReLU and the pools are positively homogeneous) and
+                # the next layer's weights on that channel by 1 / a; the pieces are not.  So the channel's scale is FIXED here: its
+                # activations are carried times 2^k with k = -round(log2(|gamma| + |beta|)) (the channel's spread and offset
+                # behind BatchNorm), the next layer takes 2^-k into its weights -- exact in f32, k = 0 for every channel of a
+                # checkpoint trained from PyTorch's initialisation, and FC5 takes the last layer's.
+                # (round(log2 m) from m's own exponent and mantissa: the same k shift for m and 2^j m, whatever log2 rounds to)
+                mant, expo = torch.frexp((bn.weight.abs() + bn.bias.abs()).float().clamp(min=2.0 ** -40, max=2.0 ** 40))
+                k = -(expo - (mant < 0.5 ** 0.5).to(expo.dtype))
+                s_out = torch.exp2(k.to(torch.float32))
+                w = w * s_out.view(-1, 1, 1, 1, 1)
+                b = b * s_out
+                if s_in is not None:
+                    w = w / s_in.view(1, -1, 1, 1, 1)
+                self.stages.append((w.contiguous(), b.contiguous(), act.weight.detach().clone(), tuple(conv.stride), pool, False))
+                self.act_scale.append(s_out)
+                s_in = s_out
             self.fc_w = model.FC5.weight.detach().clone()
+            if self.fc_w.shape[1] % s_in.numel() == 0:       # model.py:168 flattens NCDHW: column = channel * positions + position
+                self.fc_w = (self.fc_w.view(self.fc_w.shape[0], s_in.numel(), -1) / s_in.view(1, -1, 1)).reshape(self.fc_w.shape).contiguous()
             self.fc_b = model.FC5.bias.detach().clone()
+            for w, b, *_ in self.stages:
+                if not (bool(torch.isfinite(w).all()) and bool(torch.isfinite(b).all()) and float(w.abs().max()) < 65504.0):
+                    raise ValueError("a BatchNorm-folded weight of this checkpoint is not finite or exceeds 65 504: outside what "
+                                     "libsvk's half-pair operands represent")
         tables = (self.stage1_tables(), self.stage2_tables(), self.conv31_tables(), self.conv32t_tables(),
                   self.conv41_tables(), self.conv42_tables(), self.fc5_tables())
         if any(t is None for t in tables):
@@ -189,6 +214,9 @@ class FusedEmbedder:
             raise ValueError("expected cubes of shape (n, 1, 20, 80, 40), got %s" % (tuple(cubes.shape),))
         x = self.eng.to_device(cubes, torch.float32)
         n = x.shape[0]
+        if n and not float(x.abs().max()) < 65504.0:      # (this per-call surface only: the batched pipeline feeds its own features)
+            raise ValueError("cube values must be finite and below 65 504 in magnitude (the half-pair kernels' domain, include/svk.h); "
+                             "the reference's features are log energies / MFCCs within +-100")
         rows = x.view(n, CUBE_SHAPE[1] * CUBE_SHAPE[2], CUBE_SHAPE[3])
         if n <= batch:
             return self.embed_features(rows, self.crop_starts(n, x.device)) if n else x.new_empty((0, EMBED_DIM))
@@ -205,7 +233,8 @@ class FusedEmbedder:
         operand (lane l = (co = l & 15, kk = l >> 4), eight halves: K = 8 kk + e), or None when the first block is not C3D2's
         (1 -> 16 k(3,1,5); 16 -> 16 k(3,9,1) stride (1,2,1); pool).
           w1blk [2][64][8]      : conv1_1, tap t = 8 (kk & 1) + e (t = 5 kd + kw; 15 -> 0): H for every kk | L for kk < 2, 0 above
-          w2blk [14][2][64][8]  : conv1_2, tap pairs (a | b): ci = 8 (kk & 1) + e at tap a (kk < 2) / b (kk >= 2); H | L"""
+          w2blk [14][2][64][8]  : conv1_2, tap pairs (a | b): ci = 8 (kk & 1) + e at tap a (kk < 2) / b (kk >= 2); H | L;
+                                  pair 13 is tap (2, 8) alone against an [h | l] fragment: H at every kk | L for kk < 2, 0 above"""
         hit = getattr(self, "_stage1", False)
         if hit is not False:
             return hit
@@ -233,8 +262,11 @@ class FusedEmbedder:
         w2blk = torch.zeros((14, 2, 64, 8), dtype=torch.float16, device=dev)
         for p, (ta, tb) in enumerate(pairs):
             wa = w2c[co[:, None], ci, ta[0], ta[1]]
-            wb = w2c[co[:, None], ci, tb[0], tb[1]] if tb is not None else torch.zeros_like(wa)
-            h, l = halves(torch.where((kk < 2)[:, None], wa, wb))
+            if tb is None:       # the last tap alone: the kernel reads it as [h | l], so H for every kk and L against the h half only
+                h, l = halves(wa)
+                l = torch.where((kk < 2)[:, None], l, torch.zeros_like(l))
+            else:
+                h, l = halves(torch.where((kk < 2)[:, None], wa, w2c[co[:, None], ci, tb[0], tb[1]]))
             w2blk[p, 0], w2blk[p, 1] = h, l
         slope01 = bool(((s1 >= 0) & (s1 <= 1)).all() and ((s2 >= 0) & (s2 <= 1)).all())   # one host read per checkpoint
         self._stage1 = (w1blk.contiguous(), b1.contiguous(),

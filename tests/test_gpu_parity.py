@@ -1680,6 +1680,45 @@ def test_reference_call_surface_runs_the_libsvk_network(eng):
     assert torch.equal(emb(many, batch=32), emb(many))
 
 
+def test_network_is_indifferent_to_a_checkpoints_channel_scales(eng):
+    """model.py:141-169 is the same function when a checkpoint carries channel c of a layer a > 0 times larger (BatchNorm's gamma,
+    beta) and the next layer's weights on it a times smaller; the half pairs the kernels multiply are not (floor 2^-25, ceiling
+    65 504).  A network regauged by a = 10^-3 .. 10^3 per channel on every layer -- activations up to ~10^5 and weights down to
+    ~10^-5 as the checkpoint states them -- gives the ORIGINAL network's embeddings (torch-CPU f32, unfolded BatchNorm) at the
+    end-to-end bar, through C3D2.forward on the device; and its first block's output is the original's in the units `act_scale`
+    names.  (FusedEmbedder fixes every channel's power of two before it splits weights: tests/test_host_logic.py has the exact,
+    CPU-side statement for powers of two.)"""
+    from speaker_verification_amd.model import _LAYERS
+    from test_host_logic import _regauged
+    model, emb, state = _net(eng, 61, 62)
+    gen = torch.Generator().manual_seed(9)
+    alphas = [torch.pow(10.0, 6.0 * torch.rand((t[2],), generator=gen) - 3.0) for t in _LAYERS]
+    other = _regauged(model, alphas).eval()
+    rng = np.random.default_rng(4)
+    cubes = torch.from_numpy((rng.standard_normal((6, 1, 20, 80, 40)) * 2.0 - 1.0).astype(np.float32))
+    with torch.no_grad():
+        want = model.cpu().torch_layers(cubes).numpy()                          # the original network on torch-CPU
+        model.to(eng.device)
+        assert other.runs_on_kernels(cubes.to(eng.device))
+        got = other(cubes.to(eng.device), development=False).cpu().numpy()      # the regauged one through the kernels
+        base = model(cubes.to(eng.device), development=False).cpu().numpy()
+    scale = np.abs(want).max()
+    print("regauged network: max |diff| / scale %.2e (original through the kernels: %.2e)"
+          % (np.abs(got - want).max() / scale, np.abs(base - want).max() / scale))
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=5e-5 * scale)
+    np.testing.assert_allclose(got, base, rtol=1e-4, atol=2e-5 * scale)
+    e2 = other.fused_inference()
+    rows = cubes.to(eng.device).view(6, 1600, 40)
+    y1 = eng.c3d2_stage1(rows, emb.crop_starts(6, eng.device), emb.stage1_tables())
+    y2 = eng.c3d2_stage1(rows, e2.crop_starts(6, eng.device), e2.stage1_tables()) / e2.act_scale[1].to(eng.device)
+    # (y1 itself is in the original's units only if its own channel scales are one, which perturb_inference_state's BatchNorm gives)
+    assert all(bool((s == 1).all()) for s in emb.act_scale)
+    ref = y1 * alphas[1].to(eng.device)
+    np.testing.assert_allclose(y2.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=4e-6 * float(ref.abs().max()))
+    with pytest.raises(ValueError, match="65 504"):
+        model(cubes.to(eng.device) * 1e5, development=False)                    # outside the half pairs' domain: refused, not wrong
+
+
 def test_c3d2_second_block_kernels(eng):
     """svk_c3d2_stage2 (conv2_1 -> BN -> PReLU -> conv2_2 -> BN -> PReLU -> pool2, model.py:119-124,151-158, both through the
     depth transform) against the same layers on torch-CPU with unfolded BatchNorm, on a random activation in stage 1's
@@ -1965,7 +2004,7 @@ def test_bench_two_ranks_share_one_gpu():
         # frac = issued MFMA work / time / peak: a utilisation, never above 1; algorithmic_frac (SURVEY 8(d)'s direct-form
         # multiply-adds) may pass it -- and 1 -- where the depth transform issues 2/3 of the products
         assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"]) and 0.05 < roof["frac"] < 1.0
-        assert roof["algorithmic_frac"] > roof["frac"] and roof["mfma_per_cube"] == pytest.approx(36 * (200 + 36 * 42), rel=1e-3)
+        assert roof["algorithmic_frac"] > roof["frac"] and roof["mfma_per_cube"] == pytest.approx(36 * (200 + 36 * 41), rel=1e-3)
         assert "c3d2_stage1h_kernel" in roof["kernel"] and roof["avg_launch_ms"] > 0
         # the counters behind frac are tied to the kernel sources they were collected from
         assert set(roof["this_run"]) == {"csrc_sha", "libsvk_sha"} and roof["stale"] in (True, False, None)
@@ -1980,8 +2019,8 @@ def test_bench_two_ranks_share_one_gpu():
                 assert 0.0 < row["frac"] < 1.0 and row["mfma_per_cube"] == pytest.approx(row["mfma_per_cube_by_construction"], rel=1e-3), name
                 # MFMA + the vector instructions that cannot overlap it: still a share of the SIMDs' FP32 issue slots
                 assert row["fp32_lanes_busy"] is None or row["frac"] < row["fp32_lanes_busy"] < 1.0, name
-        # issued per utterance: conv1_1 .. conv4_1: 61 632 + 41 364 + 5 400 + 12 600 + 4 752 f16 MFMAs of 16 384 FLOP; conv4_2, FC5: 8 640 f32 MFMAs of 2 048
-        assert rec["roofline_e2e"]["frac"] < 1.0 and rec["roofline_e2e"]["issued_gflop_per_utt"] == pytest.approx(2.077950, rel=1e-3)
+        # issued per utterance: conv1_1 .. conv4_1: 60 336 + 41 364 + 5 400 + 12 600 + 4 752 f16 MFMAs of 16 384 FLOP; conv4_2, FC5: 8 640 f32 MFMAs of 2 048
+        assert rec["roofline_e2e"]["frac"] < 1.0 and rec["roofline_e2e"]["issued_gflop_per_utt"] == pytest.approx(2.056717, rel=1e-3)
         assert rec["roofline_frontend"]["bound"] == "hbm" and rec["roofline_e2e"]["bound"] == "mfma"
 
 

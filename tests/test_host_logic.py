@@ -275,9 +275,12 @@ def test_half_pair_weight_blocks_against_naive_indexing():
         else:
             check(w1blk[:, lane, el], want)
         pr = rnd.randrange(14)
+        if pr == 13 and kk >= 2:                                     # the last tap alone, read as [h | l]: H again, L = 0 against the l half
+            want = float(w2[co, 8 * (kk & 1) + el, 2, 8, 0])
+            assert float(w2blk[13, 0, lane, el]) == float(torch.tensor(want).to(torch.float16)) and float(w2blk[13, 1, lane, el]) == 0.0
+            continue
         tap = pairs[pr][0] if kk < 2 else pairs[pr][1]
-        want = float(w2[co, 8 * (kk & 1) + el, tap[0], tap[1], 0]) if tap is not None else 0.0
-        check(w2blk[pr, :, lane, el], want)
+        check(w2blk[pr, :, lane, el], float(w2[co, 8 * (kk & 1) + el, tap[0], tap[1], 0]))
     w21blk, _, _, w22blk = e.stage2_tables()[:4]
     w21, w22 = e.stages[2][0], e.stages[3][0]
     assert tuple(w21blk.shape) == (2, 6, 2, 64, 8) and tuple(w22blk.shape) == (2, 24, 2, 64, 8)
@@ -298,6 +301,54 @@ def test_half_pair_weight_blocks_against_naive_indexing():
         check(w32blk[nt, kb, tap, :, lane, el], float(w32[16 * nt + co, 32 * kb + 8 * kk + el, tap // 7, tap % 7, 0]))
         nt, tap = rnd.randrange(8), rnd.randrange(9)
         check(w41blk[nt, tap, kb, :, lane, el], float(w41[16 * nt + co, 32 * kb + 8 * kk + el, tap // 3, 0, tap % 3]))
+
+
+def _regauged(model, alphas):
+    """The same function with channel c of layer l carried times alphas[l][c] > 0: BatchNorm's gamma and beta times a (PReLU and the
+    pools are positively homogeneous), the next layer's weights on that channel (FC5's columns for the last) divided by it."""
+    import copy
+    import torch
+    from speaker_verification_amd.model import _LAYERS
+    m2 = copy.deepcopy(model)
+    tags = [t[0] for t in _LAYERS]
+    with torch.no_grad():
+        for li, tag in enumerate(tags):
+            bn, a = getattr(m2, "batch_norm" + tag), alphas[li].to(m2.FC5.weight.device)
+            bn.weight.mul_(a)
+            bn.bias.mul_(a)
+            if li + 1 < len(tags):
+                getattr(m2, "conv" + tags[li + 1]).weight.div_(a.view(1, -1, 1, 1, 1))
+            else:
+                m2.FC5.weight.copy_((m2.FC5.weight.view(128, a.numel(), -1) / a.view(1, -1, 1)).reshape(128, -1))
+    return m2
+
+
+def test_tables_do_not_depend_on_how_a_checkpoint_scales_its_channels():
+    """Half pairs have an absolute floor (2^-25) and a ceiling (65 504) where f32 has neither in reach, and a checkpoint is free to
+    carry a channel 4 096 times larger with the next layer's weights 4 096 times smaller.  FusedEmbedder fixes each channel's power
+    of two from its BatchNorm before it splits the weights: the same network regauged by powers of two (2^-12 .. 2^12 per channel,
+    every layer) yields the SAME operand tables bit for bit -- so the same embeddings --, and `act_scale` records the units."""
+    import torch
+    from speaker_verification_amd.model import FusedEmbedder, _LAYERS, perturb_inference_state, seeded_model
+    m = seeded_model(5, 8)
+    m.load_state_dict(perturb_inference_state(m.state_dict(), 6))
+    m.eval()
+    gen = torch.Generator().manual_seed(1)
+    alphas = [torch.exp2(torch.randint(-12, 13, (t[2],), generator=gen).float()) for t in _LAYERS]
+    m2 = _regauged(m, alphas)
+    x = torch.randn(2, 1, 20, 80, 40, generator=gen)
+    with torch.no_grad():
+        assert torch.equal(m.torch_layers(x), m2.torch_layers(x))          # the same function (powers of two: exactly)
+    e1, e2 = FusedEmbedder(m), FusedEmbedder(m2)
+    assert all(bool((s == 1).all()) for s in e1.act_scale)                  # an ordinary checkpoint: nothing is rescaled
+    for a, s1, s2 in zip(alphas, e1.act_scale, e2.act_scale):
+        assert torch.equal(s2 * a, s1)                                      # carried times 1 / a
+    for name in ("stage1_tables", "stage2_tables", "conv31_tables", "conv32t_tables", "conv41_tables", "conv42_tables", "fc5_tables"):
+        for t1, t2 in zip(getattr(e1, name)(), getattr(e2, name)()):
+            assert torch.equal(t1, t2) if torch.is_tensor(t1) else t1 == t2, name
+    # without the fix the regauged conv1_2 weights would sit at the halves' floor: up to 2^12 x 2^12 between neighbouring columns
+    w = m2.conv1_2.weight.detach()
+    assert float(w.abs().amax(dim=(0, 2, 3, 4)).min()) < 2.0 ** -9
 
 
 def test_upload_groups_of_a_host_arena():
