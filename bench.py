@@ -78,7 +78,7 @@ F16_MFMA_FLOP = 16384            # v_mfma_f32_16x16x32_f16: 16 x 16 x 32 multipl
 # that pipe's FLOP per MFMA and peak; the others the f32 pipe's.
 NETWORK_KERNELS = (
     ("stage1", ("c3d2_stage1h_kernel",), 12.4416 + 143.327232, 36 * (100 * 2 + 36 * 41), F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # 36 items x (100 conv1_1 tiles x 2 + 36 conv1_2 tiles x (13 tap pairs x 3 + the last tap x 2))
-    ("stage2", ("c3d2_conv21h_kernel", "c3d2_conv22h_kernel"), 46.44864 + 66.3552, 9 * 53 * 36 + 21 * 8 * 2 * 72, F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # conv2_1: 9 items x 53 tiles x 6 pairs x 3 x 2 N tiles; conv2_2: 21 items x 8 tiles x 2 N tiles x 24 taps x 3
+    ("stage2", ("c3d2_conv21h_kernel", "c3d2_conv22h_kernel"), 46.44864 + 66.3552, 9 * 49 * 36 + 21 * 8 * 2 * 72, F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # conv2_1: 9 items x 49 tiles (14 of 15 columns: pool2 kills the last) x 6 pairs x 3 x 2 N tiles; conv2_2: 21 items x 8 tiles x 2 N tiles x 24 taps x 3
     ("conv3_1", ("c3d2_conv31h_kernel",), 13.824, 5 * 10 * 4 * 27, F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # 5 items x 10 tiles x 4 N tiles x 9 taps x 3
     ("conv3_2", ("c3d2_conv32h_kernel",), 30.96576, 5 * 5 * 4 * 126, F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # 5 items x 5 tiles x 4 N tiles x 21 taps x 2 K blocks x 3
     ("conv4_1", ("c3d2_conv41h_kernel",), 11.943936, 11 * 8 * 54, F16_MFMA_FLOP, F16_MATRIX_PEAK_TFLOPS),   # 11 tiles x 8 N tiles x 9 taps x 2 K blocks x 3

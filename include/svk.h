@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVK_VERSION 111 /* 0.1.9: conv1_2's last tap as ONE [h | l] fragment (d_w2blk pair 13 = [H | H], [L | 0]: 41 MFMAs per tile, not 42); half-pair domain stated; 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 / svk_c3d2_conv31 / svk_c3d2_conv32t run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
+#define SVK_VERSION 111 /* 0.1.9: conv1_2's last tap as ONE [h | l] fragment (d_w2blk pair 13 = [H | H], [L | 0]: 41 MFMAs per tile, not 42), conv2_1 leaves out the column pool2 makes dead (d_act2 [..][14][32]); half-pair domain stated; 0.1.8: svk_c3d2_stage1 / svk_c3d2_stage2 / svk_c3d2_conv31 / svk_c3d2_conv32t run on the f16 matrix pipe through two-piece products (new weight tables: half-pair blocks); 0.1.7: gathered front-end input (svk_vad_energy d_src_frame -> svk_frontend_run d_src_chunk); 0.1.6: one kernel per network layer (svk_c3d2_conv32, svk_bias_prelu, svk_cube_gather_windows and the direct-form flag bits are gone); + svk_cmvn_stats, svk_cube_gather_cmvn */
 
 typedef enum svk_status {
   SVK_OK = 0,
@@ -287,7 +287,9 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
  *            W[co][ci = 8 (kk & 1) + e][kd][kw + (kk >= 2)] of the tap pair 2 kd + kw / 2 (kw = 0, 2); block 0 = H, 1 = L
  *   d_w22blk [2 nt][24 taps][2][64][8 halves]: conv2_2, element e = W[co][ci = 8 kk + e][kd][kh], tap = 8 kd + kh; H | L
  *   d_bias / d_slope [32] per layer (BN folded; PReLU slope per channel)
- *   d_act2   [n_utt][14][36][15][32]  conv2_1's activation (scratch, f32);  d_out [n_utt][12][15][7][32] (channels last)
+ *   d_act2   [n_utt][14][36][14][32]  conv2_1's activation (scratch, f32): 14 of the layer's 15 columns -- conv2_2 is one column
+ *            wide and pool2 drops its 15th, so conv2_1's 15th is never read and (since 0.1.9) never computed;
+ *   d_out    [n_utt][12][15][7][32] (channels last)
  * flags as for svk_c3d2_stage1. */
 int svk_c3d2_stage2(svk_ctx* ctx, const float* d_in, int32_t n_utt, const void* d_w21blk, const float* d_bias21,
                     const float* d_slope21, const void* d_w22blk, const float* d_bias22, const float* d_slope22,

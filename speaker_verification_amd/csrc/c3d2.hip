@@ -480,25 +480,26 @@ int svk_c3d2_stage1(svk_ctx* ctx, const float* d_feat, int32_t n_utt, int32_t ma
 namespace {
 
 constexpr int S2_D = 16, S2_H = 36, S2_W = 18;       // input of conv2_1 (after pool1), 16 channels
-constexpr int A2_D = 14, A2_W = 15;                  // conv2_1 output (32 channels), rows = S2_H
+constexpr int A2_D = 14, A2_W = 14;                  // conv2_1 output (32 channels), rows = S2_H.  The layer has 15 columns; pool2 drops
+                                                     // conv2_2's 15th, which is all that reads conv2_1's 15th (kernel width 1): never computed
 constexpr int O2_D = 12, O2_H = 15, O2_W = 7;        // after conv2_2 + pool2 (32 channels)
 
 // ---- conv2_1 through two-piece f16 products (see c3d2_stage1h_kernel): direct form, 12 taps = 6 pairs (kd, kw | kw + 1) of
 // K = 32 blocks, three MFMAs per pair and N tile (both N tiles of a wave share the B fragments).  Item = (cube, block of 4
 // rows) as before; its input [16 d][4 rows][18 w][16 c] is split into (h, l) while it is staged and lies in LDS as four planes
 // of 16-byte slots (h c0-7, h c8-15, l c0-7, l c8-15), slot = pixel (d * 4 + row) * 18 + col: the 16 positions of a tile --
-// ANY 16 consecutive outputs of the item's 14 d x 4 rows x 15 columns = 840 (52.5 tiles) -- read consecutive slots (+ 3 across a
+// ANY 16 consecutive outputs of the item's 14 d x 4 rows x 14 columns = 784 = 49 full tiles -- read consecutive slots (+ 4 across a
 // row end).  36 MFMAs of 16 cycles per tile where the depth-transformed f32 kernel issued 128 of 32 per 16 positions of a pair. ----
 constexpr int C21H_PIX = S2_D * 4 * S2_W;            // 1 152 pixels = slots per plane
 constexpr int C21H_LDS_WORDS = 4 * 4 * C21H_PIX;     // four planes of 16-byte slots: 73 728 bytes
-constexpr int C21H_POS = A2_D * 4 * A2_W;            // 840 output positions per item
+constexpr int C21H_POS = A2_D * 4 * A2_W;            // 784 output positions per item
 
 struct Conv21hParams {
   const float* in;      // [n][16][36][18][16]
   const u32x4* wblk;    // [2 nt][6 pairs][2][64]: lane (co = 16 nt + (l & 15), kk): e: W[co][8 (kk & 1) + e][kd][kw + (kk >= 2)], pair = 2 kd + kw / 2; H | L
   const float* bias;    // [32]
   const float* slope;   // [32]
-  float* out;           // [n][14][36][15][32]
+  float* out;           // [n][14][36][14][32]
   int32_t n_utt;
   unsigned* queue;
 };
@@ -568,12 +569,13 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21h_kernel(const Conv21hParam
     if (threadIdx.x == 0) q_next = p.queue ? (int)q_ticket + (int)gridDim.x : item + (int)gridDim.x;
     __syncthreads();
     const int item_next = q_next;
-    // tiles t = wave + 4 m of 16 positions P = 16 t + i -> (depth P / 60, row (P % 60) / 15, column P % 15); 53 tiles, the last half full
+    // tiles t = wave + 4 m of 16 positions P = 16 t + i -> (depth P / 56, row (P % 56) / 14, column P % 14); 49 tiles
+    static_assert(C21H_POS % 16 == 0 && A2_W == 14, "the position decode below is for 14 columns");
 #pragma unroll 1
-    for (int t = wave; t < (C21H_POS + 15) / 16; t += 4) {
-      const int P = min(16 * t + i, C21H_POS - 1);
-      const int dq = (P * 1093) >> 16, rem = P - 60 * dq;                       // P / 60 for P < 840
-      const int row = (rem * 4370) >> 16, col = rem - 15 * row;                 // rem / 15 for rem < 60
+    for (int t = wave; t < C21H_POS / 16; t += 4) {
+      const int P = 16 * t + i;
+      const int dq = (P * 1171) >> 16, rem = P - 56 * dq;                       // P / 56 for P < 784
+      const int row = (rem * 4682) >> 16, col = rem - 14 * row;                 // rem / 14 for rem < 56
       // input pixel (dq + kd, row, col + kw): slot (dq * 4 + row) * 18 + col + 72 kd + kw of plane (kk & 1) [l: + 2]; tap b = + 1 slot
       const char* const a2 = reinterpret_cast<const char*>(reg) + 16 * ((kk & 1) * C21H_PIX + (dq * 4 + row) * S2_W + col + (kk >= 2 ? 1 : 0));
       auto rd = [&](int pr, int piece) -> u32x4 {
@@ -600,11 +602,9 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21h_kernel(const Conv21hParam
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (16 * t + i < C21H_POS) {
-        float* const o = p.out + ((((int64_t)u * A2_D + dq) * S2_H + hb + row) * A2_W + col) * 32 + 4 * kk;
-        *reinterpret_cast<f32x4*>(o) = prelu4<SLOPE01>(acc[0], sl4[0]);
-        *reinterpret_cast<f32x4*>(o + 16) = prelu4<SLOPE01>(acc[1], sl4[1]);
-      }
+      float* const o = p.out + ((((int64_t)u * A2_D + dq) * S2_H + hb + row) * A2_W + col) * 32 + 4 * kk;
+      *reinterpret_cast<f32x4*>(o) = prelu4<SLOPE01>(acc[0], sl4[0]);
+      *reinterpret_cast<f32x4*>(o + 16) = prelu4<SLOPE01>(acc[1], sl4[1]);
     }
     __syncthreads();
     item = item_next;
@@ -625,7 +625,7 @@ constexpr int C22H_LDS_WORDS = 4 * 8 * C22H_PLANE;   // 71 680 bytes
 constexpr int C22H_POS = 4 * O2_H * 2;               // 120 positions per item
 
 struct Conv22hParams {
-  const float* in;      // [n][14][36][15][32]
+  const float* in;      // [n][14][36][14][32]
   const u32x4* wblk;    // [2 nt][24 taps][2][64]: lane (co = 16 nt + (l & 15), kk): e: W[co][8 kk + e][kd][kh], tap = 8 kd + kh; H | L
   const float* bias;    // [32]
   const float* slope;   // [32]

@@ -483,7 +483,7 @@ class Engine:
         if w21.dtype != torch.float16 or w22.dtype != torch.float16 or tuple(w21.shape) != (2, 6, 2, 64, 8) or tuple(w22.shape) != (2, 24, 2, 64, 8):
             raise ValueError("c3d2_stage2 wants the half-pair weight blocks of FusedEmbedder.stage2_tables()")
         slope01 = bool(tables[6]) if len(tables) > 6 else False
-        act2 = torch.empty((n, 14, 36, 15, 32), dtype=torch.float32, device=self.device)
+        act2 = torch.empty((n, 14, 36, 14, 32), dtype=torch.float32, device=self.device)   # scratch: the 14 columns of conv2_1 that pool2 leaves alive
         out = torch.empty((n, 12, 15, 7, 32), dtype=torch.float32, device=self.device)
         self._stream()
         check(self.lib.svk_c3d2_stage2(self.ctx, self._ptr(act1), n, self._ptr(w21), self._ptr(b21), self._ptr(s21),

@@ -38,7 +38,7 @@ kernels = {
     # the first block runs two-piece f16 products: its MFMAs (v_mfma_f32_16x16x32_f16, 16 cycles) counted in units of the f32 MFMA's
     # 32 cycles -- 36 items x (100 conv1_1 tiles x 2 + 36 conv1_2 tiles x 42) / 2 -- so that "issued" stays a share of issue TIME
     "stage1": (lambda: eng.c3d2_stage1(feat, crops, emb.stage1_tables()), 36 * (100 * 2 + 36 * 42) / 2, 155.768832e6),
-    "stage2": (lambda x=rnd(n, 16, 36, 18, 16): eng.c3d2_stage2(x, emb.stage2_tables()), (9 * 53 * 36 + 21 * 8 * 2 * 72) / 2, 112.80384e6),
+    "stage2": (lambda x=rnd(n, 16, 36, 18, 16): eng.c3d2_stage2(x, emb.stage2_tables()), (9 * 49 * 36 + 21 * 8 * 2 * 72) / 2, 112.80384e6),
     "conv3_1": (lambda x=rnd(n, 12, 15, 7, 32): eng.c3d2_conv31(x, emb.conv31_tables()), 5 * 10 * 4 * 27 / 2, 13.824e6),
     "conv3_2": (lambda x=rnd(n, 10, 8, 5, 15, 8): eng.c3d2_conv32t(x, emb.conv32t_tables()), 5 * 5 * 4 * 126 / 2, 30.96576e6),
     "conv4_1": (lambda x=rnd(n, 8, 8, 45, 8): eng.c3d2_conv41(x, emb.conv41_tables()), 11 * 8 * 54 / 2, 11.943936e6),
