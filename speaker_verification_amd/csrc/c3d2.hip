@@ -499,7 +499,7 @@ struct Conv21hParams {
   const u32x4* wblk;    // [2 nt][6 pairs][2][64]: lane (co = 16 nt + (l & 15), kk): e: W[co][8 (kk & 1) + e][kd][kw + (kk >= 2)], pair = 2 kd + kw / 2; H | L
   const float* bias;    // [32]
   const float* slope;   // [32]
-  float* out;           // [n][14][36][14] positions of 128 bytes: the 32 channels as half pairs, eight 16-byte slots [h q0 .. q3][l q0 .. q3]
+  float* out;           // [n][14][36][14][32]
   int32_t n_utt;
   unsigned* queue;
 };
@@ -602,19 +602,9 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21h_kernel(const Conv21hParam
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // the pieces are made HERE (this kernel waits on HBM: the twelve vector instructions are free) and conv2_2 stages them with
-      // plain 16-byte copies: a position's 128 bytes are eight 16-byte slots [h c0-7][h c8-15][h c16-23][h c24-31][l ...] -- the
-      // planes conv2_2 keeps in LDS; this lane's four channels 16 nt + 4 kk .. + 3 are bytes 8 (kk & 1) .. + 7 of slot 2 nt + kk / 2
-      unsigned* const o = reinterpret_cast<unsigned*>(p.out) + ((((int64_t)u * A2_D + dq) * S2_H + hb + row) * A2_W + col) * 32 + 4 * (kk >> 1) + 2 * (kk & 1);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const f32x4 y = prelu4<SLOPE01>(acc[nt], sl4[nt]);
-        unsigned h0, l0, h1, l1;
-        split2(__builtin_shufflevector(y, y, 0, 1), h0, l0);
-        split2(__builtin_shufflevector(y, y, 2, 3), h1, l1);
-        *reinterpret_cast<u32x2*>(o + 8 * nt) = (u32x2){h0, h1};
-        *reinterpret_cast<u32x2*>(o + 8 * nt + 16) = (u32x2){l0, l1};
-      }
+      float* const o = p.out + ((((int64_t)u * A2_D + dq) * S2_H + hb + row) * A2_W + col) * 32 + 4 * kk;
+      *reinterpret_cast<f32x4*>(o) = prelu4<SLOPE01>(acc[0], sl4[0]);
+      *reinterpret_cast<f32x4*>(o + 16) = prelu4<SLOPE01>(acc[1], sl4[1]);
     }
     __syncthreads();
     item = item_next;
@@ -623,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv21h_kernel(const Conv21hParam
 
 // ---- conv2_2 + pool2 through two-piece f16 products: direct form, K = 32 = the 32 input channels of ONE tap, three MFMAs per
 // tap (H x h, H x l, L x h), 24 taps.  Item = (cube, pooled column j, third q of the output depths) as before; its input
-// [6 d][36 h][2 w][32 c] arrives as the half pairs conv2_1 wrote and is copied into eight planes (four channel quarters x {h, l}) of 16-byte slots, a plane
+// [6 d][36 h][2 w][32 c] is split while it is staged: eight planes (four channel quarters x {h, l}) of 16-byte slots, a plane
 // split by the parity of the row (rows are 2 apart along a tile): slot ((r & 1) * 6 + d) * 46 + (r >> 1) * 2 + col.  The item's
 // 4 d x 15 rows x 2 columns = 120 positions are 7.5 tiles of 16; wave = (N tile nt, every other tile): the 48 weight blocks of an
 // N tile are 192 VGPRs.  Pool = max over adjacent lanes (the column pair), the even lane stores four channels. ----
@@ -635,7 +625,7 @@ constexpr int C22H_LDS_WORDS = 4 * 8 * C22H_PLANE;   // 71 680 bytes
 constexpr int C22H_POS = 4 * O2_H * 2;               // 120 positions per item
 
 struct Conv22hParams {
-  const float* in;      // [n][14][36][14] positions of 128 bytes as conv2_1 writes them (half pairs in eight 16-byte slots)
+  const float* in;      // [n][14][36][14][32]
   const u32x4* wblk;    // [2 nt][24 taps][2][64]: lane (co = 16 nt + (l & 15), kk): e: W[co][8 kk + e][kd][kh], tap = 8 kd + kh; H | L
   const float* bias;    // [32]
   const float* slope;   // [32]
@@ -671,8 +661,7 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22h_kernel(const Conv22hParam
     unsigned q_ticket = 0;
     if (threadIdx.x == 0 && p.queue) q_ticket = atomicAdd(p.queue, 1u);
     const int u = item / PER_CUBE, rem = item - u * PER_CUBE, q = rem / O2_W, j = rem - q * O2_W;
-    // stage: piece e = t + 256 k = 16-byte slot e & 7 (plane: h quarters 0 - 3, l quarters 0 - 3) of pixel (dh = (t >> 4) + 16 k, column
-    // (e >> 3) & 1), dh = d * 36 + h: conv2_1 wrote the half pairs, this is a copy
+    // stage + split: piece e = t + 256 k: channels 4 (e & 7) .. + 3 of pixel (dh = (t >> 4) + 16 k, column (e >> 3) & 1), dh = d * 36 + h
     const float* src = p.in + ((int64_t)u * A2_D + 4 * q) * (S2_H * A2_W * 32) + 2 * j * 32;
     {
       int tl = threadIdx.x;
@@ -682,10 +671,10 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22h_kernel(const Conv22hParam
       constexpr int NV = 7;   // (all 14 in flight spill: the 192 weight registers stay live)
 #pragma unroll
       for (int r0 = 0; r0 < 14; r0 += NV) {
-        u32x4 sv[NV];
+        f32x4 sv[NV];
 #pragma unroll
         for (int k = r0; k < r0 + NV; ++k)
-          if (k < 13 || tl < 128) sv[k - r0] = *reinterpret_cast<const u32x4*>(g0 + (int64_t)(16 * k) * (A2_W * 32));
+          if (k < 13 || tl < 128) sv[k - r0] = *reinterpret_cast<const f32x4*>(g0 + (int64_t)(16 * k) * (A2_W * 32));
 #pragma unroll
         for (int k = r0; k < r0 + NV; ++k) {
           // dh = dh0 + 16 k -> (d, h): 16 k = 36 d_lo + h_lo at compile time, one comparison for the carry
@@ -697,7 +686,14 @@ __global__ __launch_bounds__(256, 2) void c3d2_conv22h_kernel(const Conv22hParam
             d = carry ? d + 1 : d;
           }
           const int slot = ((hh & 1) * 6 + d) * C22H_DP + (hh >> 1) * 2 + wq;
-          if (k < 13 || tl < 128) *reinterpret_cast<u32x4*>(reg + 4 * (piece * C22H_PLANE + slot)) = sv[k - r0];
+          unsigned* const dst = reg + 4 * ((piece >> 1) * C22H_PLANE + slot) + 2 * (piece & 1);
+          unsigned h0, l0, h1, l1;
+          split2(__builtin_shufflevector(sv[k - r0], sv[k - r0], 0, 1), h0, l0);
+          split2(__builtin_shufflevector(sv[k - r0], sv[k - r0], 2, 3), h1, l1);
+          if (k < 13 || tl < 128) {
+            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+            *reinterpret_cast<u32x2*>(dst + 4 * 4 * C22H_PLANE) = (u32x2){l0, l1};
+          }
         }
       }
     }
