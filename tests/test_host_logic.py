@@ -351,6 +351,32 @@ def test_tables_do_not_depend_on_how_a_checkpoint_scales_its_channels():
     assert float(w.abs().amax(dim=(0, 2, 3, 4)).min()) < 2.0 ** -9
 
 
+def test_checkpoints_outside_the_half_pairs_range_are_refused():
+    """A BatchNorm-folded weight that no half can hold (not finite, or 65 504 and more once the channel scales are fixed) raises
+    when the operand tables are built -- before any kernel could turn it into an infinity."""
+    import pytest
+    import torch
+    from speaker_verification_amd.model import FusedEmbedder, seeded_model
+    m = seeded_model(7, 8).eval()
+    with torch.no_grad():
+        m.conv2_1.weight[3, 2, 1, 0, 1] = 1.0e6
+    with pytest.raises(ValueError, match="65 504"):
+        FusedEmbedder(m)
+    m = seeded_model(7, 8).eval()
+    with torch.no_grad():
+        m.batch_norm3_1.running_var[5] = float("nan")
+    with pytest.raises(ValueError, match="not finite"):
+        FusedEmbedder(m)
+    # ... while a channel that is merely carried large is not: its scale is fixed first
+    m = seeded_model(7, 8).eval()
+    with torch.no_grad():
+        m.batch_norm2_1.weight.mul_(1.0e6)
+        m.batch_norm2_1.bias.mul_(1.0e6)
+        m.conv2_2.weight.div_(1.0e6)
+    e = FusedEmbedder(m)
+    assert float(e.act_scale[2].max()) == 2.0 ** -20 and float(e.stages[2][0].abs().max()) < 16.0
+
+
 def test_upload_groups_of_a_host_arena():
     """`VerificationPipeline._upload_groups` (embed_ragged_resident on a host arena): pieces tile the arena, every clip lies
     inside its group's piece, pieces stay under the cap unless one clip alone exceeds it, arena order need not be list order."""
