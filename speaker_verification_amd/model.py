@@ -214,7 +214,9 @@ class FusedEmbedder:
             raise ValueError("expected cubes of shape (n, 1, 20, 80, 40), got %s" % (tuple(cubes.shape),))
         x = self.eng.to_device(cubes, torch.float32)
         n = x.shape[0]
-        if n and not float(x.abs().max()) < 65504.0:      # (this per-call surface only: the batched pipeline feeds its own features)
+        if n:       # (this per-call surface only: the batched pipeline feeds its own features; aminmax: no temporary, NaN propagates)
+            lo, hi = (float(v) for v in torch.aminmax(x))
+        if n and not (lo > -65504.0 and hi < 65504.0):
             raise ValueError("cube values must be finite and below 65 504 in magnitude (the half-pair kernels' domain, include/svk.h); "
                              "the reference's features are log energies / MFCCs within +-100")
         rows = x.view(n, CUBE_SHAPE[1] * CUBE_SHAPE[2], CUBE_SHAPE[3])
