@@ -96,8 +96,12 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--corpus", type=int, default=N_CORPUS, help="clips in the whole job (all ranks), per step")
-    ap.add_argument("--micro-batch", type=int, default=4096,
-                    help="clips per launch sequence (4 096: +2.4 % over 1 024: fewer persistent-kernel tails and launch gaps)")
+    ap.add_argument("--micro-batch", type=int, default=0,
+                    help="clips per launch sequence; 0 (default) = the shard in as few equal sequences as fit in 0.6 of the free HBM at ~2 MB of live "
+                         "intermediates per clip (one MI355X: the 148 642-clip corpus in two sequences of 74 321, 146 GB at the "
+                         "peak).  Measured on one box: 4 096 -> 402 k utt/s, 16 384 -> 412 k, 32 768 -> 419 k; another: 32 768 -> "
+                         "415.6 k, 74 321 -> 421.8 k -- every launch of a persistent kernel drains and refills the chip; the "
+                         "embeddings do not depend on the batching, bit for bit (tools/check_micro_batch.py)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="clips of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--no-vad", action="store_true")
     ap.add_argument("--no-cmvn", action="store_true")
@@ -890,6 +894,16 @@ def main():
     n_local = hi_r - lo_r
     pcm, _ = synth.corpus_device(n_local, dev, first_clip=lo_r, utts_per_speaker=UTTS_PER_SPK)
     model, weights_meta = bench_model()
+    if args.micro_batch <= 0:
+        # live per clip while the second block runs: 663 552 (after pool1) + 903 168 (conv2_1's scratch) + 161 280 (after pool2)
+        # + 47 520 (features) + the VAD's index and slack: ~2 MB.  The corpus is already resident: mem_get_info sees what is left
+        # (a whole number of equal sequences: 148 642 clips on one 288 GB card = 2 x 74 321, and still 2 with 20 GB less free)
+        try:
+            free_bytes, _ = torch.cuda.mem_get_info(dev)
+            sequences = max(1, int(np.ceil(n_local * 2.0e6 / (0.6 * free_bytes))))
+            args.micro_batch = max(1024, -(-n_local // sequences))
+        except RuntimeError:
+            args.micro_batch = 4096
     pipe = VerificationPipeline(model, use_vad=not args.no_vad, normalize=not args.no_cmvn,
                                 preemph_cof=None if args.no_preemph else 0.98, crop_rng="device",
                                 micro_batch=args.micro_batch,
@@ -1145,6 +1159,10 @@ def main():
         }
 
     if rank == 0 and world == 1 and not args.no_extras and not args.parity_only:
+        # the side entries keep round 4's 4 096-clip launch sequences (their numbers stay comparable, and a host-fed run of
+        # 8 x 74 321 clips would copy the whole corpus to the host four times)
+        pipe.micro_batch = min(pipe.micro_batch, 4096)
+        spans = pipe.chunks(n_local)
         # host-fed variant (PCIe included; NOT `value`): 8 micro-batches of the shard from pageable host memory (the
         # first batch's H2D copy is not overlapped)
         n_host = min(n_local, 8 * (spans[0][1] - spans[0][0]))
