@@ -900,6 +900,7 @@ def main():
         # (a whole number of equal sequences: 148 642 clips on one 288 GB card = 2 x 74 321, and still 2 with 20 GB less free)
         try:
             free_bytes, _ = torch.cuda.mem_get_info(dev)
+            free_bytes /= max(1, -(-world // max(1, torch.cuda.device_count())))     # (ranks rehearsing on one card share it)
             sequences = max(1, int(np.ceil(n_local * 2.0e6 / (0.6 * free_bytes))))
             args.micro_batch = max(1024, -(-n_local // sequences))
         except RuntimeError:
