@@ -936,7 +936,9 @@ def main():
         # timed region: everything from resident PCM to the score matrix
         pipe.kernel_events = [] if record and pipe.kernel_events is None else pipe.kernel_events
         local = torch.empty((n_local, 128), dtype=torch.float32, device=dev)
-        for lo, hi in spans:
+        # SVK_BENCH_OVERLAP=1: the pipeline's own two-stream form (the front of sequence k + 1 on a side stream under the network
+        # of sequence k: VerificationPipeline._embed_overlapped) instead of the loop below -- an experiment switch, off by default
+        for lo, hi in ([] if (pipe.overlap_front and len(spans) > 1) else spans):
             chunk = pcm[lo:hi]
             vlen, gather = pipe.vad(chunk)
             if record:
@@ -950,6 +952,8 @@ def main():
                 eng.cmvn_(feat, n_frames, variance=True)
             idx = eng.draw_crops(n_frames, c.CUBE_CROPS, c.CUBE_FRAMES, pipe.crop_seed, lo_r + lo, pipe.bad_clips)
             local[lo:hi] = pipe.embed_features(feat, idx)      # feature rows + crop starts -> the seven network kernels
+        if pipe.overlap_front and len(spans) > 1:
+            local = pipe.embed(pcm, first_utt=lo_r)
         if record:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
